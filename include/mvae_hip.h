@@ -1,0 +1,252 @@
+/*
+ * mvae_hip.h -- C ABI of libmvae_hip.so: the MVAE train-step kernels for MI355X (gfx950).
+ *
+ * The reference (mhw32/multimodal-vae-public) has no FFI: its hot path is a chain of
+ * PyTorch ATen ops dispatched from model.py / train.py.  Each entry point below
+ * replaces the ATen op(s) at the cited reference call sites (paths relative to the
+ * reference repository root; SURVEY.md section 2.2 is the op inventory K1..K15).
+ *
+ * Conventions
+ *   - every tensor is fp32, contiguous unless a leading dimension is given, NCHW for images;
+ *     class labels are int64;
+ *   - all pointers are DEVICE pointers borrowed for the duration of the enqueue; the
+ *     library never allocates, frees or retains device memory; scratch is passed in
+ *     (`ws`, `ws_bytes`; size it with the matching *_ws_bytes query);
+ *   - `stream` is a hipStream_t passed as void*; kernels are asynchronous, no host sync;
+ *   - return 0 on success, <0 on error (MVAE_ERR_*); no C++ exception crosses the ABI;
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef MVAE_HIP_H
+#define MVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVAE_OK          0
+#define MVAE_ERR_ARG    (-1)   /* bad shape / null pointer / unsupported stride */
+#define MVAE_ERR_LAUNCH (-2)   /* hipLaunchKernel reported an error */
+#define MVAE_ERR_WS     (-3)   /* workspace too small */
+
+/* flags */
+#define MVAE_ACT_SWISH   1     /* fwd: also write swish(out); bwd: multiply by swish'(preact) */
+#define MVAE_ACCUMULATE  2     /* add into the destination instead of overwriting it */
+
+#define MVAE_POE_VARIANT_A 0   /* mnist/model.py:156-163, fashionmnist/model.py:175-182 */
+#define MVAE_POE_VARIANT_B 1   /* celeba/model.py:200-207, celeba19/model.py:219-226 */
+#define MVAE_MAX_EXPERTS  32
+
+typedef void *mvae_stream_t;   /* hipStream_t */
+
+int mvae_abi_version(void);
+/* number of bytes of scratch any GEMM-shaped wgrad call below may need for this shape */
+size_t mvae_wgrad_ws_bytes(int rows_out, int cols_out, int reduce_len);
+
+/* ------------------------------------------------------------------------------------
+ * K1  Linear (nn.Linear forward / backward): mnist/model.py:75-78,95-98,117-119,136-139;
+ *     fashionmnist/model.py:84-86,107-109,135-137,155-161; celeba/model.py:89-92,114,
+ *     148-154,175-184; celeba19/model.py:115-118,140,176-178,199-205.
+ * K5  Swish (x*sigmoid(x), mnist/model.py:166-169) and K7 Dropout(0.1) (celeba/model.py:91)
+ *     are fused into the epilogues.
+ *
+ * fwd : pre[M,N] = x[M,K] . w[N,K]^T + bias[N]         (pre may be NULL when act given)
+ *       act[M,N] = swish(pre) * (mask ? mask*mask_scale : 1)   (if act != NULL)
+ * dgrad: dx[M,K] (+)= (dy[M,N] . w[N,K]) * (mask ? mask*mask_scale : 1) * swish'(pre_in)
+ *        (pre_in = pre-activation that produced this layer's INPUT, NULL for none)
+ * wgrad: dw[N,K] (+)= dy^T . x ;  db[N] (+)= sum_m dy   (db may be NULL)
+ * ---------------------------------------------------------------------------------- */
+int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
+                    float *pre, float *act, int ldy,
+                    const float *mask, float mask_scale,
+                    int M, int N, int K, mvae_stream_t stream);
+int mvae_linear_dgrad(const float *dy, int lddy, const float *w,
+                      float *dx, int lddx,
+                      const float *pre_in, const float *mask, float mask_scale,
+                      int M, int N, int K, int flags, mvae_stream_t stream);
+int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
+                      float *dw, float *db, int M, int N, int K, int flags,
+                      void *ws, size_t ws_bytes, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  Conv2d 4x4, bias=False, (stride,pad) in {(2,1),(1,0)}: fashionmnist/model.py:79,81;
+ *     celeba/model.py:77,79,82,85; celeba19/model.py:103,105,108,111.
+ *     Implicit im2col GEMM on fp32 MFMA; x[B,Cin,H,W], w[Cout,Cin,4,4], y[B,Cout,OH,OW].
+ *     fwd  : pre = conv(x,w) ; act = swish(pre) (either may be NULL)
+ *     dgrad: dx (+)= conv^T(dy,w) * swish'(pre_in)   (pre_in NULL for none)
+ *     wgrad: dw (+)= correlate(x, dy)
+ * K3  ConvTranspose2d 4x4, bias=False: fashionmnist/model.py:112,114; celeba/model.py:117,
+ *     120,123,126; celeba19/model.py:143,146,149,152.  w[Cin,Cout,4,4].  Forward of the
+ *     transpose is the dgrad of the mirrored conv and vice versa.
+ * ---------------------------------------------------------------------------------- */
+int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act,
+                       int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                       mvae_stream_t stream);
+int mvae_conv2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in,
+                         int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                         mvae_stream_t stream);
+int mvae_conv2d_k4_wgrad(const float *dy, const float *x, float *dw,
+                         int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                         int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
+int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, float *act,
+                        int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                        mvae_stream_t stream);
+int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in,
+                          int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                          mvae_stream_t stream);
+int mvae_convT2d_k4_wgrad(const float *dy, const float *x, float *dw,
+                          int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                          int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  BatchNorm2d / BatchNorm1d (training mode, eps 1e-5, momentum 0.1) + fused Swish:
+ *     celeba/model.py:80,83,86,118,121,124,149,152,176,179,182; celeba19/model.py:106,109,
+ *     112,144,147,150.  x is [G*B, C, HW] (HW = 1 for BatchNorm1d): G independent groups
+ *     of B samples, each normalised with its own batch statistics -- G > 1 lets one launch
+ *     serve the G model() calls of a train step that the reference issues separately.
+ *     Running statistics are updated sequentially for g = 0..G-1, each `n_updates` times
+ *     (unbiased variance for the running estimate, biased for normalisation).
+ *     save_mean / save_invstd are [G, C].  ws: mvae_bn_ws_bytes(G, C, B*HW).
+ *     eval: y = swish?((x - running_mean) / sqrt(running_var + eps) * gamma + beta).
+ * ---------------------------------------------------------------------------------- */
+size_t mvae_bn_ws_bytes(int G, int C, int n_per_group);
+int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                      float *save_mean, float *save_invstd,
+                      float *running_mean, float *running_var,
+                      int G, int B, int C, int HW, float eps, float momentum,
+                      int n_updates, int flags, void *ws, size_t ws_bytes,
+                      mvae_stream_t stream);
+int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
+                      const float *save_mean, const float *save_invstd,
+                      float *dx, float *dgamma, float *dbeta,
+                      int G, int B, int C, int HW, int flags,
+                      void *ws, size_t ws_bytes, mvae_stream_t stream);
+int mvae_bn_eval_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                     const float *running_mean, const float *running_var,
+                     int N, int C, int HW, float eps, int flags, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  stand-alone Swish (only where no producer epilogue can host it).
+ * K6  Embedding lookup + Swish and its scatter-add backward: mnist/model.py:116,123;
+ *     fashionmnist/model.py:133; celeba19/model.py:174,183.
+ *     fwd: act[r,:] = swish(w[idx[r],:]) ; bwd: dw[c,:] (+)= sum_{r: idx[r]==c} dact[r,:]*swish'(w[c,:])
+ *     idx is int64 (labels) or, with idx_is_float, the {0,1} floats celeba19 casts by .long().
+ * ---------------------------------------------------------------------------------- */
+int mvae_swish_fwd(const float *x, float *y, size_t n, mvae_stream_t stream);
+int mvae_swish_bwd(const float *dy, const float *x, float *dx, size_t n, mvae_stream_t stream);
+int mvae_embedding_swish_fwd(const void *idx, int idx_is_float, const float *w, float *act,
+                             int R, int n_classes, int width, mvae_stream_t stream);
+int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, const float *w,
+                             const float *dact, float *dw,
+                             int R, int n_classes, int width, int flags, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K8-K10, K12  prior expert + product of experts + reparameterise + analytic KL, fused:
+ *     mnist/model.py:29-35,46-64,156-163,172-185; celeba/model.py:200-207;
+ *     celeba19/model.py:63-89,219-226; KL: mnist/train.py:56, celeba/train.py:62,
+ *     celeba19/train.py:58.
+ *     E experts (the N(0,1) prior is implicit and always present) given as mu_e/logvar_e
+ *     pointers with a common row stride `ld`; T terms, term t fuses the experts whose bit
+ *     is set in masks[t] (DEVICE uint32[T], so a captured graph can be replayed with new
+ *     subsets).  noise is [T,B,D] or NULL (eval: z = mu).
+ *     fwd outputs mu/logvar/z [T,B,D] and kl[T,B] = -0.5*sum_d(1+lv-mu^2-exp(lv)).
+ *     bwd inputs: dz, dmu, dlogvar [T,B,D] and dkl [T,B] = d loss / d kl (any may be NULL);
+ *     outputs the per-expert gradients, summed over the terms that contain the expert.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    const float *mu[MVAE_MAX_EXPERTS];
+    const float *logvar[MVAE_MAX_EXPERTS];
+} mvae_experts_t;
+typedef struct {
+    float *dmu[MVAE_MAX_EXPERTS];
+    float *dlogvar[MVAE_MAX_EXPERTS];
+} mvae_expert_grads_t;
+
+int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E,
+                 const uint32_t *masks_dev, int T,
+                 const float *noise, float *mu, float *logvar, float *z, float *kl,
+                 int B, int D, int variant, mvae_stream_t stream);
+int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E,
+                 const uint32_t *masks_dev, int T,
+                 const float *noise, const float *mu, const float *logvar,
+                 const float *dz, const float *dmu, const float *dlogvar,
+                 const float *dkl, int dkl_per_term /* dkl is [T] (beta/B per term) instead of [T,B] */,
+                 const mvae_expert_grads_t *grads, int ldg,
+                 int B, int D, int variant, mvae_stream_t stream);
+
+/* stand-alone reparameterised draw for the public MVAE.reparametrize (mnist/model.py:29-35):
+ * z = eps * exp(0.5 * logvar) + mu */
+int mvae_reparam_fwd(const float *mu, const float *logvar, const float *eps, float *z, size_t n,
+                     mvae_stream_t stream);
+int mvae_reparam_bwd(const float *dz, const float *logvar, const float *eps,
+                     float *dmu, float *dlogvar, size_t n, mvae_stream_t stream);
+
+/* stand-alone KL rows for the reference-surface elbo_loss(mu, logvar) (mnist/train.py:56) */
+int mvae_kl_rows_fwd(const float *mu, const float *logvar, float *kl, int B, int D,
+                     mvae_stream_t stream);
+int mvae_kl_rows_bwd(const float *mu, const float *logvar, const float *dkl,
+                     float *dmu, float *dlogvar, int B, int D, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K11 BCE-with-logits row sums: mnist/train.py:47-49,62-74; celeba/train.py:50-58,68-80;
+ *     celeba19/train.py:52-57,63-75.  logits/target [R,P];
+ *     rowsum[r] = sum_p colw[(r / rows_per_group), p] * bce(logits[r,p], target[r % target_rows, p])
+ *     (colw NULL -> 1).  target is broadcast over row groups by `target_rows`.
+ *     bwd: dlogits[r,p] = drow[r / rows_per_group] * colw * dbce/dx  (drow is a DEVICE array;
+ *     d loss / d rowsum is the constant lambda/B, so the fwd entry can emit it in the same pass).
+ * K13 categorical CE: mnist/train.py:52,77-94.  row[r] = -log_softmax(logits[r,:]+1e-6)[label[r % label_rows]]
+ * K14 ELBO combine: total = sum_r coef[r / rows_per_group] * rows[r]  (mnist/train.py:57-58,214)
+ * ---------------------------------------------------------------------------------- */
+int mvae_bce_rowsum_fwd(const float *logits, const float *target, const float *colw,
+                        float *rowsum, const float *drow_dev, float *dlogits /* nullable: fused bwd */,
+                        int R, int P, int rows_per_group, int target_rows,
+                        mvae_stream_t stream);
+int mvae_bce_rowsum_bwd(const float *logits, const float *target, const float *colw,
+                        const float *drow_dev, float *dlogits,
+                        int R, int P, int rows_per_group, int target_rows,
+                        mvae_stream_t stream);
+int mvae_ce_fwd(const float *logits, const int64_t *label, float *row,
+                const float *drow_dev, float *dlogits /* nullable: fused bwd */,
+                int R, int K, int rows_per_group, int label_rows, mvae_stream_t stream);
+int mvae_ce_bwd(const float *logits, const int64_t *label, const float *drow_dev,
+                float *dlogits, int R, int K, int rows_per_group, int label_rows,
+                mvae_stream_t stream);
+/* out[g] (+)= coef[g] * sum_{r in group g} rows[r] for g < G; *total_out (+)= sum_g of those
+ * (either destination may be NULL) */
+int mvae_group_sums(const float *rows, const float *coef_dev, float *out, float *total_out,
+                    int G, int rows_per_group, int flags, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K10 noise: counter-based Philox4x32-10 on device (perf mode; parity mode passes the
+ *     host-drawn noise of the reference's CPU generator instead).  `counter_dev` is a
+ *     device uint64 advanced by the kernel itself, so a captured hipGraph replays fresh noise.
+ * K15 Adam (torch.optim.Adam defaults, mnist/train.py:168,219), one launch over the flat
+ *     parameter arena; `step_dev` is a device int64 incremented by the kernel.
+ * ---------------------------------------------------------------------------------- */
+int mvae_randn(float *out, size_t n, uint64_t seed, uint64_t *counter_dev, mvae_stream_t stream);
+int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t seed, uint64_t *counter_dev,
+                   mvae_stream_t stream);
+int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   size_t n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   int64_t *step_dev, mvae_stream_t stream);
+int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
+
+/* K7 Dropout fan-out (celeba/model.py:89-92 runs twice per step on the same batch; only the
+ *    Bernoulli draw differs): out[g,b,:] = h[b,:] * masks[g,b,:] * scale, and its backward
+ *    dh[b,:] = sum_g dout[g,b,:] * masks[g,b,:] * scale. */
+int mvae_dropout_fanout_fwd(const float *h, const float *masks, float *out, float scale,
+                            int G, int B, int N, mvae_stream_t stream);
+int mvae_dropout_fanin_bwd(const float *dout, const float *masks, float *dh, float scale,
+                           int G, int B, int N, mvae_stream_t stream);
+/* elementwise BCE-with-logits, the reference helper's own shape (mnist/train.py:62-74) */
+int mvae_bce_elem_fwd(const float *logits, const float *target, float *out, size_t n,
+                      mvae_stream_t stream);
+int mvae_bce_elem_bwd(const float *logits, const float *target, const float *g,
+                      float *dlogits, float *dtarget, size_t n, mvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVAE_HIP_H */

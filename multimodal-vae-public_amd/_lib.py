@@ -1,0 +1,106 @@
+"""ctypes binding of libmvae_hip.so (the C ABI declared in include/mvae_hip.h).
+
+The library is the product: there is no CPU / eager-PyTorch fallback.  ``lib()`` raises
+``RuntimeError`` when the shared object has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C multimodal-vae-public_amd/csrc``), and every
+wrapper in ``ops.py`` raises when it is handed a non-GPU tensor.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmvae_hip.so')
+
+MVAE_OK = 0
+ERRORS = {-1: 'MVAE_ERR_ARG (bad shape / null pointer / unsupported stride)',
+          -2: 'MVAE_ERR_LAUNCH (hip kernel launch failed)',
+          -3: 'MVAE_ERR_WS (workspace too small)'}
+ACT_SWISH = 1
+ACCUMULATE = 2
+POE_VARIANT = {'A': 0, 'B': 1}
+MAX_EXPERTS = 32
+MAX_TERMS = 40
+
+
+class Experts(ctypes.Structure):
+    _fields_ = [('mu', c_void_p * MAX_EXPERTS), ('logvar', c_void_p * MAX_EXPERTS)]
+
+
+class ExpertGrads(ctypes.Structure):
+    _fields_ = [('dmu', c_void_p * MAX_EXPERTS), ('dlogvar', c_void_p * MAX_EXPERTS)]
+
+
+P = c_void_p
+_SIGNATURES = {
+    'mvae_abi_version': (c_int, []),
+    'mvae_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mvae_linear_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_float, c_int, c_int, c_int, P]),
+    'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P]),
+    'mvae_linear_wgrad': (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'mvae_conv2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_conv2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_conv2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),
+    'mvae_convT2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_convT2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_convT2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),
+    'mvae_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mvae_bn_train_fwd': (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, c_int, P, c_size_t, P]),
+    'mvae_bn_train_bwd': (c_int, [P] * 9 + [c_int] * 5 + [P, c_size_t, P]),
+    'mvae_bn_eval_fwd': (c_int, [P] * 6 + [c_int] * 3 + [c_float, c_int, P]),
+    'mvae_swish_fwd': (c_int, [P, P, c_size_t, P]),
+    'mvae_swish_bwd': (c_int, [P, P, P, c_size_t, P]),
+    'mvae_embedding_swish_fwd': (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
+    'mvae_embedding_swish_bwd': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_poe_fwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P,
+                             c_int, c_int, c_int, P]),
+    'mvae_poe_bwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P, P, P, c_int,
+                             ctypes.POINTER(ExpertGrads), c_int, c_int, c_int, c_int, P]),
+    'mvae_kl_rows_fwd': (c_int, [P, P, P, c_int, c_int, P]),
+    'mvae_kl_rows_bwd': (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    'mvae_bce_rowsum_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_bce_rowsum_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_ce_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_ce_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'mvae_randn': (c_int, [P, c_size_t, c_uint64, P, P]),
+    'mvae_bernoulli': (c_int, [P, c_size_t, c_float, c_uint64, P, P]),
+    'mvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P, P]),
+    'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
+    'mvae_reparam_fwd': (c_int, [P, P, P, P, c_size_t, P]),
+    'mvae_reparam_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
+    'mvae_dropout_fanout_fwd': (c_int, [P, P, P, c_float, c_int, c_int, c_int, P]),
+    'mvae_dropout_fanin_bwd': (c_int, [P, P, P, c_float, c_int, c_int, c_int, P]),
+    'mvae_bce_elem_fwd': (c_int, [P, P, P, c_size_t, P]),
+    'mvae_bce_elem_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/mvae_hip.h declares (the not-gpu tests check the .so exports each)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libmvae_hip.so is not built (%s missing): run `make -C %s/csrc`; there is no '
+                'CPU fallback for the MVAE HIP path.' % (LIB_PATH, _HERE))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if handle.mvae_abi_version() != 1:
+            raise RuntimeError('libmvae_hip.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != MVAE_OK:
+        raise RuntimeError('%s failed: %s' % (what, ERRORS.get(rc, 'error %d' % rc)))

@@ -1,0 +1,124 @@
+"""Shared machinery of the four MVAE modules (mnist / fashionmnist / celeba / celeba19).
+
+Mirrors the reference's ``MVAE`` surface (mnist/model.py:14-64):
+``MVAE(n_latents)``, ``forward(image=None, text=None)`` (kwarg ``attrs`` for CelebA) returning
+``(image_recon, label_recon, mu, logvar)``, ``infer``, ``reparametrize``, and the sub-module
+attributes ``image_encoder / image_decoder / text_encoder / ...`` that ``sample.py`` calls
+directly.  All arithmetic is HIP (``layers.py`` stacks + ``functional.py`` latent path).
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import layers as L
+from .arena import ParamArena
+from .functional import PoEFn, ReparamFn
+
+
+class Stack(nn.Module):
+    """An encoder or decoder: ``self.stack_modules()`` lists its layers in execution order;
+    the compiled plan runs them as fused HIP launches."""
+    def stack_modules(self):
+        raise NotImplementedError
+
+    def plan(self):
+        p = self.__dict__.get('_plan')
+        if p is None:
+            p = L.compile_plan(self.stack_modules())
+            self.__dict__['_plan'] = p
+        return p
+
+    def run(self, x, groups=1, masks=None, bn_updates=1):
+        return L.run_plan(self.plan(), x, groups=groups, masks=masks, bn_updates=bn_updates,
+                          training=self.training)
+
+
+class MVAEBase(nn.Module):
+    POE_VARIANT = 'A'
+
+    def __init__(self, n_latents):
+        super().__init__()
+        self.n_latents = n_latents
+        self.__dict__['_arena'] = None
+        self.__dict__['_rng'] = None
+
+    # ------------------------------------------------------------------ arena / device plumbing
+    def arena_order(self):
+        """Sub-modules in backward-completion order (decoders first)."""
+        raise NotImplementedError
+
+    def arena_adjacent(self):
+        return ()
+
+    def finalize(self):
+        """Move parameters into the flat arena (idempotent; needs the model on the GPU)."""
+        if self.__dict__.get('_arena') is None:
+            p = next(self.parameters())
+            if not p.is_cuda:
+                raise RuntimeError('multimodal-vae-public_amd: move the model to the GPU first (model.cuda()); '
+                                   'the HIP path has no CPU fallback')
+            self.__dict__['_arena'] = ParamArena(self, order=self.arena_order(),
+                                                 adjacent=self.arena_adjacent())
+        return self.__dict__['_arena']
+
+    @property
+    def arena(self):
+        return self.finalize()
+
+    def _apply(self, fn, *a, **kw):
+        # .cuda()/.cpu()/.to() re-materialise every parameter: the arena views are gone
+        self.__dict__['_arena'] = None
+        return super()._apply(fn, *a, **kw)
+
+    def flush_counters(self):
+        for m in self.modules():
+            if isinstance(m, L._BatchNormMixin):
+                m.flush_counters()
+
+    # ------------------------------------------------------------------ noise
+    def _noise_state(self, device):
+        st = self.__dict__.get('_rng')
+        if st is None or st[1].device != device:
+            st = (0x5DEECE66D, torch.zeros(1, dtype=torch.int64, device=device))
+            self.__dict__['_rng'] = st
+        return st
+
+    def seed_noise(self, seed):
+        dev = next(self.parameters()).device
+        self.__dict__['_rng'] = (int(seed), torch.zeros(1, dtype=torch.int64, device=dev))
+
+    def device_randn(self, *shape):
+        dev = next(self.parameters()).device
+        seed, ctr = self._noise_state(dev)
+        out = torch.empty(*shape, dtype=torch.float32, device=dev)
+        K.randn_(out, seed, ctr)
+        return out
+
+    def device_bernoulli(self, keep, *shape):
+        dev = next(self.parameters()).device
+        seed, ctr = self._noise_state(dev)
+        out = torch.empty(*shape, dtype=torch.float32, device=dev)
+        K.bernoulli_(out, keep, seed ^ 0x9E3779B97F4A7C15, ctr)
+        return out
+
+    # ------------------------------------------------------------------ reference surface
+    def reparametrize(self, mu, logvar, eps=None):
+        """mnist/model.py:29-35: train -> eps * exp(0.5 logvar) + mu, eval -> mu."""
+        if not self.training:
+            return mu
+        if eps is None:
+            eps = self.device_randn(*mu.shape)
+        return ReparamFn.apply(mu, logvar, eps)
+
+    def _fuse(self, heads, eps, want_z):
+        """PoE over the prior and the given encoder outputs ([B, 2D] each)."""
+        self.finalize()
+        B = heads[0].shape[0]
+        dev = heads[0].device
+        masks = torch.full((1,), (1 << len(heads)) - 1, dtype=torch.int32, device=dev)
+        noise = None
+        if want_z and self.training:
+            noise = eps if eps is not None else self.device_randn(1, B, self.n_latents)
+            noise = noise.reshape(1, B, self.n_latents).contiguous()
+        mu, lv, z, _ = PoEFn.apply((masks, noise, self.POE_VARIANT, self.n_latents), *heads)
+        return mu[0], lv[0], z[0]

@@ -1,0 +1,46 @@
+// Shared device helpers for libmvae_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mvae_hip.h"
+
+#define MVAE_EXPORT extern "C" __attribute__((visibility("default")))
+
+static inline int mvae_launch_status() {
+    return hipGetLastError() == hipSuccess ? MVAE_OK : MVAE_ERR_LAUNCH;
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// sigmoid / swish exactly as the reference composes them: x * (1 / (1 + exp(-x)))
+// (mnist/model.py:166-169).  expf, not __expf: the step is graded at 1e-4 relative.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// d/dx [x s(x)] = s + x s (1 - s)
+__device__ __forceinline__ float swish_grad_(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// 64-lane wavefront sum (CDNA wave = 64).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.
+// Every thread receives the total.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}

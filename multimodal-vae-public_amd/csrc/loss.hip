@@ -1,0 +1,191 @@
+// loss.hip -- the reconstruction terms of the ELBO and their gradients (HBM-bound).
+//
+//   BCE-with-logits row sums   mnist/train.py:47-49,62-74; celeba/train.py:50-58,68-80;
+//                              celeba19/train.py:52-57,63-75
+//   categorical cross-entropy  mnist/train.py:52,77-94
+//   ELBO combine / batch mean  mnist/train.py:57-58,214; celeba19/train.py:59
+//
+// The reference evaluates the BCE as 7 elementwise ATen kernels + a row reduction and
+// autograd replays ~10 more; here one pass reads logits+target once and emits the row sum
+// and (optionally, since d loss / d rowsum is a known constant lambda/B) the gradient.
+#include "common.h"
+
+namespace {
+
+// clamp(x,0) - x*t + log(1 + exp(-|x|))   (mnist/train.py:73-74)
+__device__ __forceinline__ float bce_elem(float x, float t) {
+    return fmaxf(x, 0.f) - x * t + logf(1.0f + expf(-fabsf(x)));
+}
+// autograd of the expression above, term by term: 1[x>=0] - t - sign(x) * e/(1+e), e = exp(-|x|)
+__device__ __forceinline__ float bce_grad(float x, float t) {
+    const float e = expf(-fabsf(x));
+    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e / (1.0f + e));
+}
+
+struct BceArgs {
+    const float *logits, *target, *colw, *drow;
+    float *rowsum, *dlogits;
+    int R, P, rows_per_group, target_rows;
+};
+
+// One block per row (wide rows: pixels).  Optionally writes the gradient in the same pass.
+__global__ __launch_bounds__(256) void bce_row_block_kernel(BceArgs a) {
+    __shared__ float red[16];
+    const int r = blockIdx.x;
+    const int g = r / a.rows_per_group;
+    const float *x = a.logits + (size_t)r * a.P;
+    const float *t = a.target + (size_t)(r % a.target_rows) * a.P;
+    const float *w = a.colw ? a.colw + (size_t)g * a.P : nullptr;
+    float *dx = a.dlogits ? a.dlogits + (size_t)r * a.P : nullptr;
+    const float dr = (dx && a.drow) ? a.drow[g] : 0.f;
+    float s = 0.f;
+    const bool vec = (a.P % 4 == 0) && aligned16_dev(x) && aligned16_dev(t) && (!w || aligned16_dev(w)) &&
+                     (!dx || aligned16_dev(dx));
+    if (vec) {
+        const int p4 = a.P / 4;
+        for (int i = threadIdx.x; i < p4; i += 256) {
+            const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+            const float4 tv = reinterpret_cast<const float4 *>(t)[i];
+            float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (w) wv = reinterpret_cast<const float4 *>(w)[i];
+            s += wv.x * bce_elem(xv.x, tv.x) + wv.y * bce_elem(xv.y, tv.y) + wv.z * bce_elem(xv.z, tv.z) +
+                 wv.w * bce_elem(xv.w, tv.w);
+            if (dx) {
+                float4 gv;
+                gv.x = dr * wv.x * bce_grad(xv.x, tv.x);
+                gv.y = dr * wv.y * bce_grad(xv.y, tv.y);
+                gv.z = dr * wv.z * bce_grad(xv.z, tv.z);
+                gv.w = dr * wv.w * bce_grad(xv.w, tv.w);
+                reinterpret_cast<float4 *>(dx)[i] = gv;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < a.P; i += 256) {
+            const float wi = w ? w[i] : 1.f;
+            s += wi * bce_elem(x[i], t[i]);
+            if (dx) dx[i] = dr * wi * bce_grad(x[i], t[i]);
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0 && a.rowsum) a.rowsum[r] = s;
+}
+
+// One wave per row (narrow rows: the 18 attributes).
+__global__ __launch_bounds__(256) void bce_row_wave_kernel(BceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.R) return;
+    const int g = r / a.rows_per_group;
+    const float *x = a.logits + (size_t)r * a.P;
+    const float *t = a.target + (size_t)(r % a.target_rows) * a.P;
+    const float *w = a.colw ? a.colw + (size_t)g * a.P : nullptr;
+    float *dx = a.dlogits ? a.dlogits + (size_t)r * a.P : nullptr;
+    const float dr = (dx && a.drow) ? a.drow[g] : 0.f;
+    float s = 0.f;
+    for (int i = lane; i < a.P; i += 64) {
+        const float wi = w ? w[i] : 1.f;
+        s += wi * bce_elem(x[i], t[i]);
+        if (dx) dx[i] = dr * wi * bce_grad(x[i], t[i]);
+    }
+    s = wave_sum(s);
+    if (lane == 0 && a.rowsum) a.rowsum[r] = s;
+}
+
+// -log_softmax(x + 1e-6)[label]  and its gradient  drow * (softmax(x + 1e-6) - onehot)
+__global__ __launch_bounds__(256) void ce_kernel(const float *logits, const int64_t *label, const float *drow,
+                                                 float *row, float *dlogits, int R, int K, int rows_per_group,
+                                                 int label_rows) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float *x = logits + (size_t)r * K;
+    const int y = (int)label[r % label_rows];
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k] + 1e-6f);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(x[k] + 1e-6f - mx);
+    const float lse = logf(se) + mx;
+    if (row) row[r] = -((x[y] + 1e-6f) - lse);
+    if (dlogits) {
+        const float dr = drow[r / rows_per_group];
+        for (int k = 0; k < K; ++k) {
+            const float p = expf(x[k] + 1e-6f - lse);
+            dlogits[(size_t)r * K + k] = dr * (p - (k == y ? 1.f : 0.f));
+        }
+    }
+}
+
+// out[g] (+)= coef[g] * sum(rows of group g);  out[G] (+)= sum over g of the same
+__global__ __launch_bounds__(1024) void group_sums_kernel(const float *rows, const float *coef, float *out, float *total_out, int G,
+                                                          int rows_per_group, int accumulate) {
+    __shared__ float red[16];
+    float total = 0.f;
+    for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < rows_per_group; i += 1024) s += rows[(size_t)g * rows_per_group + i];
+        s = block_sum(s, red) * (coef ? coef[g] : 1.f);
+        total += s;
+        if (threadIdx.x == 0 && out) out[g] = accumulate ? out[g] + s : s;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = accumulate ? *total_out + total : total;
+}
+
+int bce_launch(BceArgs a, hipStream_t st) {
+    if (!a.logits || !a.target || a.R <= 0 || a.P <= 0 || a.rows_per_group <= 0 || a.target_rows <= 0)
+        return MVAE_ERR_ARG;
+    if (!a.rowsum && !a.dlogits) return MVAE_ERR_ARG;
+    if (a.dlogits && !a.drow) return MVAE_ERR_ARG;
+    if (a.P >= 512)
+        hipLaunchKernelGGL(bce_row_block_kernel, dim3(a.R), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(bce_row_wave_kernel, dim3((a.R + 3) / 4), dim3(256), 0, st, a);
+    return mvae_launch_status();
+}
+
+}  // namespace
+
+MVAE_EXPORT int mvae_bce_rowsum_fwd(const float *logits, const float *target, const float *colw, float *rowsum,
+                                    const float *drow_dev, float *dlogits, int R, int P, int rows_per_group,
+                                    int target_rows, mvae_stream_t stream) {
+    BceArgs a{logits, target, colw, drow_dev, rowsum, dlogits, R, P, rows_per_group, target_rows};
+    if (!rowsum) return MVAE_ERR_ARG;
+    return bce_launch(a, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_bce_rowsum_bwd(const float *logits, const float *target, const float *colw,
+                                    const float *drow_dev, float *dlogits, int R, int P, int rows_per_group,
+                                    int target_rows, mvae_stream_t stream) {
+    BceArgs a{logits, target, colw, drow_dev, nullptr, dlogits, R, P, rows_per_group, target_rows};
+    if (!dlogits) return MVAE_ERR_ARG;
+    return bce_launch(a, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_ce_fwd(const float *logits, const int64_t *label, float *row, const float *drow_dev,
+                            float *dlogits, int R, int K, int rows_per_group, int label_rows,
+                            mvae_stream_t stream) {
+    if (!logits || !label || !row || R <= 0 || K <= 0 || K > 1024 || label_rows <= 0 || rows_per_group <= 0)
+        return MVAE_ERR_ARG;
+    if (dlogits && !drow_dev) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(ce_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, label,
+                       drow_dev, row, dlogits, R, K, rows_per_group, label_rows);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_ce_bwd(const float *logits, const int64_t *label, const float *drow_dev, float *dlogits,
+                            int R, int K, int rows_per_group, int label_rows, mvae_stream_t stream) {
+    if (!logits || !label || !drow_dev || !dlogits || R <= 0 || K <= 0 || K > 1024 || label_rows <= 0 ||
+        rows_per_group <= 0)
+        return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(ce_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, label,
+                       drow_dev, (float *)nullptr, dlogits, R, K, rows_per_group, label_rows);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_group_sums(const float *rows, const float *coef_dev, float *out, float *total_out, int G,
+                                int rows_per_group,
+                                int flags, mvae_stream_t stream) {
+    if (!rows || (!out && !total_out) || G <= 0 || rows_per_group <= 0) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(group_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rows, coef_dev, out, total_out, G,
+                       rows_per_group, (flags & MVAE_ACCUMULATE) ? 1 : 0);
+    return mvae_launch_status();
+}

@@ -1,0 +1,297 @@
+// misc.hip -- the remaining HBM-bound pieces of the step: stand-alone Swish, Embedding(+Swish)
+// gather / scatter, counter-based Philox noise, fused Adam over the flat parameter arena, fill.
+#include "common.h"
+
+namespace {
+
+inline int ew_blocks(size_t n, int per_block) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b > 8192) b = 8192;          // grid-stride the rest (256 CUs x 32 resident blocks)
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(256) void swish_fwd_kernel(const float *x, float *y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = swishf_(x[i]);
+}
+
+__global__ __launch_bounds__(256) void swish_bwd_kernel(const float *dy, const float *x, float *dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dx[i] = dy[i] * swish_grad_(x[i]);
+}
+
+__device__ __forceinline__ int read_index(const void *idx, int is_float, int r) {
+    return is_float ? (int)((const float *)idx)[r] : (int)((const int64_t *)idx)[r];
+}
+
+// act[r,:] = swish(w[idx[r],:])   (nn.Embedding + Swish, mnist/model.py:116,123)
+__global__ __launch_bounds__(256) void embedding_swish_fwd_kernel(const void *idx, int is_float, const float *w,
+                                                                  float *act, int R, int n_classes, int width) {
+    const size_t total = (size_t)R * width;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / width), j = (int)(i - (size_t)r * width);
+        int c = read_index(idx, is_float, r);
+        c = min(max(c, 0), n_classes - 1);
+        act[i] = swishf_(w[(size_t)c * width + j]);
+    }
+}
+
+// dw[c,j] (+)= swish'(w[c,j]) * sum_{r: idx[r]==c} dact[r,j]  -- one thread per (c,j), rows in order:
+// deterministic (the reference's index_add_ backward is not).
+__global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *idx, int is_float, const float *w,
+                                                                  const float *dact, float *dw, int R,
+                                                                  int n_classes, int width, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (j >= width) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        int cr = read_index(idx, is_float, r);
+        cr = min(max(cr, 0), n_classes - 1);
+        if (cr == c) s += dact[(size_t)r * width + j];
+    }
+    const size_t o = (size_t)c * width + j;
+    s *= swish_grad_(w[o]);
+    dw[o] = accumulate ? dw[o] + s : s;
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter = (element group, launch offset), key = seed ----
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// mode 0: standard normal (Box-Muller on pairs), mode 1: Bernoulli(keep) in {0,1}
+__global__ __launch_bounds__(256) void philox_fill_kernel(float *out, size_t n, uint64_t seed,
+                                                          const uint64_t *counter, int mode, float keep) {
+    const uint64_t launch = *counter;
+    const size_t groups = (n + 3) / 4;
+    for (size_t gidx = (size_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (size_t)gridDim.x * 256) {
+        uint32_t r[4];
+        philox4x32_10(gidx, launch, seed, r);
+        float v[4];
+        if (mode == 0) {
+            const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), r1 = sqrtf(-2.0f * logf(u01(r[2])));
+            float s0, c0, s1, c1;
+            sincosf(6.2831853071795864f * u01(r[1]), &s0, &c0);
+            sincosf(6.2831853071795864f * u01(r[3]), &s1, &c1);
+            v[0] = r0 * c0; v[1] = r0 * s0; v[2] = r1 * c1; v[3] = r1 * s1;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = u01(r[q]) < keep ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (gidx * 4 + q < n) out[gidx * 4 + q] = v[q];
+    }
+}
+
+__global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
+
+// ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) ----
+// step t = *step_dev + 1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
+                                                   float lr, float b1, float b2, float eps, float gscale,
+                                                   const int64_t *step_dev) {
+    const double t = (double)(*step_dev + 1);
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    const size_t n4 = n / 4;
+    const bool vec = aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v);
+    if (vec) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 pv = reinterpret_cast<float4 *>(p)[i];
+            const float4 gv = reinterpret_cast<const float4 *>(g)[i];
+            float4 mv = reinterpret_cast<float4 *>(m)[i];
+            float4 vv = reinterpret_cast<float4 *>(v)[i];
+#define MVAE_ADAM1(c)                                                       \
+    {                                                                       \
+        const float gg = gv.c * gscale;                                     \
+        mv.c = b1 * mv.c + (1.f - b1) * gg;                                 \
+        vv.c = b2 * vv.c + (1.f - b2) * gg * gg;                            \
+        pv.c -= step_size * (mv.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));    \
+    }
+            MVAE_ADAM1(x) MVAE_ADAM1(y) MVAE_ADAM1(z) MVAE_ADAM1(w)
+#undef MVAE_ADAM1
+            reinterpret_cast<float4 *>(p)[i] = pv;
+            reinterpret_cast<float4 *>(m)[i] = mv;
+            reinterpret_cast<float4 *>(v)[i] = vv;
+        }
+    }
+    const size_t tail0 = vec ? n4 * 4 : 0;
+    for (size_t i = tail0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gg = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gg;
+        const float vi = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+__global__ void bump_i64_kernel(int64_t *step) { *step += 1; }
+
+__global__ __launch_bounds__(256) void fill_kernel(float *out, size_t n, float value) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = value;
+}
+
+}  // namespace
+
+MVAE_EXPORT int mvae_swish_fwd(const float *x, float *y, size_t n, mvae_stream_t stream) {
+    if (!x || !y) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(swish_fwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_swish_bwd(const float *dy, const float *x, float *dx, size_t n, mvae_stream_t stream) {
+    if (!dy || !x || !dx) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(swish_bwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_embedding_swish_fwd(const void *idx, int idx_is_float, const float *w, float *act, int R,
+                                         int n_classes, int width, mvae_stream_t stream) {
+    if (!idx || !w || !act || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(embedding_swish_fwd_kernel, dim3(ew_blocks((size_t)R * width, 256)), dim3(256), 0,
+                       (hipStream_t)stream, idx, idx_is_float, w, act, R, n_classes, width);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, const float *w, const float *dact,
+                                         float *dw, int R, int n_classes, int width, int flags,
+                                         mvae_stream_t stream) {
+    if (!idx || !w || !dact || !dw || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 255) / 256, n_classes), dim3(256), 0,
+                       (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
+                       (flags & MVAE_ACCUMULATE) ? 1 : 0);
+    return mvae_launch_status();
+}
+
+static int philox_launch(float *out, size_t n, uint64_t seed, uint64_t *counter_dev, int mode, float keep,
+                         mvae_stream_t stream) {
+    if (!out || !counter_dev) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, st, out, n, seed,
+                       (const uint64_t *)counter_dev, mode, keep);
+    hipLaunchKernelGGL(bump_u64_kernel, dim3(1), dim3(1), 0, st, counter_dev);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_randn(float *out, size_t n, uint64_t seed, uint64_t *counter_dev, mvae_stream_t stream) {
+    return philox_launch(out, n, seed, counter_dev, 0, 0.f, stream);
+}
+
+MVAE_EXPORT int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t seed, uint64_t *counter_dev,
+                               mvae_stream_t stream) {
+    return philox_launch(out, n, seed, counter_dev, 1, keep_prob, stream);
+}
+
+MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                               float lr, float beta1, float beta2, float eps, float grad_scale,
+                               int64_t *step_dev, mvae_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev);
+    hipLaunchKernelGGL(bump_i64_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream) {
+    if (!out) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, value);
+    return mvae_launch_status();
+}
+
+// ---- Dropout fan-out: ONE activation h[B,N] feeding G calls that differ only in their keep-mask
+// (celeba/model.py:89-92 is run twice per step on the same batch: the conv trunk and the
+// Linear(6400,512)+Swish are identical, only the Dropout(0.1) draw differs) ----
+namespace {
+__global__ __launch_bounds__(256) void dropout_fanout_kernel(const float *h, const float *masks, float *out,
+                                                             float scale, int G, size_t bn) {
+    const size_t total = (size_t)G * bn;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+        out[i] = h[i % bn] * (masks[i] * scale);
+}
+__global__ __launch_bounds__(256) void dropout_fanin_kernel(const float *dout, const float *masks, float *dh,
+                                                            float scale, int G, size_t bn) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < bn; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += dout[(size_t)g * bn + i] * (masks[(size_t)g * bn + i] * scale);
+        dh[i] = s;
+    }
+}
+// elementwise BCE-with-logits for the reference-surface helper (mnist/train.py:62-74)
+__global__ __launch_bounds__(256) void bce_elem_fwd_kernel(const float *x, const float *t, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = fmaxf(x[i], 0.f) - x[i] * t[i] + logf(1.0f + expf(-fabsf(x[i])));
+}
+__global__ __launch_bounds__(256) void bce_elem_bwd_kernel(const float *x, const float *t, const float *g,
+                                                           float *dx, float *dt, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float xv = x[i];
+        const float e = expf(-fabsf(xv));
+        const float sgn = (xv > 0.f) ? 1.f : ((xv < 0.f) ? -1.f : 0.f);
+        if (dx) dx[i] = g[i] * (((xv >= 0.f) ? 1.f : 0.f) - t[i] - sgn * (e / (1.0f + e)));
+        if (dt) dt[i] = -g[i] * xv;
+    }
+}
+}  // namespace
+
+MVAE_EXPORT int mvae_dropout_fanout_fwd(const float *h, const float *masks, float *out, float scale, int G,
+                                        int B, int N, mvae_stream_t stream) {
+    if (!h || !masks || !out || G <= 0 || B <= 0 || N <= 0) return MVAE_ERR_ARG;
+    const size_t bn = (size_t)B * N;
+    hipLaunchKernelGGL(dropout_fanout_kernel, dim3(ew_blocks(bn * G, 256)), dim3(256), 0, (hipStream_t)stream, h,
+                       masks, out, scale, G, bn);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_dropout_fanin_bwd(const float *dout, const float *masks, float *dh, float scale, int G,
+                                       int B, int N, mvae_stream_t stream) {
+    if (!dout || !masks || !dh || G <= 0 || B <= 0 || N <= 0) return MVAE_ERR_ARG;
+    const size_t bn = (size_t)B * N;
+    hipLaunchKernelGGL(dropout_fanin_kernel, dim3(ew_blocks(bn, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       masks, dh, scale, G, bn);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_bce_elem_fwd(const float *logits, const float *target, float *out, size_t n,
+                                  mvae_stream_t stream) {
+    if (!logits || !target || !out) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(bce_elem_fwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                       target, out, n);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_bce_elem_bwd(const float *logits, const float *target, const float *g, float *dlogits,
+                                  float *dtarget, size_t n, mvae_stream_t stream) {
+    if (!logits || !target || !g || (!dlogits && !dtarget)) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(bce_elem_bwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                       target, g, dlogits, dtarget, n);
+    return mvae_launch_status();
+}

@@ -1,0 +1,253 @@
+// norm.hip -- training-mode BatchNorm2d / BatchNorm1d (+ fused Swish), HBM-bound.
+//
+// x is [G*B, C, HW]; each of the G groups of B samples is normalised with its own batch
+// statistics, so the G `model()` calls the reference issues per train step on the same layer
+// (celeba/train.py:193-195: 3 decoder passes; celeba19/train.py:264-302: 21) run as one launch.
+//
+// Statistics are computed as (count, mean, M2) per slice with a two-pass sum inside the slice
+// (the slice is L2-resident for the second pass) and merged with Chan's formula -- no
+// E[x^2]-E[x]^2 cancellation.  All cross-block reductions go through the caller's workspace in
+// a fixed order: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_SLICES = 64;
+
+__host__ __device__ inline int bn_slices(int n_per_group) {
+    int s = n_per_group / 4096;
+    if (s < 1) s = 1;
+    if (s > BN_MAX_SLICES) s = BN_MAX_SLICES;
+    return s;
+}
+
+struct BnShape { int G, B, C, HW, S, n; };  // n = B * HW elements per (group, channel)
+
+__device__ __forceinline__ size_t bn_addr(const BnShape &sh, int g, int c, int n) {
+    const int b = n / sh.HW, sp = n - b * sh.HW;
+    return ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW + sp;
+}
+
+__device__ __forceinline__ void slice_range(const BnShape &sh, int s, int *lo, int *hi) {
+    const int len = (sh.n + sh.S - 1) / sh.S;
+    *lo = s * len;
+    *hi = min(sh.n, *lo + len);
+}
+
+// ws[((g*C + c)*S + s)*3 + {0,1,2}] = (count, mean, M2) of the slice
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_stats_kernel(const float *x, float *ws, BnShape sh) {
+    __shared__ float red[16];
+    const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
+    int lo, hi;
+    slice_range(sh, s, &lo, &hi);
+    float sum = 0.f;
+    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) sum += x[bn_addr(sh, g, c, n)];
+    sum = block_sum(sum, red);
+    const float cnt = (float)max(hi - lo, 0);
+    const float mean = cnt > 0.f ? sum / cnt : 0.f;
+    float m2 = 0.f;
+    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
+        const float d = x[bn_addr(sh, g, c, n)] - mean;
+        m2 += d * d;
+    }
+    m2 = block_sum(m2, red);
+    if (threadIdx.x == 0) {
+        float *o = ws + ((size_t)(g * sh.C + c) * sh.S + s) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
+// Chan merge of the S slice statistics of (g, c): returns mean and biased variance.
+__device__ inline void bn_merge(const float *ws, const BnShape &sh, int g, int c, float *mean, float *var) {
+    const float *p = ws + (size_t)(g * sh.C + c) * sh.S * 3;
+    float n = 0.f, m = 0.f, m2 = 0.f;
+    for (int s = 0; s < sh.S; ++s) {
+        const float nb = p[s * 3], mb = p[s * 3 + 1], m2b = p[s * 3 + 2];
+        if (nb <= 0.f) continue;
+        const float nt = n + nb, d = mb - m;
+        m += d * (nb / nt);
+        m2 += m2b + d * d * (n * nb / nt);
+        n = nt;
+    }
+    *mean = m;
+    *var = n > 0.f ? m2 / n : 0.f;
+}
+
+// y = swish?(gamma * (x - mean) * invstd + beta); also saves mean/invstd and advances the
+// running statistics (one block per channel does that, sequentially over groups).
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x, const float *gamma,
+                                                                  const float *beta, float *y, const float *ws,
+                                                                  float *save_mean, float *save_invstd,
+                                                                  float *running_mean, float *running_var,
+                                                                  BnShape sh, float eps, float momentum,
+                                                                  int n_updates, int swish) {
+    const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
+    float mean, var;
+    bn_merge(ws, sh, g, c, &mean, &var);
+    const float invstd = rsqrtf(var + eps);
+    if (s == 0 && threadIdx.x == 0) {
+        save_mean[g * sh.C + c] = mean;
+        save_invstd[g * sh.C + c] = invstd;
+        if (g == 0 && running_mean) {
+            float rm = running_mean[c], rv = running_var[c];
+            const float unb = sh.n > 1 ? (float)sh.n / (float)(sh.n - 1) : 1.f;
+            for (int gg = 0; gg < sh.G; ++gg) {
+                float m, v;
+                bn_merge(ws, sh, gg, c, &m, &v);
+                for (int u = 0; u < n_updates; ++u) {
+                    rm = (1.f - momentum) * rm + momentum * m;
+                    rv = (1.f - momentum) * rv + momentum * (v * unb);
+                }
+            }
+            running_mean[c] = rm;
+            running_var[c] = rv;
+        }
+    }
+    const float ga = gamma[c], be = beta[c];
+    int lo, hi;
+    slice_range(sh, s, &lo, &hi);
+    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
+        const size_t a = bn_addr(sh, g, c, n);
+        const float h = ga * ((x[a] - mean) * invstd) + be;   // same expression as the backward's
+        y[a] = swish ? swishf_(h) : h;
+    }
+}
+
+// ws[((g*C + c)*S + s)*2 + {0,1}] = (sum dh, sum dh * xhat), dh = dy * swish'(h)
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *dy, const float *x,
+                                                                    const float *gamma, const float *beta,
+                                                                    const float *save_mean,
+                                                                    const float *save_invstd, float *ws,
+                                                                    BnShape sh, int swish) {
+    __shared__ float red[16];
+    const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
+    const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
+    const float ga = gamma[c], be = beta[c];
+    int lo, hi;
+    slice_range(sh, s, &lo, &hi);
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
+        const size_t a = bn_addr(sh, g, c, n);
+        const float xh = (x[a] - mean) * invstd;
+        float d = dy[a];
+        if (swish) d *= swish_grad_(ga * xh + be);
+        s1 += d;
+        s2 += d * xh;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        float *o = ws + ((size_t)(g * sh.C + c) * sh.S + s) * 2;
+        o[0] = s1; o[1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *dy, const float *x,
+                                                                  const float *gamma, const float *beta,
+                                                                  const float *save_mean,
+                                                                  const float *save_invstd, const float *ws,
+                                                                  float *dx, float *dgamma, float *dbeta,
+                                                                  BnShape sh, int swish, int accumulate) {
+    const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
+    const float *p = ws + (size_t)(g * sh.C + c) * sh.S * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < sh.S; ++k) { s1 += p[k * 2]; s2 += p[k * 2 + 1]; }
+    if (s == 0 && g == 0 && threadIdx.x == 0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int gg = 0; gg < sh.G; ++gg) {
+            const float *q = ws + (size_t)(gg * sh.C + c) * sh.S * 2;
+            for (int k = 0; k < sh.S; ++k) { t1 += q[k * 2]; t2 += q[k * 2 + 1]; }
+        }
+        if (accumulate) { t1 += dbeta[c]; t2 += dgamma[c]; }
+        dbeta[c] = t1;
+        dgamma[c] = t2;
+    }
+    const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
+    const float ga = gamma[c], be = beta[c];
+    const float inv_n = 1.f / (float)sh.n;
+    const float m1 = s1 * inv_n, m2 = s2 * inv_n, k = ga * invstd;
+    int lo, hi;
+    slice_range(sh, s, &lo, &hi);
+    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
+        const size_t a = bn_addr(sh, g, c, n);
+        const float xh = (x[a] - mean) * invstd;
+        float d = dy[a];
+        if (swish) d *= swish_grad_(ga * xh + be);
+        dx[a] = k * (d - m1 - xh * m2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float *x, const float *gamma, const float *beta,
+                                                      float *y, const float *rm, const float *rv, size_t total,
+                                                      int C, int HW, float eps, int swish) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const float h = (x[i] - rm[c]) * rsqrtf(rv[c] + eps) * gamma[c] + beta[c];
+        y[i] = swish ? swishf_(h) : h;
+    }
+}
+
+inline bool bn_shape(int G, int B, int C, int HW, BnShape *sh) {
+    if (G <= 0 || B <= 0 || C <= 0 || HW <= 0) return false;
+    if ((long)G * B * C * HW >= (1L << 40) || (long)B * HW >= (1L << 31)) return false;
+    sh->G = G; sh->B = B; sh->C = C; sh->HW = HW; sh->n = B * HW; sh->S = bn_slices(B * HW);
+    return true;
+}
+
+}  // namespace
+
+MVAE_EXPORT size_t mvae_bn_ws_bytes(int G, int C, int n_per_group) {
+    if (G <= 0 || C <= 0 || n_per_group <= 0) return 0;
+    return (size_t)G * C * bn_slices(n_per_group) * 3 * sizeof(float);
+}
+
+MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                                  float *save_mean, float *save_invstd, float *running_mean,
+                                  float *running_var, int G, int B, int C, int HW, float eps, float momentum,
+                                  int n_updates, int flags, void *ws, size_t ws_bytes, mvae_stream_t stream) {
+    BnShape sh;
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, &sh)) return MVAE_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
+    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(sh.S, C, G);
+    hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(BN_THREADS), 0, st, x, (float *)ws, sh);
+    hipLaunchKernelGGL(bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
+                       save_mean, save_invstd, running_mean, running_var, sh, eps, momentum, n_updates,
+                       (flags & MVAE_ACT_SWISH) ? 1 : 0);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
+                                  float *dbeta, int G, int B, int C, int HW, int flags, void *ws,
+                                  size_t ws_bytes, mvae_stream_t stream) {
+    BnShape sh;
+    if (!dy || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta ||
+        !bn_shape(G, B, C, HW, &sh))
+        return MVAE_ERR_ARG;
+    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(sh.S, C, G);
+    const int swish = (flags & MVAE_ACT_SWISH) ? 1 : 0;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(BN_THREADS), 0, st, dy, x, gamma, beta, save_mean,
+                       save_invstd, (float *)ws, sh, swish);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(BN_THREADS), 0, st, dy, x, gamma, beta, save_mean,
+                       save_invstd, (const float *)ws, dx, dgamma, dbeta, sh, swish,
+                       (flags & MVAE_ACCUMULATE) ? 1 : 0);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_bn_eval_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                                 const float *running_mean, const float *running_var, int N, int C, int HW,
+                                 float eps, int flags, mvae_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !running_mean || !running_var || N <= 0 || C <= 0 || HW <= 0)
+        return MVAE_ERR_ARG;
+    const size_t total = (size_t)N * C * HW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       running_mean, running_var, total, C, HW, eps, (flags & MVAE_ACT_SWISH) ? 1 : 0);
+    return mvae_launch_status();
+}

@@ -1,0 +1,218 @@
+// poe.hip -- prior expert + product-of-experts fuse + reparameterised draw + analytic KL,
+// forward and backward, for all the ELBO terms of a train step in one launch each.
+//
+// Reference: prior_expert mnist/model.py:172-185; stacking MVAE.infer mnist/model.py:46-64,
+// celeba19/model.py:63-89; ProductOfExperts mnist/model.py:156-163 (variant A) and
+// celeba/model.py:200-207 (variant B); reparametrize mnist/model.py:29-35; KL mnist/train.py:56.
+//
+// HBM-bound and tiny: one wave per batch row (lanes along the latent dim, so the KL row sum is a
+// wavefront reduction), every term t of the step handled by the same thread so each expert's
+// mu/logvar is fetched once from L1/L2.  The [M,B,D] expert stack of the reference (torch.cat
+// per expert) is never materialised; the N(0,1) prior is a constant.
+#include "common.h"
+
+namespace {
+
+constexpr int POE_THREADS = 128;   // 2 waves = 2 batch rows per block
+constexpr int POE_MAX_TERMS = 40;   // 3 * T * 128 floats of LDS in the backward <= 60 KiB
+constexpr float POE_EPS = 1e-8f;
+
+struct PoeArgs {
+    mvae_experts_t ex;
+    int ld, E, T, B, D, variant;
+};
+
+// precision of one expert: 1 / (exp(lv) + eps [+ eps])
+__device__ __forceinline__ float poe_precision(float lv, int variant) {
+    float var = expf(lv) + POE_EPS;
+    if (variant == MVAE_POE_VARIANT_A) var = var + POE_EPS;
+    return 1.0f / var;
+}
+
+__global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const uint32_t *masks,
+                                                              const float *noise, float *mu, float *logvar,
+                                                              float *z, float *kl) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (POE_THREADS / 64) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const float t0 = poe_precision(0.f, a.variant);   // the N(0,1) prior: mu = 0, logvar = 0
+    for (int t = 0; t < a.T; ++t) {
+        const uint32_t mask = masks[t];
+        float klp = 0.f;
+        for (int d = lane; d < a.D; d += 64) {
+            float sum_t = t0, sum_mt = 0.f * t0;
+            for (int e = 0; e < a.E; ++e) {
+                if (!((mask >> e) & 1u)) continue;
+                const size_t o = (size_t)b * a.ld + d;
+                const float te = poe_precision(a.ex.logvar[e][o], a.variant);
+                sum_mt += a.ex.mu[e][o] * te;
+                sum_t += te;
+            }
+            const float pmu = sum_mt / sum_t;
+            const float pvar = 1.0f / sum_t;
+            const float plv = (a.variant == MVAE_POE_VARIANT_A) ? logf(pvar + POE_EPS) : logf(pvar);
+            const size_t o = ((size_t)t * a.B + b) * a.D + d;
+            mu[o] = pmu;
+            logvar[o] = plv;
+            if (z) z[o] = noise ? noise[o] * expf(0.5f * plv) + pmu : pmu;
+            klp += 1.0f + plv - pmu * pmu - expf(plv);
+        }
+        klp = wave_sum(klp);
+        if (lane == 0 && kl) kl[(size_t)t * a.B + b] = -0.5f * klp;
+    }
+}
+
+// Backward.  Phase 1 (per term): total gradient reaching (mu_t, logvar_t) from z, from the
+// KL row and from direct consumers, folded into A_t = dmu_t / S_t, B_t = dlv_t * dlv/dS and the
+// fused mean; kept in LDS ([term][3][thread], conflict-free).  Phase 2 (per expert): T_e and
+// exp(lv_e) once, then a sweep over the terms that contain the expert.
+__global__ __launch_bounds__(POE_THREADS) void poe_bwd_kernel(PoeArgs a, const uint32_t *masks,
+                                                              const float *noise, const float *mu,
+                                                              const float *logvar, const float *dz,
+                                                              const float *dmu, const float *dlogvar,
+                                                              const float *dkl, int dkl_stride,
+                                                              mvae_expert_grads_t gr, int ldg) {
+    extern __shared__ float lds[];   // [T][3][POE_THREADS]
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (POE_THREADS / 64) + (threadIdx.x >> 6);
+    if (b >= a.B) return;            // whole waves exit together; no block barrier is used below
+    float *mine = lds + threadIdx.x;
+    for (int d = lane; d < a.D; d += 64) {
+        for (int t = 0; t < a.T; ++t) {
+            const size_t o = ((size_t)t * a.B + b) * a.D + d;
+            const float pmu = mu[o], plv = logvar[o];
+            float gmu = dmu ? dmu[o] : 0.f;
+            float glv = dlogvar ? dlogvar[o] : 0.f;
+            if (dz) {
+                const float g = dz[o];
+                gmu += g;
+                if (noise) glv += g * noise[o] * 0.5f * expf(0.5f * plv);
+            }
+            if (dkl) {
+                // dkl_stride == B: per-row gradient [T,B]; 0: a per-term table [T]
+                const float ks = dkl_stride ? dkl[(size_t)t * dkl_stride + b] : dkl[t];
+                gmu += ks * pmu;
+                glv += ks * (-0.5f) * (1.0f - expf(plv));
+            }
+            // recover S = sum of precisions from the fused log-variance
+            float s, dlv_ds;
+            if (a.variant == MVAE_POE_VARIANT_A) {
+                const float v = expf(plv) - POE_EPS;        // 1/S
+                s = 1.0f / v;
+                dlv_ds = -(v * v) / (v + POE_EPS);          // d log(1/S + eps) / dS
+            } else {
+                s = expf(-plv);
+                dlv_ds = -1.0f / s;
+            }
+            mine[(t * 3 + 0) * POE_THREADS] = gmu / s;
+            mine[(t * 3 + 1) * POE_THREADS] = glv * dlv_ds;
+            mine[(t * 3 + 2) * POE_THREADS] = pmu;
+        }
+        for (int e = 0; e < a.E; ++e) {
+            const size_t o = (size_t)b * a.ld + d;
+            const float me = a.ex.mu[e][o], lve = a.ex.logvar[e][o];
+            const float ex = expf(lve);
+            const float te = poe_precision(lve, a.variant);
+            float gm = 0.f, gt = 0.f;
+            bool any = false;
+            for (int t = 0; t < a.T; ++t) {
+                if (!((masks[t] >> e) & 1u)) continue;
+                any = true;
+                const float at = mine[(t * 3 + 0) * POE_THREADS];
+                gm += at * te;
+                gt += at * (me - mine[(t * 3 + 2) * POE_THREADS]) + mine[(t * 3 + 1) * POE_THREADS];
+            }
+            const size_t og = (size_t)b * ldg + d;
+            gr.dmu[e][og] = any ? gm : 0.f;
+            gr.dlogvar[e][og] = any ? gt * (-(te * te) * ex) : 0.f;
+        }
+    }
+}
+
+// Stand-alone KL rows for the reference-surface elbo_loss(mu, logvar): mnist/train.py:56.
+__global__ __launch_bounds__(POE_THREADS) void kl_rows_fwd_kernel(const float *mu, const float *logvar, float *kl,
+                                                                  int B, int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (POE_THREADS / 64) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float m = mu[(size_t)b * D + d], lv = logvar[(size_t)b * D + d];
+        s += 1.0f + lv - m * m - expf(lv);
+    }
+    s = wave_sum(s);
+    if (lane == 0) kl[b] = -0.5f * s;
+}
+
+__global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float *mu, const float *logvar, const float *dkl,
+                                                          float *dmu, float *dlogvar, int B, int D) {
+    const size_t n = (size_t)B * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float g = dkl[i / D];
+        dmu[i] = g * mu[i];
+        dlogvar[i] = g * (-0.5f) * (1.0f - expf(logvar[i]));
+    }
+}
+
+inline bool poe_args_ok(const mvae_experts_t *ex, int ld, int E, int T, int B, int D, int variant) {
+    if (!ex || E < 0 || E > MVAE_MAX_EXPERTS || T <= 0 || T > POE_MAX_TERMS || B <= 0 || D <= 0 || ld < D)
+        return false;
+    if (variant != MVAE_POE_VARIANT_A && variant != MVAE_POE_VARIANT_B) return false;
+    for (int e = 0; e < E; ++e)
+        if (!ex->mu[e] || !ex->logvar[e]) return false;
+    return true;
+}
+
+}  // namespace
+
+MVAE_EXPORT int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E, const uint32_t *masks_dev, int T,
+                             const float *noise, float *mu, float *logvar, float *z, float *kl, int B, int D,
+                             int variant, mvae_stream_t stream) {
+    if (!poe_args_ok(experts, ld, E, T, B, D, variant) || !masks_dev || !mu || !logvar) return MVAE_ERR_ARG;
+    PoeArgs a;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    const int rows = POE_THREADS / 64;
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), 0, (hipStream_t)stream, a,
+                       masks_dev, noise, mu, logvar, z, kl);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E, const uint32_t *masks_dev, int T,
+                             const float *noise, const float *mu, const float *logvar, const float *dz,
+                             const float *dmu, const float *dlogvar, const float *dkl, int dkl_per_term,
+                             const mvae_expert_grads_t *grads, int ldg, int B, int D, int variant,
+                             mvae_stream_t stream) {
+    // dkl is [T,B] (per row) or, with dkl_per_term, a [T] table (beta/B of each ELBO term)
+    const int dkl_stride = dkl_per_term ? 0 : B;
+    if (!poe_args_ok(experts, ld, E, T, B, D, variant) || !masks_dev || !mu || !logvar || !grads || ldg < D)
+        return MVAE_ERR_ARG;
+    for (int e = 0; e < E; ++e)
+        if (!grads->dmu[e] || !grads->dlogvar[e]) return MVAE_ERR_ARG;
+    PoeArgs a;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    const int rows = POE_THREADS / 64;
+    const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,
+                       (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz, dmu, dlogvar, dkl, dkl_stride,
+                       *grads, ldg);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_kl_rows_fwd(const float *mu, const float *logvar, float *kl, int B, int D,
+                                 mvae_stream_t stream) {
+    if (!mu || !logvar || !kl || B <= 0 || D <= 0) return MVAE_ERR_ARG;
+    const int rows = POE_THREADS / 64;
+    hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), 0, (hipStream_t)stream,
+                       mu, logvar, kl, B, D);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_kl_rows_bwd(const float *mu, const float *logvar, const float *dkl, float *dmu,
+                                 float *dlogvar, int B, int D, mvae_stream_t stream) {
+    if (!mu || !logvar || !dkl || !dmu || !dlogvar || B <= 0 || D <= 0) return MVAE_ERR_ARG;
+    size_t blocks = ((size_t)B * D + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, mu, logvar, dkl,
+                       dmu, dlogvar, B, D);
+    return mvae_launch_status();
+}

@@ -1,0 +1,461 @@
+"""HIP-backed layers and the stack executor.
+
+The layer classes subclass the ``torch.nn`` containers the reference uses (so parameter names,
+shapes, default initialisation and ``state_dict`` keys are identical -- SURVEY.md Appendix A),
+but their arithmetic never touches ATen: a *stack* (an encoder or a decoder: a list of these
+layers) is compiled into a short plan of fused HIP launches
+
+    Linear(+Swish)(+Dropout) | Conv2d/ConvTranspose2d 4x4 (+Swish) | BatchNorm(+Swish) |
+    Embedding+Swish | view
+
+and run by ``forward_tape`` / ``backward_tape``.  The backward is hand-written: each dgrad
+launch multiplies by swish'(pre-activation) of the layer that produced its input in the GEMM
+epilogue, weight gradients are written straight into the gradient arena, and BatchNorm handles
+its own Swish.  ``StackFn`` exposes the pair to autograd for the reference's module surface
+(``model(image, text)`` ... ``loss.backward()``); the fused train step in ``engine.py`` calls
+the tape functions directly.
+
+A stack may process ``G`` groups of ``B`` rows at once (``groups=G``): BatchNorm statistics are
+per group, so the G separate ``model()`` calls of the reference's train step become one launch
+per layer with identical results.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .arena import grad_target
+
+
+# ----------------------------------------------------------------------------- layer containers
+class Swish(nn.Module):
+    """x * sigmoid(x) (reference: mnist/model.py:166-169); fused into its producer when it
+    follows a Linear / conv / BatchNorm inside a stack."""
+    def forward(self, x):
+        return _SwishFn.apply(x.contiguous())
+
+
+class _SwishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        K.swish_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        K.swish_bwd(g.contiguous(), x, dx)
+        return dx
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return run_stack([self], x)
+
+
+class Conv2d(nn.Conv2d):
+    """4x4, bias=False, (stride, pad) in {(2,1), (1,0)} -- the only shapes on the hot path."""
+    def forward(self, x):
+        return run_stack([self], x)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x):
+        return run_stack([self], x)
+
+
+class _BatchNormMixin(object):
+    def _init_pending(self):
+        self._nbt_pending = 0
+
+    def flush_counters(self):
+        """num_batches_tracked is advanced on the host and written back lazily: a device-side
+        int64 add per BatchNorm per call would be 11-21 stray launches per step."""
+        if getattr(self, '_nbt_pending', 0):
+            self.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counters()
+        return super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def forward(self, x):
+        return run_stack([self], x)
+
+
+class BatchNorm2d(_BatchNormMixin, nn.BatchNorm2d):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._init_pending()
+
+
+class BatchNorm1d(_BatchNormMixin, nn.BatchNorm1d):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._init_pending()
+
+
+class Embedding(nn.Embedding):
+    """Only ever followed by Swish in the reference; the stack fuses the pair."""
+    def forward(self, idx):
+        raise RuntimeError('Embedding runs fused with the Swish that follows it; call the '
+                           'enclosing encoder instead')
+
+
+class Dropout(nn.Dropout):
+    """p = 0.1 after the CelebA encoder's Linear+Swish (celeba/model.py:91); the keep-mask is
+    an explicit input of the stack (host-drawn for parity, Philox on device otherwise)."""
+    def forward(self, x):
+        raise RuntimeError('Dropout runs fused into the preceding Linear; call the enclosing encoder')
+
+
+class View(nn.Module):
+    """x.view(-1, *shape) between the conv and linear halves of a stack (parameter-free and
+    not registered in any Sequential, so state_dict keys are unchanged)."""
+    def __init__(self, *shape):
+        super().__init__()
+        self.shape = tuple(shape)
+
+
+# ----------------------------------------------------------------------------- plan
+class _Op(object):
+    __slots__ = ('kind', 'mod', 'act', 'drop', 'pair')
+
+    def __init__(self, kind, mod, act=False, drop=0.0, pair=None):
+        self.kind, self.mod, self.act, self.drop, self.pair = kind, mod, act, drop, pair
+
+
+class HeadPair(nn.Module):
+    """Two Linear heads on the same input (fc31 / fc32 of the MNIST encoders,
+    mnist/model.py:77-78,84) executed as ONE GEMM of width 2D: the arena lays the two weight
+    matrices (and biases) back to back.  Parameter-free wrapper; the heads stay registered on
+    their owner under the reference's names."""
+    def __init__(self, head_a, head_b):
+        super().__init__()
+        object.__setattr__(self, 'heads', (head_a, head_b))   # not registered as children
+
+
+def flatten_modules(mods):
+    out = []
+    for m in mods:
+        if isinstance(m, nn.Sequential):
+            out.extend(flatten_modules(list(m)))
+        else:
+            out.append(m)
+    return out
+
+
+def compile_plan(mods):
+    mods = flatten_modules(mods)
+    plan, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(m, (nn.Linear, HeadPair)):
+            kind = 'lin' if isinstance(m, nn.Linear) else 'lin2'
+            act = isinstance(nxt, Swish)
+            i += 2 if act else 1
+            drop = 0.0
+            if act and i < len(mods) and isinstance(mods[i], nn.Dropout):
+                drop = mods[i].p
+                i += 1
+            plan.append(_Op(kind, m, act=act, drop=drop))
+        elif isinstance(m, (nn.ConvTranspose2d, nn.Conv2d)):
+            _check_conv(m)
+            kind = 'convT' if isinstance(m, nn.ConvTranspose2d) else 'conv'
+            act = isinstance(nxt, Swish)
+            plan.append(_Op(kind, m, act=act))
+            i += 2 if act else 1
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            act = isinstance(nxt, Swish)
+            plan.append(_Op('bn', m, act=act))
+            i += 2 if act else 1
+        elif isinstance(m, nn.Embedding):
+            if not isinstance(nxt, Swish):
+                raise RuntimeError('Embedding must be followed by Swish')
+            plan.append(_Op('emb', m, act=True))
+            i += 2
+        elif isinstance(m, View):
+            plan.append(_Op('view', m))
+            i += 1
+        elif isinstance(m, Swish):
+            raise RuntimeError('dangling Swish: no fusable producer in front of it')
+        else:
+            raise RuntimeError('layer %s is not on the MVAE hot path' % type(m).__name__)
+    for a, b in zip(plan[:-1], plan[1:]):
+        if b.kind == 'bn' and a.act:
+            raise RuntimeError('BatchNorm directly after an activated layer is not supported')
+    return plan
+
+
+def _check_conv(m):
+    ok = (tuple(m.kernel_size) == (4, 4) and m.bias is None and
+          (tuple(m.stride), tuple(m.padding)) in (((2, 2), (1, 1)), ((1, 1), (0, 0))))
+    if not ok:
+        raise RuntimeError('only 4x4 convs with bias=False and (stride,pad) in {(2,1),(1,0)} are built')
+
+
+def plan_params(plan):
+    ps = []
+    for op in plan:
+        if op.kind == 'lin2':
+            for h in op.mod.heads:
+                ps.extend(h.parameters())
+        elif op.kind != 'view':
+            ps.extend(op.mod.parameters())
+    return ps
+
+
+def n_dropout(plan):
+    return sum(1 for op in plan if op.drop > 0)
+
+
+# ----------------------------------------------------------------------------- executor
+def _lin_weights(op):
+    """(weight [N,K], bias [N] or None) -- for a HeadPair the joined arena views."""
+    if op.kind == 'lin':
+        return op.mod.weight, op.mod.bias
+    a, b = op.mod.heads
+    arena = getattr(a.weight, '_arena', None)
+    if arena is None:
+        raise RuntimeError('paired heads need the parameter arena (call model.finalize())')
+    w, _ = arena.joined(a.weight, b.weight)
+    bias, _ = arena.joined(a.bias, b.bias)
+    return w, bias
+
+
+def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True):
+    """Run the plan.  Returns (output, tape); tape is None when not training."""
+    masks = list(masks) if masks is not None else []
+    tape = [] if training else None
+    h = x
+    for op in plan:
+        saved = None
+        if op.kind in ('lin', 'lin2'):
+            if h.dim() != 2 or h.stride(1) != 1:
+                raise RuntimeError('Linear expects a [rows, features] input with unit column stride')
+            w, b = _lin_weights(op)
+            M, N = h.shape[0], w.shape[0]
+            mask = None
+            if op.drop > 0 and training:
+                if not masks:
+                    raise RuntimeError('stack has a Dropout but no keep-mask was supplied')
+                mask = masks.pop(0)
+            if op.act:
+                pre = torch.empty(M, N, dtype=torch.float32, device=h.device) if training else None
+                act = torch.empty(M, N, dtype=torch.float32, device=h.device)
+                K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, act, mask,
+                             1.0 / (1.0 - op.drop) if mask is not None else 1.0)
+                saved = (h, pre, mask)
+                h = act
+            else:
+                pre = torch.empty(M, N, dtype=torch.float32, device=h.device)
+                K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, None)
+                saved = (h, None, None)
+                h = pre
+        elif op.kind in ('conv', 'convT'):
+            m = op.mod
+            s, p = m.stride[0], m.padding[0]
+            h = h.contiguous()
+            Bn, _, H, W = h.shape
+            if op.kind == 'conv':
+                Cout, OH, OW = m.out_channels, (H + 2 * p - 4) // s + 1, (W + 2 * p - 4) // s + 1
+            else:
+                Cout, OH, OW = m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4
+            pre = act = None
+            if (not op.act) or training:
+                pre = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
+            if op.act:
+                act = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
+            (K.conv2d_fwd if op.kind == 'conv' else K.convT2d_fwd)(h, m.weight.detach(), pre, act, s, p)
+            saved = (h, pre if op.act else None, None)
+            h = act if op.act else pre
+        elif op.kind == 'bn':
+            m = op.mod
+            h = h.contiguous()
+            y = torch.empty_like(h)
+            if training:
+                C = h.shape[1]
+                sm = torch.empty(groups, C, dtype=torch.float32, device=h.device)
+                si = torch.empty(groups, C, dtype=torch.float32, device=h.device)
+                K.bn_train_fwd(h, m.weight.detach(), m.bias.detach(), y, sm, si, m.running_mean,
+                               m.running_var, groups, eps=m.eps, momentum=m.momentum,
+                               n_updates=bn_updates, swish=op.act)
+                m._nbt_pending += groups * bn_updates
+                saved = (h, sm, si)
+            else:
+                K.bn_eval_fwd(h, m.weight.detach(), m.bias.detach(), y, m.running_mean, m.running_var,
+                              eps=m.eps, swish=op.act)
+            h = y
+        elif op.kind == 'emb':
+            m = op.mod
+            idx = h.contiguous()
+            act = torch.empty(idx.numel(), m.embedding_dim, dtype=torch.float32, device=idx.device)
+            K.embedding_swish_fwd(idx, m.weight.detach(), act)
+            saved = (idx,)
+            h = act
+        elif op.kind == 'view':
+            h = h.reshape((-1,) + op.mod.shape)
+        if training:
+            tape.append(saved)
+    return h, tape
+
+
+def _producer(plan, tape, i):
+    """(pre, mask, drop) of the activated Linear/conv that produced op i's input, skipping views."""
+    j = i - 1
+    while j >= 0 and plan[j].kind == 'view':
+        j -= 1
+    if j >= 0 and plan[j].act and plan[j].kind in ('lin', 'lin2', 'conv', 'convT'):
+        return tape[j][1], tape[j][2], plan[j].drop
+    return None, None, 0.0
+
+
+def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out=None,
+                  input_grad_accumulate=False):
+    """Backward through the plan.  ``g`` = gradient w.r.t. the stack output.  Parameter
+    gradients go to ``p.grad`` (the arena); returns the input gradient or None.
+    ``input_grad_out`` (stacks that start with a Linear): write -- or with
+    ``input_grad_accumulate`` add -- the input gradient into this buffer (the shared dz of the
+    decoders) instead of allocating one."""
+    last = len(plan) - 1
+    while last >= 0 and plan[last].kind == 'view':
+        last -= 1
+    if plan[last].act and plan[last].kind in ('lin', 'lin2', 'conv', 'convT'):
+        pre = tape[last][1]
+        g2 = torch.empty_like(pre)
+        K.swish_bwd(g.reshape(pre.shape).contiguous(), pre, g2)
+        if tape[last][2] is not None:
+            raise RuntimeError('a stack may not end in Dropout')
+        g = g2
+    first = 0
+    while first < len(plan) and plan[first].kind == 'view':
+        first += 1
+    for i in range(len(plan) - 1, -1, -1):
+        op, saved = plan[i], tape[i]
+        want_dx = need_input_grad or i > first
+        if op.kind == 'view':
+            continue
+        pre_in, mask_in, drop_in = _producer(plan, tape, i)
+        if op.kind in ('lin', 'lin2'):
+            x = saved[0]
+            g = g.reshape(x.shape[0], -1)
+            if g.stride(1) != 1:
+                g = g.contiguous()
+            _lin_wgrad(op, g, x)
+            if want_dx:
+                w, _ = _lin_weights(op)
+                acc = False
+                if i == first and input_grad_out is not None:
+                    dx, acc = input_grad_out, input_grad_accumulate
+                else:
+                    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                K.linear_dgrad(g, w.detach(), dx, pre_in, mask_in,
+                               1.0 / (1.0 - drop_in) if mask_in is not None else 1.0, accumulate=acc)
+                g = dx
+        elif op.kind in ('conv', 'convT'):
+            m = op.mod
+            x = saved[0]
+            s, p = m.stride[0], m.padding[0]
+            out_shape = _conv_out_shape(op, x)
+            g = g.reshape(out_shape).contiguous()
+            dw, acc = grad_target(m.weight)
+            (K.conv2d_wgrad if op.kind == 'conv' else K.convT2d_wgrad)(g, x, dw, s, p, accumulate=acc)
+            if want_dx:
+                dx = torch.empty_like(x)
+                (K.conv2d_dgrad if op.kind == 'conv' else K.convT2d_dgrad)(
+                    g, m.weight.detach(), dx, None if pre_in is None else pre_in.reshape(x.shape), s, p)
+                g = dx
+        elif op.kind == 'bn':
+            m = op.mod
+            x, sm, si = saved
+            g = g.reshape(x.shape).contiguous()
+            dgam, acc1 = grad_target(m.weight)
+            dbet, acc2 = grad_target(m.bias)
+            if acc1 != acc2:
+                raise RuntimeError('BatchNorm weight/bias gradients out of sync')
+            dx = torch.empty_like(x)
+            K.bn_train_bwd(g, x, m.weight.detach(), m.bias.detach(), sm, si, dx, dgam, dbet, groups,
+                           swish=op.act, accumulate=acc1)
+            if pre_in is not None:
+                raise RuntimeError('BatchNorm input must come from a non-activated layer')
+            g = dx
+        elif op.kind == 'emb':
+            m = op.mod
+            dw, acc = grad_target(m.weight)
+            K.embedding_swish_bwd(saved[0], m.weight.detach(), g.contiguous(), dw, accumulate=acc)
+            g = None
+    return g if need_input_grad else None
+
+
+def _conv_out_shape(op, x):
+    m = op.mod
+    s, p = m.stride[0], m.padding[0]
+    Bn, _, H, W = x.shape
+    if op.kind == 'conv':
+        return (Bn, m.out_channels, (H + 2 * p - 4) // s + 1, (W + 2 * p - 4) // s + 1)
+    return (Bn, m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4)
+
+
+def _lin_wgrad(op, g, x):
+    if op.kind == 'lin':
+        m = op.mod
+        dw, acc = grad_target(m.weight)
+        db = None
+        if m.bias is not None:
+            db, acc_b = grad_target(m.bias)
+            if acc_b != acc:
+                raise RuntimeError('Linear weight/bias gradients out of sync')
+        K.linear_wgrad(g, x, dw, db, accumulate=acc)
+    else:
+        a, b = op.mod.heads
+        arena = a.weight._arena
+        acc = a.weight.grad is not None
+        for p in (a.weight, a.bias, b.weight, b.bias):
+            if (p.grad is not None) != acc:
+                raise RuntimeError('paired-head gradients out of sync')
+            grad_target(p)
+        _, dw = arena.joined(a.weight, b.weight)
+        _, db = arena.joined(a.bias, b.bias)
+        K.linear_wgrad(g, x, dw, db, accumulate=acc)
+
+
+# ----------------------------------------------------------------------------- autograd bridge
+class StackFn(torch.autograd.Function):
+    """autograd wrapper used by the module surface.  Parameters are passed as inputs only so
+    that autograd schedules the backward; their gradients are written to the arena by the
+    kernels and ``None`` is returned for them."""
+
+    @staticmethod
+    def forward(ctx, x, holder, *params):
+        plan, groups, masks, bn_updates = holder
+        out, tape = forward_tape(plan, x, groups=groups, masks=masks, bn_updates=bn_updates, training=True)
+        ctx.plan, ctx.tape, ctx.groups = plan, tape, groups
+        ctx.n_params = len(params)
+        ctx.x_needs_grad = bool(ctx.needs_input_grad[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = backward_tape(ctx.plan, ctx.tape, g, need_input_grad=ctx.x_needs_grad, groups=ctx.groups)
+        ctx.tape = None
+        return (gx, None) + (None,) * ctx.n_params
+
+
+def run_plan(plan, x, groups=1, masks=None, bn_updates=1, training=True):
+    """Module-surface entry: autograd-tracked in training mode, plain launches otherwise."""
+    if not x.is_cuda:
+        raise RuntimeError('multimodal-vae-public_amd runs on the GPU only (input on %s): move the model '
+                           'and the batch to cuda; there is no CPU fallback' % x.device)
+    if training and torch.is_grad_enabled():
+        return StackFn.apply(x, (plan, groups, masks, bn_updates), *plan_params(plan))
+    out, _ = forward_tape(plan, x, groups=groups, masks=masks, bn_updates=bn_updates, training=training)
+    return out
+
+
+def run_stack(mods, x):
+    mods = list(mods)
+    training = any(m.training for m in mods)
+    return run_plan(compile_plan(mods), x, training=training)

@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mvae_hip.h declares; host-side
+plan compilation, arena layout and error behaviour (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import mvae_amd
+from mvae_amd import _lib, layers as L
+from mvae_amd.arena import ParamArena
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'mvae_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mvae_[a-zA-Z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), 'libmvae_hip.so is not built: run __graft_entry__.build()'
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
+    assert handle.mvae_abi_version() == 1
+
+
+def test_binding_table_matches_header():
+    assert _lib.exported_symbols() == _header_functions()
+    _lib.lib()   # sets argtypes for every entry; AttributeError = mismatch
+
+
+def test_workspace_queries_are_pure_host_calls():
+    lib = _lib.lib()
+    assert lib.mvae_wgrad_ws_bytes(512, 784, 1024) > 0
+    assert lib.mvae_wgrad_ws_bytes(0, 784, 1024) == 0
+    assert lib.mvae_bn_ws_bytes(3, 64, 256 * 256) == 3 * 64 * 16 * 3 * 4
+
+
+def test_bad_arguments_return_error_codes_without_a_gpu():
+    lib = _lib.lib()
+    # null pointers / bad shapes are rejected on the host before any launch
+    assert lib.mvae_linear_fwd(None, 4, None, None, None, None, 4, None, 1.0, 4, 4, 4, None) == -1
+    assert lib.mvae_conv2d_k4_fwd(None, None, None, None, 1, 1, 8, 8, 1, 3, 1, None) == -1
+    assert lib.mvae_fill(None, 4, 0.0, None) == -1
+
+
+def test_no_cpu_fallback():
+    m = mvae_amd.mnist.model.MVAE(8)
+    with pytest.raises(RuntimeError, match='GPU'):
+        m(torch.zeros(2, 1, 28, 28), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(RuntimeError, match='GPU'):
+        m.finalize()
+    with pytest.raises(RuntimeError, match='GPU'):
+        mvae_amd.functional.elbo_loss_label(None, None, None, None, torch.zeros(2, 8), torch.zeros(2, 8))
+
+
+@pytest.mark.parametrize('kind,n_latents,n_params', [
+    ('mnist', 64, 2588186), ('fashionmnist', 64, 7689610), ('celeba', 100, 6373346),
+    ('celeba19', 100, 22395690)])
+def test_state_dict_keys_and_sizes_match_reference(kind, n_latents, n_params):
+    """parameter counts dumped from the reference modules; key sets are
+    compared with the oracle modules, which load into the real reference in make_golden.py."""
+    from oracle import models as OM
+    model = getattr(mvae_amd, kind).model.MVAE(n_latents)
+    assert sum(p.numel() for p in model.parameters()) == n_params
+    ref = OM.MODELS[kind][0](n_latents).state_dict()
+    mine = model.state_dict()
+    assert set(ref.keys()) == set(mine.keys())
+    for k in ref:
+        assert tuple(ref[k].shape) == tuple(mine[k].shape), k
+
+
+def test_plan_compilation_fuses_the_reference_layer_patterns():
+    c = mvae_amd.celeba.model.MVAE(100)
+    enc = [(op.kind, op.act, op.drop) for op in c.image_encoder.plan()]
+    assert enc == [('conv', True, 0.0), ('conv', False, 0.0), ('bn', True, 0.0), ('conv', False, 0.0),
+                   ('bn', True, 0.0), ('conv', False, 0.0), ('bn', True, 0.0), ('view', False, 0.0),
+                   ('lin', True, 0.1), ('lin', False, 0.0)]
+    dec = [(op.kind, op.act) for op in c.image_decoder.plan()]
+    assert dec == [('lin', True), ('view', False), ('convT', False), ('bn', True), ('convT', False),
+                   ('bn', True), ('convT', False), ('bn', True), ('convT', False)]
+    m = mvae_amd.mnist.model.MVAE(64)
+    assert [op.kind for op in m.text_encoder.plan()] == ['emb', 'lin', 'lin2']
+    with pytest.raises(RuntimeError, match='4x4'):
+        L.compile_plan([L.Conv2d(3, 8, 3, 1, 1, bias=False)])
+
+
+def test_arena_layout_on_cpu_tensors():
+    """The arena itself is device-agnostic bookkeeping; check ordering/adjacency/alignment."""
+    m = mvae_amd.mnist.model.MVAE(64)
+    arena = ParamArena(m, order=m.arena_order(), adjacent=m.arena_adjacent())
+    assert arena.numel >= 2588186
+    enc = m.image_encoder
+    assert enc.fc31.weight._arena_off + enc.fc31.weight.numel() == enc.fc32.weight._arena_off
+    assert enc.fc31.bias._arena_off + enc.fc31.bias.numel() == enc.fc32.bias._arena_off
+    w, _ = arena.joined(enc.fc31.weight, enc.fc32.weight)
+    assert w.shape == (128, 512)
+    assert torch.equal(w[:64], enc.fc31.weight) and torch.equal(w[64:], enc.fc32.weight)
+    for p in arena.params:
+        assert p.data_ptr() == arena.flat.data_ptr() + 4 * p._arena_off
+    # decoders first (backward-completion order), every range inside the arena
+    lo_d, hi_d = arena.module_ranges[m.image_decoder]
+    lo_e, hi_e = arena.module_ranges[m.image_encoder]
+    assert lo_d == 0 and hi_d <= lo_e
+    from mvae_amd.parallel import bucket_ranges
+    (a0, a1), (b0, b1) = bucket_ranges(m, arena)
+    assert a0 == 0 and a1 == b0 and b1 == arena.numel
+    # state_dict round trip keeps the views
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert enc.fc1.weight.data_ptr() == arena.flat.data_ptr() + 4 * enc.fc1.weight._arena_off

@@ -1,0 +1,189 @@
+"""GPU parity proper: the HIP train step (fused engine and the reference-surface module path)
+against (i) the golden fixtures captured from the real reference and (ii) the live oracle on
+fresh seeds at other batch sizes.  Bar: 1e-4 relative on ELBO terms, latents and every
+gradient (north_star); BatchNorm running statistics 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import mvae_amd
+from mvae_amd.engine import BimodalStep
+from mvae_amd.optim import FusedAdam
+from oracle import models as OM, steps as OS
+from util import REL_TOL, assert_close, golden_noise, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build_pair(kind, weight_seed):
+    cls, d = OM.MODELS[kind]
+    oracle = OM.fill_parameters(cls(d), weight_seed)
+    oracle.train()
+    model = getattr(mvae_amd, kind).model.MVAE(d)
+    model.load_state_dict(oracle.state_dict())
+    model.to(DEV).train()
+    model.finalize()
+    return oracle, model, d
+
+
+def check_grads_vs_golden(model, fx):
+    for name, p in model.named_parameters():
+        assert p.grad is not None, 'no gradient for ' + name
+        gv = p.grad.detach().reshape(-1).cpu()
+        assert_close(gv.double().norm().item(), fx['gnorm/' + name], 'grad norm ' + name)
+        ref = fx['ghead/' + name]
+        scale = max(float(np.abs(ref).max()), float(fx['gnorm/' + name]) / max(gv.numel(), 1) ** 0.5, 1e-12)
+        err = np.abs(gv[:8].numpy() - ref).max() / scale
+        assert err <= REL_TOL, 'grad head %s: %.3e' % (name, err)
+
+
+def check_grads_vs_oracle(model, oracle):
+    og = dict(oracle.named_parameters())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        assert p.grad is not None, 'no gradient for ' + name
+        worst = max(worst, assert_close(p.grad, og[name].grad, 'grad ' + name))
+    return worst
+
+
+def check_bn_vs(model, ref_sd, tol=1e-5):
+    sd = model.state_dict()
+    for k, v in ref_sd.items():
+        if 'running_' in k or 'num_batches' in k:
+            assert_close(sd[k].double(), torch.as_tensor(np.asarray(v)).double(), 'bn ' + k, tol=tol)
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 4), ('mnist', 8), ('fashionmnist', 4), ('fashionmnist', 8),
+                                        ('celeba', 4), ('celeba', 8)])
+def test_fused_step_matches_reference_goldens(golden_dir, kind, batch):
+    fx, meta = load_golden(golden_dir, '%s_b%d' % (kind, batch))
+    _, model, d = build_pair(kind, meta['weight_seed'])
+    image, label = OS.synthetic_batch(kind, batch, meta['input_seed'])
+    eng = BimodalStep(model, batch, meta['lambda_image'], meta['lambda_label'])
+    elbo = eng.step(image.to(DEV), label.to(DEV), meta['beta'], noise=golden_noise(fx, 3))
+    terms = eng.terms_in_reference_order(elbo).cpu()
+    assert_close(terms[:3], fx['terms'], 'ELBO terms')
+    assert_close(terms[3].item(), fx['total'], 'total loss')
+    mu, lv, z = eng.last_latents
+    for c in range(3):
+        t = eng.ref_order.index(c)
+        assert_close(mu[t], fx['mu%d' % c], 'mu%d' % c)
+        assert_close(lv[t], fx['logvar%d' % c], 'logvar%d' % c)
+        assert_close(z[t], fx['z%d' % c], 'z%d' % c)
+    check_grads_vs_golden(model, fx)
+    check_bn_vs(model, {k[3:]: v for k, v in fx.items() if k.startswith('bn/')})
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 96), ('fashionmnist', 40), ('celeba', 12)])
+def test_fused_step_matches_live_oracle(kind, batch):
+    oracle, model, d = build_pair(kind, weight_seed=11)
+    image, label = OS.synthetic_batch(kind, batch, seed=77)
+    torch.manual_seed(5)
+    noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+    lam_i, lam_l, beta = 1.0, (10.0 if kind == 'celeba' else 50.0), 0.37
+    total, terms, lat = OS.bimodal_step(oracle, kind, image, label, noise, lam_i, lam_l, beta)
+    total.backward()
+    eng = BimodalStep(model, batch, lam_i, lam_l)
+    elbo = eng.terms_in_reference_order(eng.step(image.to(DEV), label.to(DEV), beta, noise=noise)).cpu()
+    assert_close(elbo[:3], torch.stack(terms).detach(), 'ELBO terms')
+    assert_close(elbo[3], total.detach(), 'total')
+    worst = check_grads_vs_oracle(model, oracle)
+    check_bn_vs(model, oracle.state_dict())
+    print('%s B=%d worst gradient rel err %.2e' % (kind, batch, worst))
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6)])
+def test_module_surface_matches_live_oracle(kind, batch):
+    """The reference's own call pattern: three model() calls, three elbo_loss calls, backward
+    (mnist/train.py:200-218) on the drop-in nn.Module + functional surface."""
+    import mvae_amd.functional as MF
+    oracle, model, d = build_pair(kind, weight_seed=13)
+    image, label = OS.synthetic_batch(kind, batch, seed=78)
+    torch.manual_seed(6)
+    noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+    lam_i, lam_l, beta = 1.0, 10.0, 0.5
+    total, terms, lat = OS.bimodal_step(oracle, kind, image, label, noise, lam_i, lam_l, beta)
+    total.backward()
+
+    img, lbl = image.to(DEV), label.to(DEV)
+    eps = [e.to(DEV) for e in noise['eps']]
+    model.zero_grad()
+    if kind == 'celeba':
+        elbo = MF.elbo_loss_attrs
+        r1 = model(img, lbl, eps=eps[0], dropout_mask=noise['mask'][0].to(DEV))
+        r2 = model(img, eps=eps[1], dropout_mask=noise['mask'][1].to(DEV))
+        r3 = model(attrs=lbl, eps=eps[2])
+        kw = dict(lambda_image=lam_i, lambda_attrs=lam_l, annealing_factor=beta)
+    else:
+        elbo = MF.elbo_loss_label
+        r1 = model(img, lbl, eps=eps[0])
+        r2 = model(img, eps=eps[1])
+        r3 = model(text=lbl, eps=eps[2])
+        kw = dict(lambda_image=lam_i, lambda_text=lam_l, annealing_factor=beta)
+    joint = elbo(r1[0], img, r1[1], lbl, r1[2], r1[3], **kw)
+    iloss = elbo(r2[0], img, None, None, r2[2], r2[3], **kw)
+    lloss = elbo(None, None, r3[1], lbl, r3[2], r3[3], **kw)
+    train_loss = joint + iloss + lloss
+    train_loss.backward()
+    assert_close(torch.stack([joint, iloss, lloss]).detach(), torch.stack(terms).detach(), 'ELBO terms')
+    assert_close(r1[2], lat[0][0].detach(), 'mu (joint)')
+    assert_close(r1[3], lat[0][1].detach(), 'logvar (joint)')
+    check_grads_vs_oracle(model, oracle)
+    check_bn_vs(model, oracle.state_dict())
+
+
+def test_eval_mode_and_error_behaviour():
+    import mvae_amd.functional as MF
+    oracle, model, d = build_pair('celeba', weight_seed=17)
+    image, label = OS.synthetic_batch('celeba', 5, seed=79)
+    oracle.eval(); model.eval()
+    with torch.no_grad():
+        ri, ra, mu, lv, z = oracle(image, label)
+        hi, ha, hmu, hlv = model(image.to(DEV), label.to(DEV))
+    assert_close(hmu, mu, 'eval mu'); assert_close(hlv, lv, 'eval logvar')
+    assert_close(hi, ri, 'eval image logits'); assert_close(ha, ra, 'eval attr logits')
+    with pytest.raises(ValueError, match='Target size'):
+        MF.binary_cross_entropy_with_logits(torch.zeros(4, 3, device=DEV), torch.zeros(4, 2, device=DEV))
+    with pytest.raises(ValueError, match='Target size'):
+        MF.cross_entropy(torch.zeros(4, 10, device=DEV), torch.zeros(3, dtype=torch.long, device=DEV))
+    x = torch.randn(6, 10, device=DEV); y = torch.randint(0, 10, (6,), device=DEV)
+    from oracle import functional as OF
+    assert_close(MF.cross_entropy(x, y), OF.cross_entropy(x.cpu(), y.cpu()), 'cross_entropy matrix')
+    t = torch.rand(6, 10, device=DEV)
+    assert_close(MF.binary_cross_entropy_with_logits(x, t),
+                 OF.binary_cross_entropy_with_logits(x.cpu(), t.cpu()), 'bce elementwise')
+
+
+def test_training_trajectory_with_fused_adam_and_graph():
+    """5 optimizer steps: eager engine + FusedAdam vs oracle + torch.optim.Adam on the same
+    noise; then the same model under hipGraph replay keeps training (loss finite, parameters
+    move, captured state restored exactly)."""
+    kind, batch = 'mnist', 32
+    oracle, model, d = build_pair(kind, weight_seed=19)
+    opt_ref = torch.optim.Adam(oracle.parameters(), lr=1e-3)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    eng = BimodalStep(model, batch, 1.0, 50.0)
+    for step in range(5):
+        image, label = OS.synthetic_batch(kind, batch, seed=200 + step)
+        torch.manual_seed(300 + step)
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=False)
+        opt_ref.zero_grad()
+        total, _, _ = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, 50.0, 0.1 * (step + 1))
+        total.backward(); opt_ref.step()
+        elbo = eng.step(image.to(DEV), label.to(DEV), 0.1 * (step + 1), noise=noise)
+        opt.step()
+        assert_close(elbo[3], total.detach(), 'loss at step %d' % step)
+    for (n, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        assert_close(p, q, 'param after 5 steps ' + n, tol=2e-4)
+    before = model.arena.flat.clone()
+    image, label = OS.synthetic_batch(kind, batch, seed=400)
+    eng.capture(opt, image.shape[1:], label)
+    assert torch.equal(before, model.arena.flat), 'capture() must not change the parameters'
+    losses = []
+    for step in range(4):
+        image, label = OS.synthetic_batch(kind, batch, seed=500 + step)
+        losses.append(eng.replay(image.to(DEV), label.to(DEV), 0.5)[3].item())
+    assert all(np.isfinite(losses)) and len(set(losses)) == 4
+    assert not torch.equal(before, model.arena.flat)
+    assert opt._step_dev.item() == 5 + 4

@@ -1,0 +1,407 @@
+"""GPU: every HIP kernel against a plain torch-CPU fp32 reference of the same op, called
+through the C ABI (mvae_amd.kernels -> ctypes -> libmvae_hip.so).  Tolerance: 1e-4 relative
+(max |err| / max |ref|), the north_star bound; most ops land near 1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mvae_amd
+from mvae_amd import kernels as K
+from oracle import functional as OF
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def g(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def dev(t):
+    return None if t is None else t.to(DEV)
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def swish_grad(x):
+    s = torch.sigmoid(x)
+    return s * (1 + x * (1 - s))
+
+
+# ----------------------------------------------------------------------------- Linear
+LIN_SHAPES = [(128, 512, 784), (512, 128, 512), (37, 10, 512), (256, 512, 18), (300, 1, 512),
+              (64, 200, 6400), (1024, 6272, 512), (130, 100, 200), (3, 5, 7)]
+
+
+@pytest.mark.parametrize('M,N,Kd', LIN_SHAPES)
+def test_linear_fwd(M, N, Kd):
+    x, w, b = g(M, Kd, seed=1), g(N, Kd, seed=2, scale=Kd ** -0.5), g(N, seed=3)
+    pre = torch.empty(M, N, device=DEV); act = torch.empty(M, N, device=DEV)
+    K.linear_fwd(dev(x), dev(w), dev(b), pre, act)
+    ref = x @ w.t() + b
+    assert_close(pre, ref, 'linear pre')
+    assert_close(act, swish(ref), 'linear act')
+    # dropout mask fused on the activation, no pre buffer
+    mask = (torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.9).float()
+    act2 = torch.empty(M, N, device=DEV)
+    K.linear_fwd(dev(x), dev(w), dev(b), None, act2, dev(mask), 1 / 0.9)
+    assert_close(act2, swish(ref) * (mask / 0.9), 'linear act*mask')
+    # no bias
+    K.linear_fwd(dev(x), dev(w), None, pre, None)
+    assert_close(pre, x @ w.t(), 'linear nobias')
+
+
+@pytest.mark.parametrize('M,N,Kd', LIN_SHAPES)
+def test_linear_dgrad(M, N, Kd):
+    dy, w = g(M, N, seed=5), g(N, Kd, seed=6, scale=N ** -0.5)
+    pre_in = g(M, Kd, seed=7)
+    mask = (torch.rand(M, Kd, generator=torch.Generator().manual_seed(8)) < 0.9).float()
+    dx = torch.empty(M, Kd, device=DEV)
+    K.linear_dgrad(dev(dy), dev(w), dx)
+    ref = dy @ w
+    assert_close(dx, ref, 'dgrad plain')
+    K.linear_dgrad(dev(dy), dev(w), dx, dev(pre_in))
+    assert_close(dx, ref * swish_grad(pre_in), 'dgrad * swish\'')
+    K.linear_dgrad(dev(dy), dev(w), dx, dev(pre_in), dev(mask), 1 / 0.9)
+    assert_close(dx, ref * (mask / 0.9) * swish_grad(pre_in), 'dgrad * mask * swish\'')
+    base = g(M, Kd, seed=9)
+    dx2 = dev(base).clone()
+    K.linear_dgrad(dev(dy), dev(w), dx2, accumulate=True)
+    assert_close(dx2, base + ref, 'dgrad accumulate')
+
+
+@pytest.mark.parametrize('M,N,Kd', LIN_SHAPES)
+def test_linear_wgrad(M, N, Kd):
+    dy, x = g(M, N, seed=10), g(M, Kd, seed=11)
+    dw = torch.empty(N, Kd, device=DEV); db = torch.empty(N, device=DEV)
+    K.linear_wgrad(dev(dy), dev(x), dw, db)
+    assert_close(dw, dy.t() @ x, 'wgrad dw')
+    assert_close(db, dy.sum(0), 'wgrad db')
+    K.linear_wgrad(dev(dy), dev(x), dw, db, accumulate=True)
+    assert_close(dw, 2 * (dy.t() @ x), 'wgrad dw accumulate')
+    assert_close(db, 2 * dy.sum(0), 'wgrad db accumulate')
+    dw2 = torch.empty(N, Kd, device=DEV)
+    K.linear_wgrad(dev(dy), dev(x), dw2, None)
+    assert_close(dw2, dy.t() @ x, 'wgrad no bias')
+
+
+def test_linear_strided_views():
+    """Row-strided operands: column slices of a [B, 2D] head and a column of the [rows, 18] logits."""
+    M, Kd = 96, 64
+    big = g(M, 2 * Kd, seed=12)
+    w, b = g(32, Kd, seed=13, scale=0.1), g(32, seed=14)
+    xs = dev(big)[:, Kd:]
+    pre = torch.empty(M, 32, device=DEV)
+    K.linear_fwd(xs, dev(w), dev(b), pre, None)
+    assert_close(pre, big[:, Kd:] @ w.t() + b, 'strided x')
+    out = torch.zeros(M, 18, device=DEV)
+    w1, b1 = g(1, Kd, seed=15), g(1, seed=16)
+    K.linear_fwd(dev(big)[:, :Kd], dev(w1), dev(b1), out[:, 5:6], None)
+    ref = torch.zeros(M, 18); ref[:, 5:6] = big[:, :Kd] @ w1.t() + b1
+    assert_close(out, ref, 'strided y (ldy=18)')
+
+
+# ----------------------------------------------------------------------------- Conv / ConvT
+CONV_CASES = [(4, 3, 64, 32, 2, 1), (3, 32, 32, 64, 2, 1), (2, 64, 16, 128, 2, 1), (2, 128, 8, 256, 1, 0),
+              (5, 1, 28, 64, 2, 1), (2, 64, 14, 128, 2, 1), (1, 5, 6, 7, 1, 0), (3, 2, 4, 3, 2, 1)]
+
+
+@pytest.mark.parametrize('B,Cin,H,Cout,s,p', CONV_CASES)
+def test_conv2d(B, Cin, H, Cout, s, p):
+    x = g(B, Cin, H, H, seed=20).requires_grad_()
+    w = g(Cout, Cin, 4, 4, seed=21, scale=(Cin * 16) ** -0.5).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    dy = g(*y.shape, seed=22)
+    y.backward(dy)
+    pre = torch.empty(*y.shape, device=DEV); act = torch.empty(*y.shape, device=DEV)
+    K.conv2d_fwd(dev(x.detach()), dev(w.detach()), pre, act, s, p)
+    assert_close(pre, y, 'conv fwd')
+    assert_close(act, swish(y.detach()), 'conv fwd act')
+    dx = torch.empty(*x.shape, device=DEV)
+    K.conv2d_dgrad(dev(dy), dev(w.detach()), dx, None, s, p)
+    assert_close(dx, x.grad, 'conv dgrad')
+    pre_in = g(*x.shape, seed=23)
+    K.conv2d_dgrad(dev(dy), dev(w.detach()), dx, dev(pre_in), s, p)
+    assert_close(dx, x.grad * swish_grad(pre_in), 'conv dgrad * swish\'')
+    dw = torch.empty(*w.shape, device=DEV)
+    K.conv2d_wgrad(dev(dy), dev(x.detach()), dw, s, p)
+    assert_close(dw, w.grad, 'conv wgrad')
+    K.conv2d_wgrad(dev(dy), dev(x.detach()), dw, s, p, accumulate=True)
+    assert_close(dw, 2 * w.grad, 'conv wgrad accumulate')
+
+
+CONVT_CASES = [(3, 256, 5, 128, 1, 0), (2, 128, 8, 64, 2, 1), (2, 64, 16, 32, 2, 1), (2, 32, 32, 3, 2, 1),
+               (4, 128, 7, 64, 2, 1), (3, 64, 14, 1, 2, 1), (2, 3, 2, 5, 1, 0)]
+
+
+@pytest.mark.parametrize('B,Cin,H,Cout,s,p', CONVT_CASES)
+def test_conv_transpose2d(B, Cin, H, Cout, s, p):
+    x = g(B, Cin, H, H, seed=30).requires_grad_()
+    w = g(Cin, Cout, 4, 4, seed=31, scale=(Cin * 4) ** -0.5).requires_grad_()
+    y = F.conv_transpose2d(x, w, None, s, p)
+    dy = g(*y.shape, seed=32)
+    y.backward(dy)
+    pre = torch.empty(*y.shape, device=DEV); act = torch.empty(*y.shape, device=DEV)
+    K.convT2d_fwd(dev(x.detach()), dev(w.detach()), pre, act, s, p)
+    assert_close(pre, y, 'convT fwd')
+    assert_close(act, swish(y.detach()), 'convT fwd act')
+    dx = torch.empty(*x.shape, device=DEV)
+    K.convT2d_dgrad(dev(dy), dev(w.detach()), dx, None, s, p)
+    assert_close(dx, x.grad, 'convT dgrad')
+    dw = torch.empty(*w.shape, device=DEV)
+    K.convT2d_wgrad(dev(dy), dev(x.detach()), dw, s, p)
+    assert_close(dw, w.grad, 'convT wgrad')
+
+
+# ----------------------------------------------------------------------------- BatchNorm
+@pytest.mark.parametrize('G,B,C,spatial', [(1, 16, 64, (16, 16)), (3, 8, 32, (32, 32)), (2, 6, 256, (5, 5)),
+                                           (3, 32, 512, ()), (1, 256, 512, ()), (2, 64, 128, (8, 8))])
+@pytest.mark.parametrize('act', [True, False])
+def test_batchnorm_train(G, B, C, spatial, act):
+    x = g(G * B, C, *spatial, seed=40) * 1.7 + 0.4
+    gamma, beta = 1 + 0.1 * g(C, seed=41), 0.1 * g(C, seed=42)
+    dy = g(*x.shape, seed=43)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(); gr = gamma.clone().requires_grad_(); br = beta.clone().requires_grad_()
+    outs = []
+    for gi in range(G):
+        for _ in range(2):   # n_updates = 2: the second call must not change the output
+            o = F.batch_norm(xr[gi * B:(gi + 1) * B], rm, rv, gr, br, True, 0.1, 1e-5)
+        outs.append(swish(o) if act else o)
+    yref = torch.cat(outs)
+    yref.backward(dy)
+    y = torch.empty(*x.shape, device=DEV)
+    sm = torch.empty(G, C, device=DEV); si = torch.empty(G, C, device=DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    K.bn_train_fwd(dev(x), dev(gamma), dev(beta), y, sm, si, rmd, rvd, G, n_updates=2, swish=act)
+    assert_close(y, yref, 'bn fwd')
+    assert_close(rmd, rm, 'bn running_mean', tol=1e-5)
+    assert_close(rvd, rv, 'bn running_var', tol=1e-5)
+    dx = torch.empty(*x.shape, device=DEV)
+    dg = torch.empty(C, device=DEV); db = torch.empty(C, device=DEV)
+    K.bn_train_bwd(dev(dy), dev(x), dev(gamma), dev(beta), sm, si, dx, dg, db, G, swish=act)
+    assert_close(dx, xr.grad, 'bn dx')
+    assert_close(dg, gr.grad, 'bn dgamma')
+    assert_close(db, br.grad, 'bn dbeta')
+    K.bn_train_bwd(dev(dy), dev(x), dev(gamma), dev(beta), sm, si, dx, dg, db, G, swish=act, accumulate=True)
+    assert_close(dg, 2 * gr.grad, 'bn dgamma accumulate')
+
+
+def test_batchnorm_eval():
+    x = g(6, 32, 8, 8, seed=44)
+    gamma, beta = 1 + 0.1 * g(32, seed=45), 0.1 * g(32, seed=46)
+    rm, rv = 0.3 * g(32, seed=47), 1 + 0.2 * torch.rand(32, generator=torch.Generator().manual_seed(48))
+    y = torch.empty(*x.shape, device=DEV)
+    K.bn_eval_fwd(dev(x), dev(gamma), dev(beta), y, dev(rm), dev(rv), swish=True)
+    assert_close(y, swish(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)), 'bn eval')
+
+
+# ----------------------------------------------------------------------------- small ops
+def test_swish_and_embedding():
+    x = g(1000, 37, seed=50) * 3
+    y = torch.empty(*x.shape, device=DEV)
+    K.swish_fwd(dev(x), y)
+    assert_close(y, swish(x), 'swish')
+    dy = g(*x.shape, seed=51)
+    dx = torch.empty(*x.shape, device=DEV)
+    K.swish_bwd(dev(dy), dev(x), dx)
+    assert_close(dx, dy * swish_grad(x), 'swish bwd')
+    for idx in (torch.randint(0, 10, (300,), generator=torch.Generator().manual_seed(52)),
+                torch.randint(0, 2, (300,), generator=torch.Generator().manual_seed(53)).float()):
+        ncls = 10 if idx.dtype == torch.int64 else 2
+        w = g(ncls, 512, seed=54).requires_grad_()
+        ref = swish(F.embedding(idx.long(), w))
+        da = g(300, 512, seed=55)
+        ref.backward(da)
+        act = torch.empty(300, 512, device=DEV)
+        K.embedding_swish_fwd(dev(idx), dev(w.detach()), act)
+        assert_close(act, ref, 'embedding fwd')
+        dw = torch.empty(ncls, 512, device=DEV)
+        K.embedding_swish_bwd(dev(idx), dev(w.detach()), dev(da), dw)
+        assert_close(dw, w.grad, 'embedding bwd')
+
+
+def test_dropout_fan():
+    h = g(40, 512, seed=56)
+    masks = (torch.rand(3, 40, 512, generator=torch.Generator().manual_seed(57)) < 0.9).float()
+    out = torch.empty(120, 512, device=DEV)
+    K.dropout_fanout_fwd(dev(h), dev(masks), out, 1 / 0.9)
+    assert_close(out, (h.unsqueeze(0) * (masks / 0.9)).reshape(120, 512), 'fanout')
+    dout = g(120, 512, seed=58)
+    dh = torch.empty(40, 512, device=DEV)
+    K.dropout_fanin_bwd(dev(dout), dev(masks), dh, 1 / 0.9)
+    assert_close(dh, (dout.reshape(3, 40, 512) * (masks / 0.9)).sum(0), 'fanin')
+
+
+# ----------------------------------------------------------------------------- PoE + reparam + KL
+@pytest.mark.parametrize('variant,D,B,E,masks', [
+    ('A', 64, 37, 2, [0b01, 0b11, 0b10]),
+    ('B', 100, 16, 3, [0b101, 0b010, 0b100]),
+    ('B', 100, 9, 19, [(1 << 19) - 1, 1, 2, 1 << 18, 0b1010101, 0b110]),
+])
+def test_poe(variant, D, B, E, masks):
+    T = len(masks)
+    heads = [g(B, 2 * D, seed=60 + e, scale=0.7).requires_grad_() for e in range(E)]
+    noise = g(T, B, D, seed=90)
+    mus_ref, lvs_ref, zs_ref, kls_ref = [], [], [], []
+    for t, m in enumerate(masks):
+        sel = [e for e in range(E) if (m >> e) & 1]
+        mu, lv = OF.poe_with_prior([heads[e][:, :D] for e in sel], [heads[e][:, D:] for e in sel], variant)
+        mus_ref.append(mu); lvs_ref.append(lv)
+        zs_ref.append(OF.reparametrize(mu, lv, noise[t])); kls_ref.append(OF.kl_rows(mu, lv))
+    mu_r, lv_r, z_r, kl_r = map(torch.stack, (mus_ref, lvs_ref, zs_ref, kls_ref))
+    dz, dmu, dlv, dkl = g(T, B, D, seed=91), g(T, B, D, seed=92), g(T, B, D, seed=93), g(T, B, seed=94)
+    ((z_r * dz).sum() + (mu_r * dmu).sum() + (lv_r * dlv).sum() + (kl_r * dkl).sum()).backward()
+
+    hd = [dev(h.detach()) for h in heads]
+    mus = [h[:, :D] for h in hd]; lvs = [h[:, D:] for h in hd]
+    md = torch.tensor(masks, dtype=torch.int32, device=DEV)
+    mu = torch.empty(T, B, D, device=DEV); lv = torch.empty_like(mu); z = torch.empty_like(mu)
+    kl = torch.empty(T, B, device=DEV)
+    K.poe_fwd(mus, lvs, md, dev(noise), mu, lv, z, kl, variant)
+    assert_close(mu, mu_r, 'poe mu', tol=1e-5)
+    assert_close(lv, lv_r, 'poe logvar', tol=1e-5)
+    assert_close(z, z_r, 'poe z', tol=1e-5)
+    assert_close(kl, kl_r, 'poe kl', tol=1e-5)
+    gh = [torch.empty_like(h) for h in hd]
+    K.poe_bwd(mus, lvs, md, dev(noise), mu, lv, dev(dz), dev(dmu), dev(dlv), dev(dkl),
+              [x[:, :D] for x in gh], [x[:, D:] for x in gh], variant)
+    for e in range(E):
+        assert_close(gh[e], heads[e].grad, 'poe grad expert %d' % e)
+    # eval mode: z = mu
+    K.poe_fwd(mus, lvs, md, None, mu, lv, z, kl, variant)
+    assert_close(z, mu_r, 'poe eval z', tol=1e-5)
+
+
+def test_poe_per_term_kl_scale():
+    B, D, T = 8, 64, 3
+    heads = [g(B, 2 * D, seed=70 + e).requires_grad_() for e in range(2)]
+    masks = [1, 3, 2]
+    coef = torch.tensor([0.1, 0.2, 0.3])
+    tot = 0
+    for t, m in enumerate(masks):
+        sel = [e for e in range(2) if (m >> e) & 1]
+        mu, lv = OF.poe_with_prior([heads[e][:, :D] for e in sel], [heads[e][:, D:] for e in sel], 'A')
+        tot = tot + coef[t] * OF.kl_rows(mu, lv).sum()
+    tot.backward()
+    hd = [dev(h.detach()) for h in heads]
+    mus = [h[:, :D] for h in hd]; lvs = [h[:, D:] for h in hd]
+    md = torch.tensor(masks, dtype=torch.int32, device=DEV)
+    mu = torch.empty(T, B, D, device=DEV); lv = torch.empty_like(mu); z = torch.empty_like(mu)
+    kl = torch.empty(T, B, device=DEV)
+    K.poe_fwd(mus, lvs, md, None, mu, lv, z, kl, 'A')
+    gh = [torch.empty_like(h) for h in hd]
+    K.poe_bwd(mus, lvs, md, None, mu, lv, None, None, None, dev(coef),
+              [x[:, :D] for x in gh], [x[:, D:] for x in gh], 'A', dkl_per_term=True)
+    for e in range(2):
+        assert_close(gh[e], heads[e].grad, 'kl-only grad expert %d' % e)
+
+
+def test_kl_and_reparam_standalone():
+    from mvae_amd.functional import ReparamFn, _KlRowsFn
+    mu, lv, eps = (g(33, 100, seed=s).requires_grad_(s < 98) for s in (96, 97, 98))
+    ref = (OF.reparametrize(mu, lv, eps).pow(2).sum() + (OF.kl_rows(mu, lv) * torch.arange(33.)).sum())
+    ref.backward()
+    md, ld = dev(mu.detach()).requires_grad_(), dev(lv.detach()).requires_grad_()
+    out = ReparamFn.apply(md, ld, dev(eps)).pow(2).sum() + (_KlRowsFn.apply(md, ld) * torch.arange(33., device=DEV)).sum()
+    out.backward()
+    assert_close(out, ref, 'kl+reparam value', tol=1e-5)
+    assert_close(md.grad, mu.grad, 'dmu')
+    assert_close(ld.grad, lv.grad, 'dlogvar')
+
+
+# ----------------------------------------------------------------------------- losses
+@pytest.mark.parametrize('R,P,groups,colw', [(12, 784, 2, False), (9, 12288, 3, False), (30, 18, 3, True),
+                                             (8, 1, 1, False), (6, 600, 1, True)])
+def test_bce_rowsum(R, P, groups, colw):
+    rpg = R // groups
+    x = (g(R, P, seed=100) * 3).requires_grad_()
+    t = torch.rand(rpg, P, generator=torch.Generator().manual_seed(101))
+    w = torch.rand(groups, P, generator=torch.Generator().manual_seed(102)) if colw else None
+    drow = torch.tensor([0.5, 0.0, 2.0][:groups])
+    el = OF.binary_cross_entropy_with_logits(x, t.repeat(groups, 1))
+    if colw:
+        el = el * w.repeat_interleave(rpg, 0)
+    rows_ref = el.sum(1)
+    (rows_ref * drow.repeat_interleave(rpg)).sum().backward()
+    rows = torch.empty(R, device=DEV); dl = torch.empty(R, P, device=DEV)
+    K.bce_rowsum_fwd(dev(x.detach()), dev(t), rows, colw=dev(w), drow=dev(drow), dlogits=dl,
+                     rows_per_group=rpg, target_rows=rpg)
+    assert_close(rows, rows_ref, 'bce rows', tol=1e-5)
+    assert_close(dl, x.grad, 'bce fused grad')
+    dl2 = torch.empty(R, P, device=DEV)
+    K.bce_rowsum_bwd(dev(x.detach()), dev(t), dev(drow), dl2, colw=dev(w), rows_per_group=rpg, target_rows=rpg)
+    assert_close(dl2, x.grad, 'bce bwd')
+
+
+def test_bce_matches_reference_subgradient_at_zero():
+    x = torch.tensor([[0.0, 0.0, -0.0, 1.5]], requires_grad=True)
+    t = torch.tensor([[0.25, 1.0, 0.0, 0.5]])
+    OF.binary_cross_entropy_with_logits(x, t).sum().backward()
+    dl = torch.empty(1, 4, device=DEV); rows = torch.empty(1, device=DEV)
+    K.bce_rowsum_fwd(dev(x.detach()), dev(t), rows, drow=torch.ones(1, device=DEV), dlogits=dl, rows_per_group=1)
+    assert torch.allclose(dl.cpu(), x.grad, atol=1e-7)
+
+
+def test_cross_entropy_rows():
+    R, Kc, groups = 24, 10, 2
+    x = (g(R, Kc, seed=103) * 2).requires_grad_()
+    y = torch.randint(0, Kc, (R // groups,), generator=torch.Generator().manual_seed(104))
+    drow = torch.tensor([0.7, 1.3])
+    rows_ref = OF.cross_entropy(x, y.repeat(groups)).sum(1)
+    (rows_ref * drow.repeat_interleave(R // groups)).sum().backward()
+    rows = torch.empty(R, device=DEV); dl = torch.empty(R, Kc, device=DEV)
+    K.ce_fwd(dev(x.detach()), dev(y), rows, drow=dev(drow), dlogits=dl, rows_per_group=R // groups,
+             label_rows=R // groups)
+    assert_close(rows, rows_ref, 'ce rows', tol=1e-5)
+    assert_close(dl, x.grad, 'ce grad')
+
+
+def test_group_sums():
+    rows = g(3 * 50, seed=105)
+    coef = torch.tensor([0.5, 0.0, 2.0])
+    out = torch.zeros(3, device=DEV); tot = torch.zeros(1, device=DEV)
+    K.group_sums(dev(rows), dev(coef), out, tot, 3, 50)
+    ref = rows.reshape(3, 50).sum(1) * coef
+    assert_close(out, ref, 'group sums', tol=1e-5)
+    assert_close(tot, ref.sum().reshape(1), 'group total', tol=1e-5)
+    K.group_sums(dev(rows), dev(coef), out, tot, 3, 50, accumulate=True)
+    assert_close(tot, 2 * ref.sum().reshape(1), 'group total accumulate', tol=1e-5)
+
+
+# ----------------------------------------------------------------------------- noise / Adam
+def test_philox_noise_statistics_and_counter():
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    a = torch.empty(1 << 20, device=DEV); b = torch.empty(1 << 20, device=DEV)
+    K.randn_(a, 1234, ctr); K.randn_(b, 1234, ctr)
+    assert ctr.item() == 2
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a * a * a * a).mean().item() - 3) < 0.05          # kurtosis of N(0,1)
+    assert (a != b).float().mean().item() > 0.999                  # a new launch is a new stream
+    ctr.zero_()
+    c = torch.empty(1 << 20, device=DEV)
+    K.randn_(c, 1234, ctr)
+    assert torch.equal(a, c)                                        # counter-based: reproducible
+    m = torch.empty(1 << 20, device=DEV)
+    K.bernoulli_(m, 0.9, 99, ctr)
+    assert abs(m.mean().item() - 0.9) < 2e-3 and set(m.unique().tolist()) == {0.0, 1.0}
+
+
+def test_fused_adam_matches_torch_adam():
+    n = 10007
+    p0, grads = g(n, seed=110), [g(n, seed=111 + i) for i in range(5)]
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = dev(p0).clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for gi in grads:
+        pr.grad = gi.clone(); opt.step()
+        K.adam_step(p, dev(gi * 4), m, v, step, 1e-3, grad_scale=0.25)
+    assert step.item() == 5
+    assert_close(p, pr.detach(), 'adam params', tol=1e-6)
+    assert_close(m, opt.state[pr]['exp_avg'], 'adam m', tol=1e-5)
+    assert_close(v, opt.state[pr]['exp_avg_sq'], 'adam v', tol=1e-5)

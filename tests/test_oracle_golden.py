@@ -1,0 +1,112 @@
+"""CPU: the oracle restatement reproduces the fixtures captured from the real reference
+(tests/golden/make_golden.py).  This is what pins the oracle -- the reference has no tests of
+its own."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as OM, steps as OS
+from util import assert_close, golden_noise, load_golden
+
+BIMODAL = [('mnist', 4), ('mnist', 8), ('fashionmnist', 4), ('fashionmnist', 8), ('celeba', 4), ('celeba', 8)]
+
+
+def _build(exp, meta):
+    cls, d = OM.MODELS[exp]
+    assert d == meta['n_latents']
+    model = OM.fill_parameters(cls(d), meta['weight_seed'])
+    model.train()
+    return model
+
+
+def _check_grads(model, fx):
+    for name, p in model.named_parameters():
+        g = p.grad.reshape(-1)
+        assert_close(g.double().norm().item(), fx['gnorm/' + name], 'grad norm ' + name)
+        ref = fx['ghead/' + name]
+        scale = max(float(np.abs(ref).max()), float(fx['gnorm/' + name]) / max(g.numel(), 1) ** 0.5, 1e-12)
+        err = np.abs(g[:8].numpy() - ref).max() / scale
+        assert err <= 1e-4, 'grad head %s: %.3e' % (name, err)
+
+
+def _check_bn(model, fx):
+    for k, v in model.state_dict().items():
+        if 'running_' in k or 'num_batches' in k:
+            assert_close(v.double(), fx['bn/' + k].astype(np.float64), 'bn ' + k, tol=1e-5)
+
+
+@pytest.mark.parametrize('exp,batch', BIMODAL)
+def test_bimodal_step_matches_reference(golden_dir, exp, batch):
+    torch.set_num_threads(4)
+    fx, meta = load_golden(golden_dir, '%s_b%d' % (exp, batch))
+    model = _build(exp, meta)
+    image, label = OS.synthetic_batch(exp, batch, meta['input_seed'])
+    if 'image' in fx:
+        assert np.array_equal(image.numpy(), fx['image'])
+    assert np.array_equal(label.numpy(), fx['label'])
+    noise = golden_noise(fx, 3)
+    total, terms, lat = OS.bimodal_step(model, exp, image, label, noise, meta['lambda_image'],
+                                        meta['lambda_label'], meta['beta'])
+    total.backward()
+    assert_close(total.item(), fx['total'], 'total', tol=2e-6)
+    assert_close([t.item() for t in terms], fx['terms'], 'terms', tol=2e-6)
+    for c in range(3):
+        assert_close(lat[c][0], fx['mu%d' % c], 'mu%d' % c, tol=1e-5)
+        assert_close(lat[c][1], fx['logvar%d' % c], 'logvar%d' % c, tol=1e-5)
+        assert_close(lat[c][2], fx['z%d' % c], 'z%d' % c, tol=1e-5)
+    _check_grads(model, fx)
+    _check_bn(model, fx)
+
+
+def test_noise_replay_matches_global_generator(golden_dir):
+    """draw_bimodal_noise under manual_seed(noise_seed) reproduces the recorded draws."""
+    fx, meta = load_golden(golden_dir, 'celeba_b4')
+    torch.manual_seed(meta['noise_seed'])
+    noise = OS.draw_bimodal_noise(meta['batch'], meta['n_latents'], has_dropout=True)
+    for c in range(3):
+        assert np.array_equal(noise['eps'][c].numpy(), fx['eps%d' % c])
+    assert np.array_equal(noise['mask'][0].numpy().astype(np.uint8), fx['mask0'])
+    assert np.array_equal(noise['mask'][1].numpy().astype(np.uint8), fx['mask1'])
+    assert noise['mask'][2] is None
+
+
+def test_celeba19_step_matches_reference(golden_dir):
+    torch.set_num_threads(4)
+    fx, meta = load_golden(golden_dir, 'celeba19_b4')
+    model = _build('celeba19', meta)
+    image, attrs = OS.synthetic_batch('celeba19', meta['batch'], meta['input_seed'])
+    terms = OS.celeba19_terms(fx['combos'].astype(bool))
+    assert len(terms) == 20 + meta['approx_m']
+    noise = golden_noise(fx, len(terms))
+    total, elbos, lat = OS.celeba19_step(model, image, attrs, terms, noise, meta['lambda_image'],
+                                         meta['lambda_label'], meta['beta'])
+    total.backward()
+    assert_close(total.item(), fx['total'], 'total', tol=2e-6)
+    assert_close([e.item() for e in elbos], fx['terms'], 'terms', tol=2e-6)
+    for c in (0, 1, 2, len(terms) - 1):
+        assert_close(lat[c][0], fx['mu%d' % c], 'mu%d' % c, tol=1e-5)
+        assert_close(lat[c][2], fx['z%d' % c], 'z%d' % c, tol=1e-5)
+    _check_grads(model, fx)
+    _check_bn(model, fx)
+
+
+def test_celeba19_combination_pool_and_sampling():
+    pool = OS.enumerate_combinations(6)
+    # all subsets of sizes 2..5 of 6 modalities: C(6,2)+C(6,3)+C(6,4)+C(6,5) = 15+20+15+6
+    assert pool.shape == (56, 6)
+    sums = pool.sum(1)
+    assert sums.min() == 2 and sums.max() == 5
+    assert len({tuple(r) for r in pool}) == 56
+    rng = np.random.RandomState(0)
+    s = OS.sample_combinations(pool, size=7, rng=rng)
+    assert s.shape == (7, 6) and s.dtype == bool
+    assert ((s.sum(1) >= 2) & (s.sum(1) <= 5)).all()
+
+
+def test_loss_helpers_error_behaviour():
+    """Same ValueError as the reference on mismatched sizes (mnist/train.py:69-71,85-88)."""
+    from oracle import functional as OF
+    with pytest.raises(ValueError, match='Target size'):
+        OF.binary_cross_entropy_with_logits(torch.zeros(4, 3), torch.zeros(4, 2))
+    with pytest.raises(ValueError, match='Target size'):
+        OF.cross_entropy(torch.zeros(4, 10), torch.zeros(3, dtype=torch.long))
