@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the MVAE train step on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mnist|fashionmnist|celeba|celeba19]
+                    [--batch B_PER_GPU]
+
+One "step" = zero_grad -> the three (celeba19: 20+M) ELBO terms forward -> backward ->
+[gradient all-reduce] -> Adam, on a synthetic random-pixel / random-label batch that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: MNIST MVAE,
+n-latents 64, batch 512 per GPU.  Weak scaling: the per-GPU batch is fixed as N grows.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline      -- the dominant kernel of the step, timed live with HIP events on the launch
+                   stream (profiler.KernelProfile) in this same process,
+  cpu_baseline  -- the oracle (CPU restatement of the reference step, kind "port") timed on the
+                   host cores of this box on a bounded sample of the same workload,
+  also          -- (default invocation only) the CelebA B=256 step: images/sec and the fp32-MFMA
+                   roofline of its conv kernels, the figure north_star's 40 % target is about.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+DEFAULT_BATCH = {'mnist': 512, 'fashionmnist': 1024, 'celeba': 256, 'celeba19': 256}
+LAMBDA_LABEL = {'mnist': 50.0, 'fashionmnist': 50.0, 'celeba': 10.0, 'celeba19': 10.0}
+N_LATENTS = {'mnist': 64, 'fashionmnist': 64, 'celeba': 100, 'celeba19': 100}
+LR = {'mnist': 1e-3, 'fashionmnist': 1e-3, 'celeba': 1e-4, 'celeba19': 1e-4}
+
+
+def synthetic(kind, batch, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    if kind in ('mnist', 'fashionmnist'):
+        image = torch.rand(batch, 1, 28, 28, generator=g)
+        label = torch.randint(0, 10, (batch,), generator=g)
+    else:
+        image = torch.rand(batch, 3, 64, 64, generator=g)
+        label = torch.randint(0, 2, (batch, 18), generator=g).float()
+    return image.to(device), label.to(device)
+
+
+def build(kind, batch, device, world, seed=0):
+    import mvae_amd
+    from mvae_amd.optim import FusedAdam
+    torch.manual_seed(seed)
+    model = getattr(mvae_amd, kind).model.MVAE(N_LATENTS[kind]).to(device).train()
+    model.finalize()
+    if kind == 'celeba19':
+        from mvae_amd.engine import Celeba19Step
+        eng = Celeba19Step(model, batch, 1.0, LAMBDA_LABEL[kind], approx_m=1, seed=1234)
+    else:
+        from mvae_amd.engine import BimodalStep
+        eng = BimodalStep(model, batch, 1.0, LAMBDA_LABEL[kind], seed=1234)
+    opt = FusedAdam(model.parameters(), lr=LR[kind], grad_scale=1.0 / world)
+    return model, eng, opt
+
+
+def annealing(step, total=2000):
+    return min(1.0, float(step + 1) / total)
+
+
+def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True):
+    import torch.distributed as dist
+    model, eng, opt = build(kind, batch, device, world)
+    dp = None
+    if world > 1:
+        from mvae_amd.parallel import DataParallel
+        dp = DataParallel(model, eng)
+    batches = [synthetic(kind, batch, 1234 + rank * 100 + i, device) for i in range(4)]
+    if use_graph:
+        eng.capture(opt, batches[0][0].shape[1:], batches[0][1], comm=dp)
+
+        def one(i):
+            img, lbl = batches[i % 4]
+            return eng.replay(img, lbl, annealing(i))
+    else:
+        def one(i):
+            img, lbl = batches[i % 4]
+            elbo = eng.step(img, lbl, annealing(i))
+            if dp is not None:
+                dp.wait()
+            opt.step()
+            return elbo
+    for i in range(warmup):
+        one(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        elbo = one(warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = float(elbo[-1].item())
+    return dt, loss, (model, eng, opt, batches)
+
+
+def roofline_from_profile(eng, opt, batches, n_steps=3):
+    """Eager steps with every launch bracketed by HIP events on the launch stream."""
+    from mvae_amd.profiler import GEMM_COSTS, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, KernelProfile
+    for i in range(2):
+        eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
+    with KernelProfile() as prof:
+        for i in range(n_steps):
+            eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
+            opt.step()
+    rows = prof.summary()
+    for r in rows:
+        r['ms_per_step'] = r['ms_total'] / n_steps
+    gemm = [r for r in rows if r['name'] in GEMM_COSTS]
+    dom = gemm[0]
+    flops_step = sum(r['flops'] * r['calls'] for r in gemm) / n_steps
+    ms_gemm = sum(r['ms_total'] for r in gemm) / n_steps
+    ms_all = sum(r['ms_total'] for r in rows) / n_steps
+    roof = {
+        'bound': 'mfma', 'kernel': 'igemm_kernel<%s %s>' % (dom['name'], dom['key']),
+        'achieved': round(dom['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+        'avg_launch_ms': round(dom['ms_avg'], 5), 'algorithmic_flops_per_launch': dom['flops'],
+        'all_gemm_kernels': {'tflops': round(flops_step / (ms_gemm * 1e-3) / 1e12, 3),
+                             'frac': round(flops_step / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                             'ms_per_step': round(ms_gemm, 4), 'gflop_per_step': round(flops_step / 1e9, 3)},
+        'kernel_ms_per_step_eager': round(ms_all, 4),
+    }
+    conv = [r for r in gemm if r['name'].startswith('conv')]
+    if conv:
+        fl = sum(r['flops'] * r['calls'] for r in conv) / n_steps
+        ms = sum(r['ms_total'] for r in conv) / n_steps
+        roof['conv_kernels'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 3),
+                                'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                'ms_per_step': round(ms, 4), 'gflop_per_step': round(fl / 1e9, 3)}
+    hbm = [r for r in rows if r['name'] not in GEMM_COSTS and r['bytes'] > 0]
+    if hbm:
+        top = max(hbm, key=lambda r: r['ms_total'])
+        roof['top_hbm_kernel'] = {'kernel': top['name'], 'gbs': round(top['gbs'], 1),
+                                  'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5)}
+    top5 = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_per_step'], 4),
+             'calls_per_step': r['calls'] / n_steps, 'tflops': round(r['tflops'], 2)} for r in rows[:6]]
+    roof['top_kernels'] = top5
+    return roof
+
+
+def cpu_baseline(kind, batch, budget_s=15.0):
+    """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
+    host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s."""
+    from oracle import models as OM, steps as OS
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cls, d = OM.MODELS[kind]
+    torch.manual_seed(0)
+    model = cls(d).train()
+    opt = torch.optim.Adam(model.parameters(), lr=LR[kind])
+    image, label = OS.synthetic_batch(kind, batch, 1234)
+    if kind == 'celeba19':
+        return None
+    n, t_total = 0, 0.0
+    for i in range(200):
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        total, _, _ = OS.bimodal_step(model, kind, image, label, noise, 1.0, LAMBDA_LABEL[kind], 0.5)
+        total.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i >= 1:          # first step pays one-time allocations
+            n += 1; t_total += dt
+        if t_total > budget_s and n >= 2:
+            break
+    return {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '
+                      '%d threads' % (n, kind, batch, torch.__version__, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='mnist', choices=sorted(DEFAULT_BATCH))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip roofline / cpu_baseline / also')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    kind = args.workload
+    batch = args.batch or DEFAULT_BATCH[kind]
+
+    dt, loss, state = timed_run(kind, batch, args.steps, args.warmup, device, world, rank,
+                                use_graph=not args.no_graph)
+    out = {
+        'metric': 'images/sec (MVAE train step)', 'value': round(world * batch * args.steps / dt, 1),
+        'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s MVAE train step, n-latents %d, batch %d per GPU' % (kind, N_LATENTS[kind], batch),
+                   'global_batch': world * batch, 'parallelism': 'dp%d' % world,
+                   'launch': 'eager' if args.no_graph else 'hipGraph replay', 'final_loss': round(loss, 3)},
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        model, eng, opt, batches = state
+        out['roofline'] = roofline_from_profile(eng, opt, batches)
+        out['cpu_baseline'] = cpu_baseline(kind, batch)
+        if kind == 'mnist' and args.batch is None:
+            del state, model, eng, opt, batches
+            torch.cuda.empty_cache()
+            dt2, loss2, st2 = timed_run('celeba', 256, 30, 5, device, 1, 0, use_graph=not args.no_graph)
+            out['also'] = [{'workload': 'celeba MVAE train step, n-latents 100, batch 256, 1 GPU',
+                            'value': round(256 * 30 / dt2, 1), 'unit': 'images/sec',
+                            'ms_per_step': round(dt2 / 30 * 1e3, 3), 'final_loss': round(loss2, 3),
+                            'roofline': roofline_from_profile(st2[1], st2[2], st2[3]),
+                            'cpu_baseline': cpu_baseline('celeba', 256, budget_s=12.0)}]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

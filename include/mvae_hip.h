@@ -116,8 +116,8 @@ int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, flo
                       float *save_mean, float *save_invstd,
                       float *running_mean, float *running_var,
                       int G, int B, int C, int HW, float eps, float momentum,
-                      int n_updates, int flags, void *ws, size_t ws_bytes,
-                      mvae_stream_t stream);
+                      int n_updates, const int *n_updates_dev /* nullable: overrides n_updates */,
+                      int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
                       const float *save_mean, const float *save_invstd,
                       float *dx, float *dgamma, float *dbeta,
@@ -193,7 +193,9 @@ int mvae_kl_rows_bwd(const float *mu, const float *logvar, const float *dkl,
  * K11 BCE-with-logits row sums: mnist/train.py:47-49,62-74; celeba/train.py:50-58,68-80;
  *     celeba19/train.py:52-57,63-75.  logits/target [R,P];
  *     rowsum[r] = sum_p colw[(r / rows_per_group), p] * bce(logits[r,p], target[r % target_rows, p])
- *     (colw NULL -> 1).  target is broadcast over row groups by `target_rows`.
+ *     (colw NULL -> 1).  target row of logits row r is (r / target_div) % target_rows, its element p
+ *     lives at row * target_row_stride + p * target_col_stride (contiguous: div 1, strides P and 1;
+ *     celeba19 reads column i of attrs[B,18] for decoder i with strides 1 and 18).
  *     bwd: dlogits[r,p] = drow[r / rows_per_group] * colw * dbce/dx  (drow is a DEVICE array;
  *     d loss / d rowsum is the constant lambda/B, so the fwd entry can emit it in the same pass).
  * K13 categorical CE: mnist/train.py:52,77-94.  row[r] = -log_softmax(logits[r,:]+1e-6)[label[r % label_rows]]
@@ -202,10 +204,12 @@ int mvae_kl_rows_bwd(const float *mu, const float *logvar, const float *dkl,
 int mvae_bce_rowsum_fwd(const float *logits, const float *target, const float *colw,
                         float *rowsum, const float *drow_dev, float *dlogits /* nullable: fused bwd */,
                         int R, int P, int rows_per_group, int target_rows,
+                        int target_div, int target_row_stride, int target_col_stride,
                         mvae_stream_t stream);
 int mvae_bce_rowsum_bwd(const float *logits, const float *target, const float *colw,
                         const float *drow_dev, float *dlogits,
                         int R, int P, int rows_per_group, int target_rows,
+                        int target_div, int target_row_stride, int target_col_stride,
                         mvae_stream_t stream);
 int mvae_ce_fwd(const float *logits, const int64_t *label, float *row,
                 const float *drow_dev, float *dlogits /* nullable: fused bwd */,
@@ -229,9 +233,22 @@ int mvae_randn(float *out, size_t n, uint64_t seed, uint64_t *counter_dev, mvae_
 int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t seed, uint64_t *counter_dev,
                    mvae_stream_t stream);
 int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                   size_t n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                    int64_t *step_dev, mvae_stream_t stream);
 int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
+
+/* CelebA-19 term plumbing (celeba19/train.py:264-302, celeba19/model.py:56-60): gather the z blocks
+ * a decoder needs, scatter-add the gradients back per term, and sum ELBO pieces by term table.
+ *   block_gather      : dst[j] = src[idx[j]]                     (blocks of block_elems floats)
+ *   block_scatter_add : dst[t] += sum_{j: idx[j]==t} src[j]      (j ascending: deterministic)
+ *   scatter_sums      : out[idx[j]] += coef[j]*vals[j]; *total (+)= sum_j coef[j]*vals[j]
+ * idx tables are DEVICE int32 so a captured graph follows each step's sampled subsets. */
+int mvae_block_gather(const float *src, const int *idx_dev, float *dst, int n_dst, size_t block_elems,
+                      mvae_stream_t stream);
+int mvae_block_scatter_add(const float *src, const int *idx_dev, float *dst, int n_src, int n_dst,
+                           size_t block_elems, mvae_stream_t stream);
+int mvae_scatter_sums(const float *vals, const float *coef_dev, const int *idx_dev, float *out,
+                      float *total_out, int n, int flags, mvae_stream_t stream);
 
 /* K7 Dropout fan-out (celeba/model.py:89-92 runs twice per step on the same batch; only the
  *    Bernoulli draw differs): out[g,b,:] = h[b,:] * masks[g,b,:] * scale, and its backward

@@ -7,7 +7,7 @@ wrapper in ``ops.py`` raises when it is handed a non-GPU tensor.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmvae_hip.so')
@@ -45,7 +45,7 @@ _SIGNATURES = {
     'mvae_convT2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
     'mvae_convT2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),
     'mvae_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'mvae_bn_train_fwd': (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, c_int, P, c_size_t, P]),
+    'mvae_bn_train_fwd': (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, P, c_int, P, c_size_t, P]),
     'mvae_bn_train_bwd': (c_int, [P] * 9 + [c_int] * 5 + [P, c_size_t, P]),
     'mvae_bn_eval_fwd': (c_int, [P] * 6 + [c_int] * 3 + [c_float, c_int, P]),
     'mvae_swish_fwd': (c_int, [P, P, c_size_t, P]),
@@ -58,19 +58,22 @@ _SIGNATURES = {
                              ctypes.POINTER(ExpertGrads), c_int, c_int, c_int, c_int, P]),
     'mvae_kl_rows_fwd': (c_int, [P, P, P, c_int, c_int, P]),
     'mvae_kl_rows_bwd': (c_int, [P, P, P, P, P, c_int, c_int, P]),
-    'mvae_bce_rowsum_fwd': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    'mvae_bce_rowsum_bwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_bce_rowsum_fwd': (c_int, [P, P, P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_bce_rowsum_bwd': (c_int, [P, P, P, P, P] + [c_int] * 7 + [P]),
     'mvae_ce_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_ce_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'mvae_randn': (c_int, [P, c_size_t, c_uint64, P, P]),
     'mvae_bernoulli': (c_int, [P, c_size_t, c_float, c_uint64, P, P]),
-    'mvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P, P]),
+    'mvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P, P]),
     'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
     'mvae_reparam_fwd': (c_int, [P, P, P, P, c_size_t, P]),
     'mvae_reparam_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
     'mvae_dropout_fanout_fwd': (c_int, [P, P, P, c_float, c_int, c_int, c_int, P]),
     'mvae_dropout_fanin_bwd': (c_int, [P, P, P, c_float, c_int, c_int, c_int, P]),
+    'mvae_block_gather': (c_int, [P, P, P, c_int, c_size_t, P]),
+    'mvae_block_scatter_add': (c_int, [P, P, P, c_int, c_int, c_size_t, P]),
+    'mvae_scatter_sums': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'mvae_bce_elem_fwd': (c_int, [P, P, P, c_size_t, P]),
     'mvae_bce_elem_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
 }

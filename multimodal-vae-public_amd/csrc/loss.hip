@@ -27,6 +27,7 @@ struct BceArgs {
     const float *logits, *target, *colw, *drow;
     float *rowsum, *dlogits;
     int R, P, rows_per_group, target_rows;
+    int target_div, t_rs, t_cs;   // target row = (r / target_div) % target_rows; element (row, p) at row*t_rs + p*t_cs
 };
 
 // One block per row (wide rows: pixels).  Optionally writes the gradient in the same pass.
@@ -35,12 +36,12 @@ __global__ __launch_bounds__(256) void bce_row_block_kernel(BceArgs a) {
     const int r = blockIdx.x;
     const int g = r / a.rows_per_group;
     const float *x = a.logits + (size_t)r * a.P;
-    const float *t = a.target + (size_t)(r % a.target_rows) * a.P;
+    const float *t = a.target + (size_t)((r / a.target_div) % a.target_rows) * a.t_rs;
     const float *w = a.colw ? a.colw + (size_t)g * a.P : nullptr;
     float *dx = a.dlogits ? a.dlogits + (size_t)r * a.P : nullptr;
     const float dr = (dx && a.drow) ? a.drow[g] : 0.f;
     float s = 0.f;
-    const bool vec = (a.P % 4 == 0) && aligned16_dev(x) && aligned16_dev(t) && (!w || aligned16_dev(w)) &&
+    const bool vec = (a.P % 4 == 0) && a.t_cs == 1 && aligned16_dev(x) && aligned16_dev(t) && (!w || aligned16_dev(w)) &&
                      (!dx || aligned16_dev(dx));
     if (vec) {
         const int p4 = a.P / 4;
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void bce_row_block_kernel(BceArgs a) {
     } else {
         for (int i = threadIdx.x; i < a.P; i += 256) {
             const float wi = w ? w[i] : 1.f;
-            s += wi * bce_elem(x[i], t[i]);
-            if (dx) dx[i] = dr * wi * bce_grad(x[i], t[i]);
+            const float ti = t[(size_t)i * a.t_cs];
+            s += wi * bce_elem(x[i], ti);
+            if (dx) dx[i] = dr * wi * bce_grad(x[i], ti);
         }
     }
     s = block_sum(s, red);
@@ -78,15 +80,16 @@ __global__ __launch_bounds__(256) void bce_row_wave_kernel(BceArgs a) {
     if (r >= a.R) return;
     const int g = r / a.rows_per_group;
     const float *x = a.logits + (size_t)r * a.P;
-    const float *t = a.target + (size_t)(r % a.target_rows) * a.P;
+    const float *t = a.target + (size_t)((r / a.target_div) % a.target_rows) * a.t_rs;
     const float *w = a.colw ? a.colw + (size_t)g * a.P : nullptr;
     float *dx = a.dlogits ? a.dlogits + (size_t)r * a.P : nullptr;
     const float dr = (dx && a.drow) ? a.drow[g] : 0.f;
     float s = 0.f;
     for (int i = lane; i < a.P; i += 64) {
         const float wi = w ? w[i] : 1.f;
-        s += wi * bce_elem(x[i], t[i]);
-        if (dx) dx[i] = dr * wi * bce_grad(x[i], t[i]);
+        const float ti = t[(size_t)i * a.t_cs];
+        s += wi * bce_elem(x[i], ti);
+        if (dx) dx[i] = dr * wi * bce_grad(x[i], ti);
     }
     s = wave_sum(s);
     if (lane == 0 && a.rowsum) a.rowsum[r] = s;
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(1024) void group_sums_kernel(const float *rows, con
 }
 
 int bce_launch(BceArgs a, hipStream_t st) {
-    if (!a.logits || !a.target || a.R <= 0 || a.P <= 0 || a.rows_per_group <= 0 || a.target_rows <= 0)
+    if (!a.logits || !a.target || a.R <= 0 || a.P <= 0 || a.rows_per_group <= 0 || a.target_rows <= 0 ||
+        a.target_div <= 0 || a.t_cs <= 0 || a.t_rs <= 0)
         return MVAE_ERR_ARG;
     if (!a.rowsum && !a.dlogits) return MVAE_ERR_ARG;
     if (a.dlogits && !a.drow) return MVAE_ERR_ARG;
@@ -146,16 +150,20 @@ int bce_launch(BceArgs a, hipStream_t st) {
 
 MVAE_EXPORT int mvae_bce_rowsum_fwd(const float *logits, const float *target, const float *colw, float *rowsum,
                                     const float *drow_dev, float *dlogits, int R, int P, int rows_per_group,
-                                    int target_rows, mvae_stream_t stream) {
-    BceArgs a{logits, target, colw, drow_dev, rowsum, dlogits, R, P, rows_per_group, target_rows};
+                                    int target_rows, int target_div, int target_row_stride,
+                                    int target_col_stride, mvae_stream_t stream) {
+    BceArgs a{logits, target, colw, drow_dev, rowsum, dlogits, R, P, rows_per_group, target_rows,
+              target_div, target_row_stride, target_col_stride};
     if (!rowsum) return MVAE_ERR_ARG;
     return bce_launch(a, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_bce_rowsum_bwd(const float *logits, const float *target, const float *colw,
                                     const float *drow_dev, float *dlogits, int R, int P, int rows_per_group,
-                                    int target_rows, mvae_stream_t stream) {
-    BceArgs a{logits, target, colw, drow_dev, nullptr, dlogits, R, P, rows_per_group, target_rows};
+                                    int target_rows, int target_div, int target_row_stride,
+                                    int target_col_stride, mvae_stream_t stream) {
+    BceArgs a{logits, target, colw, drow_dev, nullptr, dlogits, R, P, rows_per_group, target_rows,
+              target_div, target_row_stride, target_col_stride};
     if (!dlogits) return MVAE_ERR_ARG;
     return bce_launch(a, (hipStream_t)stream);
 }

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void swish_bwd_kernel(const float *dy, const f
 }
 
 __device__ __forceinline__ int read_index(const void *idx, int is_float, int r) {
-    return is_float ? (int)((const float *)idx)[r] : (int)((const int64_t *)idx)[r];
+    // is_float = 0: contiguous int64 labels; s > 0: fp32 {0,1} values with element stride s
+    // (celeba19 feeds column i of attrs[B,18]: s = 18)
+    return is_float ? (int)((const float *)idx)[(size_t)r * is_float] : (int)((const int64_t *)idx)[r];
 }
 
 // act[r,:] = swish(w[idx[r],:])   (nn.Embedding + Swish, mnist/model.py:116,123)
@@ -109,11 +111,15 @@ __global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
 // step t = *step_dev + 1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
-                                                   float lr, float b1, float b2, float eps, float gscale,
+                                                   double lr, double b1d, double b2d, double epsd, float gscale,
                                                    const int64_t *step_dev) {
+    // hyper-parameters arrive as doubles and are rounded the way torch rounds python floats into
+    // fp32 tensor ops: beta and (1 - beta) separately (1 - 0.999 != 1 - float(0.999))
+    const float b1 = (float)b1d, b2 = (float)b2d, eps = (float)epsd;
+    const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     const double t = (double)(*step_dev + 1);
-    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
-    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    const float step_size = (float)(lr / (1.0 - pow(b1d, t)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(b2d, t)));
     const size_t n4 = n / 4;
     const bool vec = aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v);
     if (vec) {
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
 #define MVAE_ADAM1(c)                                                       \
     {                                                                       \
         const float gg = gv.c * gscale;                                     \
-        mv.c = b1 * mv.c + (1.f - b1) * gg;                                 \
-        vv.c = b2 * vv.c + (1.f - b2) * gg * gg;                            \
+        mv.c = b1 * mv.c + omb1 * gg;                                 \
+        vv.c = b2 * vv.c + omb2 * gg * gg;                            \
         pv.c -= step_size * (mv.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));    \
     }
             MVAE_ADAM1(x) MVAE_ADAM1(y) MVAE_ADAM1(z) MVAE_ADAM1(w)
@@ -139,8 +145,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     const size_t tail0 = vec ? n4 * 4 : 0;
     for (size_t i = tail0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gg = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gg;
-        const float vi = b2 * v[i] + (1.f - b2) * gg * gg;
+        const float mi = b1 * m[i] + omb1 * gg;
+        const float vi = b2 * v[i] + omb2 * gg * gg;
         m[i] = mi; v[i] = vi;
         p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     }
@@ -207,7 +213,7 @@ MVAE_EXPORT int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t s
 }
 
 MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
-                               float lr, float beta1, float beta2, float eps, float grad_scale,
+                               double lr, double beta1, double beta2, double eps, float grad_scale,
                                int64_t *step_dev, mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;

@@ -81,8 +81,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x
                                                                   float *save_mean, float *save_invstd,
                                                                   float *running_mean, float *running_var,
                                                                   BnShape sh, float eps, float momentum,
-                                                                  int n_updates, int swish) {
+                                                                  int n_updates, const int *n_updates_dev,
+                                                                  int swish) {
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
+    if (n_updates_dev) n_updates = *n_updates_dev;   // device-side count: graph replays may vary it
     float mean, var;
     bn_merge(ws, sh, g, c, &mean, &var);
     const float invstd = rsqrtf(var + eps);
@@ -205,7 +207,8 @@ MVAE_EXPORT size_t mvae_bn_ws_bytes(int G, int C, int n_per_group) {
 MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y,
                                   float *save_mean, float *save_invstd, float *running_mean,
                                   float *running_var, int G, int B, int C, int HW, float eps, float momentum,
-                                  int n_updates, int flags, void *ws, size_t ws_bytes, mvae_stream_t stream) {
+                                  int n_updates, const int *n_updates_dev, int flags, void *ws,
+                                  size_t ws_bytes, mvae_stream_t stream) {
     BnShape sh;
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, &sh)) return MVAE_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
@@ -215,7 +218,7 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
     hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(BN_THREADS), 0, st, x, (float *)ws, sh);
     hipLaunchKernelGGL(bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
                        save_mean, save_invstd, running_mean, running_var, sh, eps, momentum, n_updates,
-                       (flags & MVAE_ACT_SWISH) ? 1 : 0);
+                       n_updates_dev, (flags & MVAE_ACT_SWISH) ? 1 : 0);
     return mvae_launch_status();
 }
 

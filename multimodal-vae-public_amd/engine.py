@@ -1,16 +1,17 @@
 """Fused MVAE train step: the body of the reference's ``train(epoch)`` closure
-(mnist/train.py:197-218, celeba/train.py:190-212) as ONE batched pass instead of three
-``model()`` calls.
+(mnist/train.py:197-218, celeba/train.py:190-212, celeba19/train.py:257-308) as ONE batched
+pass instead of three (celeba19: 20 + M) ``model()`` calls.
 
-What the reference does per step: 2x image encoder, 2x label encoder,
-3x image decoder, 3x label decoder, 3x PoE + reparameterise, 3 ELBOs, one backward.  Here:
+What the reference does per bimodal step: 2x image encoder, 2x label
+encoder, 3x image decoder, 3x label decoder, 3x PoE + reparameterise, 3 ELBOs, one backward.
+Here:
 
   * each encoder runs ONCE -- its output is identical in every call that includes the modality
     (BatchNorm sees the same batch, so the same statistics; the running statistics are advanced
-    twice, as in the reference).  CelebA's image encoder differs between its two calls only in
-    the Dropout(0.1) draw: the conv trunk + Linear(6400,512) + Swish run once, the two masks
-    are applied by a fan-out kernel and the final Linear runs on 2B rows;
-  * the three PoE / reparameterise / KL evaluations are one launch over T = 3 terms;
+    once per reference call).  CelebA's image encoder differs between its calls only in the
+    Dropout(0.1) draw: the conv trunk + Linear(6400,512) + Swish run once, the masks are applied
+    by a fan-out kernel and the final Linear runs on all the draws' rows;
+  * all PoE / reparameterise / KL evaluations are one launch over the T terms;
   * each decoder runs once on the rows of all the terms that need it, BatchNorm statistics
     per term (``groups``), running statistics advanced in the reference's call order; decoder
     outputs the reference computes but never uses (mnist/train.py:208,211) are only evaluated
@@ -19,10 +20,12 @@ What the reference does per step: 2x image encoder, 2x l
     (d ELBO / d row is the constant lambda / B);
   * the backward is explicit (``layers.backward_tape``), weight gradients land in the
     gradient arena, and the whole step is a fixed launch sequence that ``capture()`` records
-    into a hipGraph (``torch.cuda.CUDAGraph``) together with the optimizer.
+    into hipGraphs (``torch.cuda.CUDAGraph``) together with the optimizer.  Everything that
+    changes from step to step (annealing factor, celeba19's sampled subsets) lives in small
+    device tables refreshed from pinned host memory, so the graph never needs re-capture.
 
 Results (per-term ELBOs, total, every gradient, BatchNorm running statistics) equal the
-reference's three-call step on the same noise; ``tests/test_engine_gpu.py`` checks that against
+reference's multi-call step on the same noise; ``tests/test_engine_gpu.py`` checks that against
 the oracle and the golden fixtures.
 """
 import torch
@@ -60,17 +63,121 @@ def _restore(model, optimizer, counter, snap):
             optimizer._host_step = opt[3]
 
 
-class BimodalStep(object):
-    """Fused step for ``mnist`` / ``fashionmnist`` / ``celeba`` MVAEs."""
+def _pinned(*shape):
+    t = torch.zeros(*shape, dtype=torch.float32)
+    return t.pin_memory() if torch.cuda.is_available() else t
 
-    def __init__(self, model, batch_size, lambda_image=1.0, lambda_label=1.0, seed=0):
+
+class _StepBase(object):
+    """Launch plumbing shared by the fused steps: phase A (forward + decoder backward) and
+    phase B (PoE + encoder backward) with a gradient-bucket hook after each, eager ``step``,
+    and hipGraph capture -- one graph on a single GPU; with a communicator three graphs
+    (A | B | optimizer) so the RCCL all-reduce of the decoder bucket, launched between A and B
+    outside any capture, overlaps with phase B."""
+
+    def _init_common(self, model, batch_size, seed):
         model.finalize()
         self.model = model
         self.B = int(batch_size)
         self.D = model.n_latents
+        self.dev = next(model.parameters()).device
+        self.seed = int(seed) or 1
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.on_bucket_ready = None     # parallel.py hooks gradient all-reduce launches here
+        self._graphs = None
+        self._comm = None
+
+    # subclasses: _phase_a(image, label), _phase_b(), set_coefficients(beta), draw_noise()
+    def forward_backward(self, image, label):
+        """Launch the whole forward + backward.  Gradients go to ``p.grad`` (the arena); returns
+        the device tensor ``elbo[T+1]`` = per-term ELBOs (engine order) and their sum."""
+        self._phase_a(image, label)
+        if self.on_bucket_ready is not None:
+            self.on_bucket_ready(0)      # decoder gradients are final
+        self._phase_b()
+        if self.on_bucket_ready is not None:
+            self.on_bucket_ready(1)      # encoder gradients are final
+        return self.elbo
+
+    def step(self, image, label, annealing_factor, noise=None):
+        """One eager step (no optimizer): zero_grad -> forward/backward.  Returns elbo[T+1]."""
+        self.model.zero_grad(set_to_none=True)
+        self.set_coefficients(annealing_factor)
+        if noise is not None:
+            self.set_noise(noise)
+        else:
+            self.draw_noise()
+        return self.forward_backward(image, label)
+
+    # ------------------------------------------------------------------ hipGraph capture
+    def capture(self, optimizer, image_shape, label_example, warmup=3, comm=None):
+        """Record zero_grad + forward/backward + optimizer.step() into hipGraph(s).  After this,
+        ``replay(image, label, beta)`` copies the batch into static buffers, refreshes the
+        device tables and launches the graph(s): no per-kernel host work.  ``comm`` is a
+        ``parallel.DataParallel`` (or anything with launch(k) / wait())."""
+        dev = self.dev
+        self.static_image = torch.zeros((self.B,) + tuple(image_shape), dtype=torch.float32, device=dev)
+        self.static_label = torch.zeros_like(label_example, device=dev)
+        self.set_coefficients(1.0)
+        self._comm = comm
+        hook, self.on_bucket_ready = self.on_bucket_ready, None
+        snap = _snapshot(self.model, optimizer, self.counter)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body_a(); self._phase_b(); optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if comm is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body_a(); self._phase_b(); optimizer.step()
+            self._graphs = (g,)
+        else:
+            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(ga, pool=pool):
+                self._body_a()
+            with torch.cuda.graph(gb, pool=pool):
+                self._phase_b()
+            with torch.cuda.graph(gc, pool=pool):
+                optimizer.step()
+            self._graphs = (ga, gb, gc)
+        _restore(self.model, optimizer, self.counter, snap)   # warm-up steps must leave no trace
+        torch.cuda.synchronize(dev)
+        self.on_bucket_ready = hook
+        return self._graphs
+
+    def _body_a(self):
+        self.model.zero_grad(set_to_none=True)
+        self.draw_noise()
+        self._phase_a(self.static_image, self.static_label)
+
+    def replay(self, image, label, annealing_factor):
+        self.static_image.copy_(image, non_blocking=True)
+        self.static_label.copy_(label, non_blocking=True)
+        self.set_coefficients(annealing_factor)
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
+        else:
+            ga, gb, gc = self._graphs
+            ga.replay()
+            self._comm.launch(0)      # decoder bucket: RCCL runs behind phase B
+            gb.replay()
+            self._comm.launch(1)
+            self._comm.wait()
+            gc.replay()
+        return self.elbo
+
+
+class BimodalStep(_StepBase):
+    """Fused step for ``mnist`` / ``fashionmnist`` / ``celeba`` MVAEs."""
+
+    def __init__(self, model, batch_size, lambda_image=1.0, lambda_label=1.0, seed=0):
+        self._init_common(model, batch_size, seed)
         self.lambda_image = float(lambda_image)
         self.lambda_label = float(lambda_label)
-        self.dev = next(model.parameters()).device
         self.has_dropout = L.n_dropout(model.image_encoder.plan()) > 0
         self.has_bn = bool(model.HAS_BN)
         B, dev = self.B, self.dev
@@ -97,16 +204,11 @@ class BimodalStep(object):
         self.masks_dev = torch.tensor(self.term_masks, dtype=torch.int32, device=dev)
         # per-term loss coefficients lambda/B, beta/B: pinned host mirror -> device, so a captured
         # graph sees new annealing factors without re-capture
-        self.coef_host = torch.zeros(3, self.T, dtype=torch.float32).pin_memory() \
-            if torch.cuda.is_available() else torch.zeros(3, self.T)
+        self.coef_host = _pinned(3, self.T)
         self.coef = torch.zeros(3, self.T, dtype=torch.float32, device=dev)
         self.noise = torch.empty(self.T, B, self.D, dtype=torch.float32, device=dev)
         self.drop_masks = torch.empty(2, B, 512, dtype=torch.float32, device=dev) if self.has_dropout else None
         self.elbo = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
-        self.seed = int(seed) or 1
-        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.on_bucket_ready = None     # parallel.py hooks gradient all-reduce launches here
-        self._graph = None
 
     # ------------------------------------------------------------------ host-side setup per step
     def set_coefficients(self, annealing_factor):
@@ -131,27 +233,31 @@ class BimodalStep(object):
         if self.has_dropout:
             K.bernoulli_(self.drop_masks, KEEP, self.seed ^ 0x9E3779B97F4A7C15, self.counter)
 
+    def terms_in_reference_order(self, elbo):
+        """elbo[T+1] (engine order) -> [joint, image, label] + [total]."""
+        idx = [self.ref_order.index(r) for r in range(self.T)] + [self.T]
+        return elbo[idx]
+
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, image, label):
-        """Launch the whole forward + backward.  Gradients go to ``p.grad`` (the arena); returns
-        the device tensor ``elbo[T+1]`` = per-term ELBOs (engine order) and their sum."""
+    def _phase_a(self, image, label):
         m, B, D, T = self.model, self.B, self.D, self.T
         if image.shape[0] != B:
             raise ValueError('engine was built for batch %d, got %d' % (B, image.shape[0]))
+        c = self._carry = {}
         image = image.contiguous()
         n_up = 2  # each encoder is called twice per step in the reference
         # ---- encoders
         if self.has_dropout:
-            h, tape_trunk = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
+            h, c['tape_trunk'] = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
             hd = torch.empty(2 * B, h.shape[1], dtype=torch.float32, device=self.dev)
             K.dropout_fanout_fwd(h, self.drop_masks, hd, 1.0 / KEEP)
-            heads_img, tape_head = L.forward_tape(self.head, hd)
+            heads_img, c['tape_head'] = L.forward_tape(self.head, hd)
             img_experts = [heads_img[:B], heads_img[B:]]
         else:
-            heads_img, tape_img = L.forward_tape(m.image_encoder.plan(), image, bn_updates=n_up)
+            heads_img, c['tape_img'] = L.forward_tape(m.image_encoder.plan(), image, bn_updates=n_up)
             img_experts = [heads_img]
         lbl_in = label if m.LABEL_KIND == 'class' else label.float().contiguous()
-        heads_lbl, tape_lbl = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
+        heads_lbl, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
         experts = img_experts + [heads_lbl]
         mus = [e[:, :D] for e in experts]
         lvs = [e[:, D:] for e in experts]
@@ -196,84 +302,278 @@ class BimodalStep(object):
         # ---- backward: decoders -> dz
         dz = torch.empty(T, B, D, dtype=torch.float32, device=self.dev)
         K.fill_(dz, 0.0)
-        g = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
-                            need_input_grad=True, groups=ni,
-                            input_grad_out=dz[i0:i0 + ni].reshape(ni * B, D), input_grad_accumulate=True)
-        g = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, need_input_grad=True, groups=nl,
-                            input_grad_out=dz[l0:l0 + nl].reshape(nl * B, D), input_grad_accumulate=True)
-        del g
-        if self.on_bucket_ready is not None:
-            self.on_bucket_ready(0)      # decoder gradients are final
+        L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
+                        need_input_grad=True, groups=ni,
+                        input_grad_out=dz[i0:i0 + ni].reshape(ni * B, D), input_grad_accumulate=True)
+        L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, need_input_grad=True, groups=nl,
+                        input_grad_out=dz[l0:l0 + nl].reshape(nl * B, D), input_grad_accumulate=True)
+        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_lbl=heads_lbl)
+
+    def _phase_b(self):
+        m, B, D = self.model, self.B, self.D
+        c = self._carry
+        heads_img, heads_lbl = c['heads_img'], c['heads_lbl']
         # ---- PoE backward -> encoder heads
-        if self.has_dropout:
-            g_heads_img = torch.empty_like(heads_img)
-            g_list = [g_heads_img[:B], g_heads_img[B:], torch.empty_like(heads_lbl)]
-        else:
-            g_list = [torch.empty_like(heads_img), torch.empty_like(heads_lbl)]
-        K.poe_bwd(mus, lvs, self.masks_dev, self.noise, mu, lv, dz, None, None, self.coef[2],
-                  [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
+        g_heads_img = torch.empty_like(heads_img)
+        g_heads_lbl = torch.empty_like(heads_lbl)
+        g_list = ([g_heads_img[:B], g_heads_img[B:]] if self.has_dropout else [g_heads_img]) + [g_heads_lbl]
+        K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
+                  self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
                   dkl_per_term=True)
         # ---- encoders backward
-        L.backward_tape(m.label_encoder.plan(), tape_lbl, g_list[-1])
+        L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl)
         if self.has_dropout:
-            d_hd = L.backward_tape(self.head, tape_head, g_heads_img, need_input_grad=True)
+            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True)
             d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
             K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
-            L.backward_tape(self.trunk, tape_trunk, d_h)
+            L.backward_tape(self.trunk, c['tape_trunk'], d_h)
         else:
-            L.backward_tape(m.image_encoder.plan(), tape_img, g_list[0])
-        if self.on_bucket_ready is not None:
-            self.on_bucket_ready(1)      # encoder gradients are final
-        return elbo
+            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img)
 
-    def step(self, image, label, annealing_factor, noise=None):
-        """One eager step (no optimizer): zero_grad -> forward/backward.  Returns elbo[T+1]."""
-        self.model.zero_grad(set_to_none=True)
-        self.set_coefficients(annealing_factor)
-        if noise is not None:
-            self.set_noise(noise)
-        else:
-            self.draw_noise()
-        return self.forward_backward(image, label)
+
+# =====================================================================================
+# CelebA-19
+# =====================================================================================
+N_ATTRS = 18
+
+
+def sample_subsets(rng, n_modalities=19, size=1):
+    """``size`` random modality subsets like celeba19/train.py:111-142: a subset SIZE is drawn
+    uniformly from {2 .. n-1}, then a uniform subset of that size (distinct within a size).
+    The reference materialises all 524,267 subsets (:87-108) to index into; drawing the
+    members directly is the same distribution without the 10 MB pool."""
+    import numpy as np
+    out, seen = [], set()
+    while len(out) < size:
+        k = int(rng.randint(2, n_modalities))
+        members = tuple(sorted(rng.choice(n_modalities, k, replace=False).tolist()))
+        if members in seen:
+            continue
+        seen.add(members)
+        row = np.zeros(n_modalities, dtype=bool)
+        row[list(members)] = True
+        out.append(row)
+    out.sort(key=lambda r: int(r.sum()))       # the reference returns them grouped by size
+    return np.stack(out)
+
+
+class Celeba19Step(_StepBase):
+    """Fused step for the 19-modality MVAE: complete + image-only + 18 single-attribute + M
+    sampled-subset ELBO terms (celeba19/train.py:257-308) as one batched pass.
+
+    Static launch structure, dynamic content: which attributes / whether the image enter a
+    sampled term only changes device tables (PoE masks, loss coefficients, the BatchNorm
+    update count), so the captured graph is valid for every step.
+
+    experts : image draw k (k = 0: complete term, 1: image-only term, 2+j: sampled term j --
+              they differ only in the Dropout mask), then the 18 attribute encoders (each runs
+              once; the reference re-runs encoder i in every call that contains attribute i).
+    decoders: the image decoder runs for every term in term order (its BatchNorm running
+              statistics advance 20+M times per step in the reference) but
+              keeps activations only for the terms whose image BCE enters an ELBO;
+              attribute decoder i runs once on the gathered rows of (complete, sampled..., single i).
+    """
+
+    def __init__(self, model, batch_size, lambda_image=1.0, lambda_attrs=1.0, approx_m=1, seed=0,
+                 combo_seed=681307, faithful_bn_stats=True):
+        import numpy as np
+        self._init_common(model, batch_size, seed)
+        self.lambda_image, self.lambda_attrs = float(lambda_image), float(lambda_attrs)
+        self.M = int(approx_m)
+        self.T = 2 + N_ATTRS + self.M
+        self.n_img = 2 + self.M
+        self.S = self.M + 2                       # decoder slots: complete, sampled..., single
+        if self.n_img + N_ATTRS > 32 or self.T > 40:
+            raise ValueError('approx_m too large for the PoE kernel limits (experts <= 32, terms <= 40)')
+        self.faithful = bool(faithful_bn_stats)
+        self.rng = np.random.RandomState(combo_seed)      # same seed on every rank: same subsets
+        B, D, dev, T, S = self.B, self.D, self.dev, self.T, self.S
+        enc = model.image_encoder
+        self.trunk = L.compile_plan(enc.trunk_modules())
+        self.head = L.compile_plan(enc.head_modules())
+        self.enc_plans = [e.plan() for e in model.attr_encoders]
+        self.dec_plans = [d.plan() for d in model.attr_decoders]
+        # device tables + pinned mirrors
+        self.masks_host = torch.zeros(T, dtype=torch.int32)
+        self.masks_dev = torch.zeros(T, dtype=torch.int32, device=dev)
+        self.coef_host = _pinned(3, T)            # rows: image, (unused), kl
+        self.coef = torch.zeros(3, T, dtype=torch.float32, device=dev)
+        self.coef_attr_host = _pinned(N_ATTRS * S)
+        self.coef_attr = torch.zeros(N_ATTRS * S, dtype=torch.float32, device=dev)
+        self.nimg_host = torch.zeros(1, dtype=torch.int32)
+        self.nimg_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        if torch.cuda.is_available():
+            self.masks_host = self.masks_host.pin_memory()
+            self.nimg_host = self.nimg_host.pin_memory()
+        term_of = torch.zeros(N_ATTRS, S, dtype=torch.int32)
+        for i in range(N_ATTRS):
+            term_of[i, 0] = 0
+            for j in range(self.M):
+                term_of[i, 1 + j] = 2 + N_ATTRS + j
+            term_of[i, S - 1] = 2 + i
+        self.term_of_slot = term_of.reshape(-1).to(dev)
+        self.noise = torch.empty(T, B, D, dtype=torch.float32, device=dev)
+        self.drop_masks = torch.ones(self.n_img, B, 512, dtype=torch.float32, device=dev)
+        self.elbo = torch.zeros(T + 1, dtype=torch.float32, device=dev)
+        self.combos = None
+        self.set_terms(sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+
+    # ------------------------------------------------------------------ host-side tables
+    def set_terms(self, combos):
+        """``combos``: bool [M, 19] (column 0 = image) -- the step's sampled subsets."""
+        import numpy as np
+        combos = np.asarray(combos, dtype=bool).reshape(self.M, 1 + N_ATTRS)
+        self.combos = combos
+        n_img = self.n_img
+        m = self.masks_host
+        m[0] = 1 | (((1 << N_ATTRS) - 1) << n_img)            # complete: image draw 0 + all attributes
+        m[1] = 1 << 1                                         # image only: image draw 1
+        for i in range(N_ATTRS):
+            m[2 + i] = 1 << (n_img + i)
+        for j in range(self.M):
+            bits = (1 << (2 + j)) if combos[j, 0] else 0
+            for i in range(N_ATTRS):
+                if combos[j, 1 + i]:
+                    bits |= 1 << (n_img + i)
+            m[2 + N_ATTRS + j] = bits
+        self.masks_dev.copy_(m, non_blocking=True)
+        self.n_img_present = 2 + int(combos[:, 0].sum())
+        self.nimg_host[0] = self.n_img_present
+        self.nimg_dev.copy_(self.nimg_host, non_blocking=True)
+
+    def set_coefficients(self, annealing_factor):
+        B, T, S, M = float(self.B), self.T, self.S, self.M
+        c = self.coef_host
+        c.zero_()
+        c[0, 0] = self.lambda_image / B
+        c[0, 1] = self.lambda_image / B
+        for j in range(M):                         # sampled terms omit the lambdas -> 1.0 (:294-300)
+            c[0, 2 + N_ATTRS + j] = (1.0 / B) if self.combos[j, 0] else 0.0
+        c[2, :] = float(annealing_factor) / B
+        self.coef.copy_(c, non_blocking=True)
+        ca = self.coef_attr_host
+        for i in range(N_ATTRS):
+            ca[i * S + 0] = self.lambda_attrs / B              # complete term uses lambda_attrs (:265-267)
+            for j in range(M):
+                ca[i * S + 1 + j] = (1.0 / B) if self.combos[j, 1 + i] else 0.0
+            ca[i * S + S - 1] = 1.0 / B                        # single-attribute terms omit it (:281-282)
+        self.coef_attr.copy_(ca, non_blocking=True)
+
+    def set_noise(self, noise):
+        """``noise`` in the reference's term order (oracle.steps.draw_celeba19_noise)."""
+        for t in range(self.T):
+            self.noise[t].copy_(noise['eps'][t].to(self.dev, non_blocking=True))
+        img_terms = [0, 1] + [2 + N_ATTRS + j for j in range(self.M)]
+        for k, t in enumerate(img_terms):
+            mk = noise['mask'][t]
+            if mk is not None:
+                self.drop_masks[k].copy_(mk.to(self.dev))
+            else:
+                self.drop_masks[k].fill_(1.0)      # expert masked out of the PoE: value irrelevant
+
+    def draw_noise(self):
+        K.randn_(self.noise, self.seed, self.counter)
+        K.bernoulli_(self.drop_masks, KEEP, self.seed ^ 0x9E3779B97F4A7C15, self.counter)
+
+    def step(self, image, attrs, annealing_factor, noise=None, combos=None):
+        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+        return _StepBase.step(self, image, attrs, annealing_factor, noise=noise)
+
+    def replay(self, image, attrs, annealing_factor, combos=None):
+        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+        return _StepBase.replay(self, image, attrs, annealing_factor)
 
     def terms_in_reference_order(self, elbo):
-        """elbo[T+1] (engine order) -> [joint, image, label] + [total]."""
-        idx = [self.ref_order.index(r) for r in range(self.T)] + [self.T]
-        return elbo[idx]
+        return elbo
 
-    # ------------------------------------------------------------------ hipGraph capture
-    def capture(self, optimizer, image_shape, label_example, warmup=3):
-        """Record zero_grad + forward/backward + optimizer.step() into a hipGraph.  After this,
-        ``replay(image, label, beta)`` copies the batch into static buffers, refreshes the loss
-        coefficients and launches the graph: no per-kernel host work."""
+    # ------------------------------------------------------------------ the step
+    def _phase_a(self, image, attrs):
+        m, B, D, T, S, M, n_img = self.model, self.B, self.D, self.T, self.S, self.M, self.n_img
         dev = self.dev
-        self.static_image = torch.zeros((self.B,) + tuple(image_shape), dtype=torch.float32, device=dev)
-        self.static_label = torch.zeros_like(label_example, device=dev)
-        self.set_coefficients(1.0)
-        snap = _snapshot(self.model, optimizer, self.counter)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._captured_body(optimizer)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._captured_body(optimizer)
-        _restore(self.model, optimizer, self.counter, snap)   # warm-up steps must leave no trace
-        torch.cuda.synchronize(dev)
-        return self._graph
+        c = self._carry = {}
+        image = image.contiguous()
+        attrs = attrs.float().contiguous()
+        # ---- image encoder: trunk once, n_img Dropout draws, head on n_img*B rows
+        h, c['tape_trunk'] = L.forward_tape(self.trunk, image, bn_updates=self.n_img_present,
+                                            bn_updates_dev=self.nimg_dev)
+        hd = torch.empty(n_img * B, h.shape[1], dtype=torch.float32, device=dev)
+        K.dropout_fanout_fwd(h, self.drop_masks, hd, 1.0 / KEEP)
+        heads_img, c['tape_head'] = L.forward_tape(self.head, hd)
+        # ---- 18 attribute encoders, each once (no BatchNorm / Dropout: celeba19/model.py:173-178)
+        heads_attr, c['tape_enc'] = [], []
+        for i in range(N_ATTRS):
+            ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
+            heads_attr.append(ha); c['tape_enc'].append(tp)
+        experts = [heads_img[k * B:(k + 1) * B] for k in range(n_img)] + heads_attr
+        mus = [e[:, :D] for e in experts]
+        lvs = [e[:, D:] for e in experts]
+        mu = torch.empty(T, B, D, dtype=torch.float32, device=dev)
+        lv = torch.empty_like(mu); z = torch.empty_like(mu)
+        kl = torch.empty(T, B, dtype=torch.float32, device=dev)
+        K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, m.POE_VARIANT)
+        self.last_latents = (mu, lv, z)
+        # ---- image decoder in term order: [0,1] kept, [2..19] statistics only, sampled kept
+        dplan = m.image_decoder.plan()
+        t_s = 2 + N_ATTRS
+        logit_a, tape_a = L.forward_tape(dplan, z[0:2].reshape(2 * B, D), groups=2)
+        if self.faithful:
+            L.forward_tape(dplan, z[2:t_s].reshape(N_ATTRS * B, D), groups=N_ATTRS)
+        logit_c, tape_c = L.forward_tape(dplan, z[t_s:T].reshape(M * B, D), groups=M)
+        P = logit_a[0].numel()
+        img_flat = image.reshape(B, P)
+        rows_a = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        dlog_a = torch.empty(2 * B, P, dtype=torch.float32, device=dev)
+        K.bce_rowsum_fwd(logit_a.reshape(2 * B, P), img_flat, rows_a, drow=self.coef[0, 0:2], dlogits=dlog_a,
+                         rows_per_group=B, target_rows=B)
+        rows_c = torch.empty(M * B, dtype=torch.float32, device=dev)
+        dlog_c = torch.empty(M * B, P, dtype=torch.float32, device=dev)
+        K.bce_rowsum_fwd(logit_c.reshape(M * B, P), img_flat, rows_c, drow=self.coef[0, t_s:T], dlogits=dlog_c,
+                         rows_per_group=B, target_rows=B)
+        # ---- attribute decoders: gather the z rows each one needs, one pass per decoder
+        zcat = torch.empty(N_ATTRS, S * B, D, dtype=torch.float32, device=dev)
+        K.block_gather(z, self.term_of_slot, zcat, B * D)
+        logits_attr = torch.empty(N_ATTRS * S, B, dtype=torch.float32, device=dev)
+        tape_dec = []
+        for i in range(N_ATTRS):
+            _, tp = L.forward_tape(self.dec_plans[i], zcat[i], final_out=logits_attr[i * S:(i + 1) * S])
+            tape_dec.append(tp)
+        rows_attr = torch.empty(N_ATTRS * S, dtype=torch.float32, device=dev)
+        dlog_attr = torch.empty_like(logits_attr)
+        # logits row (i, s) holds B columns; its targets are column i of attrs[B, 18]
+        K.bce_rowsum_fwd(logits_attr, attrs, rows_attr, drow=self.coef_attr, dlogits=dlog_attr,
+                         rows_per_group=1, target_rows=N_ATTRS, target_div=S, target_strides=(1, N_ATTRS))
+        # ---- ELBO per term and total (celeba19/train.py:59,265-302)
+        elbo = self.elbo
+        K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
+        K.group_sums(rows_a, self.coef[0, 0:2], elbo[0:2], elbo[T:], 2, B, accumulate=True)
+        K.group_sums(rows_c, self.coef[0, t_s:T], elbo[t_s:T], elbo[T:], M, B, accumulate=True)
+        K.scatter_sums(rows_attr, self.coef_attr, self.term_of_slot, elbo[:T], elbo[T:], accumulate_total=True)
+        # ---- backward: decoders -> dz
+        dz = torch.empty(T, B, D, dtype=torch.float32, device=dev)
+        K.fill_(dz, 0.0)
+        L.backward_tape(dplan, tape_a, dlog_a.reshape(logit_a.shape), need_input_grad=True, groups=2,
+                        input_grad_out=dz[0:2].reshape(2 * B, D), input_grad_accumulate=True)
+        L.backward_tape(dplan, tape_c, dlog_c.reshape(logit_c.shape), need_input_grad=True, groups=M,
+                        input_grad_out=dz[t_s:T].reshape(M * B, D), input_grad_accumulate=True)
+        dzcat = torch.empty_like(zcat)
+        for i in range(N_ATTRS):
+            L.backward_tape(self.dec_plans[i], tape_dec[i], dlog_attr[i * S:(i + 1) * S].reshape(S * B, 1),
+                            need_input_grad=True, input_grad_out=dzcat[i], input_grad_accumulate=False)
+        K.block_scatter_add(dzcat, self.term_of_slot, dz, T, B * D)
+        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_attr=heads_attr)
 
-    def _captured_body(self, optimizer):
-        self.model.zero_grad(set_to_none=True)
-        self.draw_noise()
-        self.forward_backward(self.static_image, self.static_label)
-        optimizer.step()
-
-    def replay(self, image, label, annealing_factor):
-        self.static_image.copy_(image, non_blocking=True)
-        self.static_label.copy_(label, non_blocking=True)
-        self.set_coefficients(annealing_factor)
-        self._graph.replay()
-        return self.elbo
+    def _phase_b(self):
+        m, B, D, n_img = self.model, self.B, self.D, self.n_img
+        c = self._carry
+        g_img = torch.empty_like(c['heads_img'])
+        g_attr = [torch.empty_like(h) for h in c['heads_attr']]
+        g_list = [g_img[k * B:(k + 1) * B] for k in range(n_img)] + g_attr
+        K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
+                  self.coef[2], [g[:, :D] for g in g_list], [g[:, D:] for g in g_list], m.POE_VARIANT,
+                  dkl_per_term=True)
+        for i in range(N_ATTRS):
+            L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
+        d_hd = L.backward_tape(self.head, c['tape_head'], g_img, need_input_grad=True)
+        d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
+        K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
+        L.backward_tape(self.trunk, c['tape_trunk'], d_h)

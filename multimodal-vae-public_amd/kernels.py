@@ -142,8 +142,9 @@ def convT2d_wgrad(dy, x, dw, stride, pad, accumulate=False):
 
 # ---------------------------------------------------------------------------- BatchNorm
 def bn_train_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, G,
-                 eps=1e-5, momentum=0.1, n_updates=1, swish=True):
-    """x [G*B, C, *spatial]; save_* [G, C]."""
+                 eps=1e-5, momentum=0.1, n_updates=1, swish=True, n_updates_dev=None):
+    """x [G*B, C, *spatial]; save_* [G, C].  ``n_updates_dev``: device int32[1] overriding
+    ``n_updates`` (celeba19: how many terms of this step contain the image)."""
     _need_gpu(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var)
     _f32c(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var)
     GB, C = x.shape[0], x.shape[1]
@@ -153,7 +154,8 @@ def bn_train_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, runnin
     ws, wsb = _ws_args(nbytes, x.device)
     check(_lib.lib().mvae_bn_train_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean),
                                        _ptr(save_invstd), _ptr(running_mean), _ptr(running_var),
-                                       G, B, C, HW, eps, momentum, n_updates, ACT_SWISH if swish else 0,
+                                       G, B, C, HW, eps, momentum, n_updates, _ptr(n_updates_dev),
+                                       ACT_SWISH if swish else 0,
                                        ws, wsb, _stream()), 'mvae_bn_train_fwd')
 
 
@@ -194,17 +196,40 @@ def swish_bwd(dy, x, dx):
 
 
 def _index_kind(idx):
+    """0 = contiguous int64 labels; s > 0 = fp32 {0,1} values with element stride s (a column of
+    attrs[B,18] has s = 18)."""
+    if idx.dim() != 1:
+        raise RuntimeError('embedding index must be 1-D')
     if idx.dtype == torch.int64:
+        if idx.numel() > 1 and idx.stride(0) != 1:
+            raise RuntimeError('int64 embedding index must be contiguous')
         return 0
     if idx.dtype == torch.float32:
-        return 1
+        return max(int(idx.stride(0)), 1)
     raise RuntimeError('embedding index must be int64 or float32, got %s' % idx.dtype)
+
+
+def block_gather(src, idx_dev, dst, block_elems):
+    _need_gpu(src, idx_dev, dst); _f32c(src, dst)
+    check(_lib.lib().mvae_block_gather(_ptr(src), _ptr(idx_dev), _ptr(dst), idx_dev.numel(), block_elems,
+                                       _stream()), 'mvae_block_gather')
+
+
+def block_scatter_add(src, idx_dev, dst, n_dst, block_elems):
+    _need_gpu(src, idx_dev, dst); _f32c(src, dst)
+    check(_lib.lib().mvae_block_scatter_add(_ptr(src), _ptr(idx_dev), _ptr(dst), idx_dev.numel(), n_dst,
+                                            block_elems, _stream()), 'mvae_block_scatter_add')
+
+
+def scatter_sums(vals, coef, idx_dev, out, total, accumulate_total=True):
+    _need_gpu(vals, coef, idx_dev, out, total); _f32c(vals, coef, out, total)
+    check(_lib.lib().mvae_scatter_sums(_ptr(vals), _ptr(coef), _ptr(idx_dev), _ptr(out), _ptr(total),
+                                       vals.numel(), ACCUMULATE if accumulate_total else 0, _stream()),
+          'mvae_scatter_sums')
 
 
 def embedding_swish_fwd(idx, w, act):
     _need_gpu(idx, w, act); _f32c(w, act)
-    if not idx.is_contiguous():
-        raise RuntimeError('embedding index must be contiguous')
     check(_lib.lib().mvae_embedding_swish_fwd(_ptr(idx), _index_kind(idx), _ptr(w), _ptr(act), idx.numel(),
                                               w.shape[0], w.shape[1], _stream()),
           'mvae_embedding_swish_fwd')
@@ -283,21 +308,25 @@ def kl_rows_bwd(mu, logvar, dkl, dmu, dlogvar):
 
 # ---------------------------------------------------------------------------- losses
 def bce_rowsum_fwd(logits, target, rowsum, colw=None, drow=None, dlogits=None, rows_per_group=None,
-                   target_rows=None):
+                   target_rows=None, target_div=1, target_strides=None):
     """logits [R,P]; target [target_rows,P] broadcast over row groups; optional fused gradient."""
     _need_gpu(logits, target, rowsum, colw, drow, dlogits); _f32c(logits, target, rowsum, colw, drow, dlogits)
     R, P = logits.shape
+    t_rs, t_cs = target_strides if target_strides is not None else (P, 1)
     check(_lib.lib().mvae_bce_rowsum_fwd(_ptr(logits), _ptr(target), _ptr(colw), _ptr(rowsum), _ptr(drow),
                                          _ptr(dlogits), R, P, rows_per_group or R,
-                                         target_rows or target.shape[0], _stream()), 'mvae_bce_rowsum_fwd')
+                                         target_rows or target.shape[0], target_div, t_rs, t_cs, _stream()),
+          'mvae_bce_rowsum_fwd')
 
 
-def bce_rowsum_bwd(logits, target, drow, dlogits, colw=None, rows_per_group=None, target_rows=None):
+def bce_rowsum_bwd(logits, target, drow, dlogits, colw=None, rows_per_group=None, target_rows=None,
+                   target_div=1, target_strides=None):
     _need_gpu(logits, target, drow, dlogits, colw); _f32c(logits, target, drow, dlogits, colw)
     R, P = logits.shape
+    t_rs, t_cs = target_strides if target_strides is not None else (P, 1)
     check(_lib.lib().mvae_bce_rowsum_bwd(_ptr(logits), _ptr(target), _ptr(colw), _ptr(drow), _ptr(dlogits),
                                          R, P, rows_per_group or R, target_rows or target.shape[0],
-                                         _stream()), 'mvae_bce_rowsum_bwd')
+                                         target_div, t_rs, t_cs, _stream()), 'mvae_bce_rowsum_bwd')
 
 
 def ce_fwd(logits, label, row, drow=None, dlogits=None, rows_per_group=None, label_rows=None):

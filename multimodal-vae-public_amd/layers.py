@@ -226,11 +226,16 @@ def _lin_weights(op):
     return w, bias
 
 
-def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True):
-    """Run the plan.  Returns (output, tape); tape is None when not training."""
+def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, final_out=None,
+                 bn_updates_dev=None):
+    """Run the plan.  Returns (output, tape); tape is None when not training.
+    ``final_out``: preallocated [rows, N] destination for a stack that ends in a plain Linear
+    (celeba19 collects its 18 attribute decoders' logits in one buffer).  ``bn_updates_dev``:
+    device int32[1] overriding ``bn_updates`` (number of running-statistics updates)."""
     masks = list(masks) if masks is not None else []
     tape = [] if training else None
     h = x
+    last_op = plan[-1]
     for op in plan:
         saved = None
         if op.kind in ('lin', 'lin2'):
@@ -251,7 +256,10 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True):
                 saved = (h, pre, mask)
                 h = act
             else:
-                pre = torch.empty(M, N, dtype=torch.float32, device=h.device)
+                if final_out is not None and op is last_op:
+                    pre = final_out.reshape(M, N)
+                else:
+                    pre = torch.empty(M, N, dtype=torch.float32, device=h.device)
                 K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, None)
                 saved = (h, None, None)
                 h = pre
@@ -282,7 +290,7 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True):
                 si = torch.empty(groups, C, dtype=torch.float32, device=h.device)
                 K.bn_train_fwd(h, m.weight.detach(), m.bias.detach(), y, sm, si, m.running_mean,
                                m.running_var, groups, eps=m.eps, momentum=m.momentum,
-                               n_updates=bn_updates, swish=op.act)
+                               n_updates=bn_updates, swish=op.act, n_updates_dev=bn_updates_dev)
                 m._nbt_pending += groups * bn_updates
                 saved = (h, sm, si)
             else:
@@ -291,7 +299,7 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True):
             h = y
         elif op.kind == 'emb':
             m = op.mod
-            idx = h.contiguous()
+            idx = h if (h.dim() == 1 and h.dtype == torch.float32) else h.contiguous()   # fp32 may be strided
             act = torch.empty(idx.numel(), m.embedding_dim, dtype=torch.float32, device=idx.device)
             K.embedding_swish_fwd(idx, m.weight.detach(), act)
             saved = (idx,)

@@ -70,6 +70,10 @@ class DataParallel(object):
         engine.on_bucket_ready = self.buckets.launch
         self.engine = engine
 
+    def launch(self, k):
+        """Start the all-reduce of bucket k (called by the engine between captured graphs)."""
+        self.buckets.launch(k)
+
     def wait(self):
         self.buckets.wait()
 

@@ -1,0 +1,134 @@
+"""Per-launch timing with HIP events on the stream the kernels are launched on.
+
+``with KernelProfile() as prof:`` wraps every launcher of ``kernels.py`` in a pair of
+``torch.cuda.Event`` records on ``torch.cuda.current_stream()`` -- the same stream the C ABI
+receives -- and tags it with the ALGORITHMIC work of the call (2*M*N*K flops for the GEMM-shaped
+ops, bytes of the tensor arguments for the HBM-bound ones).  ``bench.py`` uses it for the
+``roofline`` object (live, in the same process as the timed run); the rocprofv3 kernel trace
+committed under ``profiles/`` is the cross-check.
+"""
+import torch
+
+from . import kernels as K
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def _numel_bytes(args, kwargs):
+    n = 0
+    for a in list(args) + list(kwargs.values()):
+        if torch.is_tensor(a):
+            n += a.numel() * a.element_size()
+        elif isinstance(a, (list, tuple)):
+            n += sum(t.numel() * t.element_size() for t in a if torch.is_tensor(t))
+    return n
+
+
+def _lin_cost(which):
+    def cost(*a, **kw):
+        if which == 'fwd':
+            (M, Kd), N = a[0].shape, a[1].shape[0]
+        elif which == 'dgrad':
+            (M, N), Kd = a[0].shape, a[1].shape[1]
+        else:
+            (M, N), Kd = a[0].shape, a[1].shape[1]
+        return 2.0 * M * N * Kd, 'M%d N%d K%d' % (M, N, Kd)
+    return cost
+
+
+def _conv_cost(kind):
+    def cost(*a, **kw):
+        # algorithmic flops = 2 * (elements of the conv-OUTPUT-shaped tensor) * Cin_conv * 16, where
+        # "conv" is the plain convolution the op is a forward / dgrad / wgrad of
+        if kind == 'conv2d_fwd':          # (x, w[Cout,Cin,4,4], pre, act)
+            out = a[2] if a[2] is not None else a[3]
+            fl = 2.0 * out.numel() * a[1].shape[1] * 16
+            shape = tuple(out.shape)
+        elif kind == 'convT2d_dgrad':     # (dy, w[CinT,CoutT,4,4], dx): a conv forward on dy producing dx
+            fl = 2.0 * a[2].numel() * a[1].shape[1] * 16
+            shape = tuple(a[2].shape)
+        elif kind == 'conv2d_dgrad':
+            dy, w = a[0], a[1]
+            fl = 2.0 * dy.numel() * w.shape[1] * 16
+            shape = tuple(a[2].shape)
+        elif kind == 'convT2d_fwd':
+            x, w = a[0], a[1]
+            fl = 2.0 * x.numel() * w.shape[1] * 16
+            shape = tuple((a[2] if a[2] is not None else a[3]).shape)
+        elif kind == 'conv2d_wgrad':
+            dy, x, dw = a[0], a[1], a[2]
+            fl = 2.0 * dy.numel() * dw.shape[1] * 16
+            shape = tuple(dw.shape)
+        else:  # convT2d_wgrad: dy = grad of the transpose's output, x its input
+            dy, x, dw = a[0], a[1], a[2]
+            fl = 2.0 * x.numel() * dw.shape[1] * 16
+            shape = tuple(dw.shape)
+        return fl, 'x'.join(str(s) for s in shape)
+    return cost
+
+
+GEMM_COSTS = {
+    'linear_fwd': _lin_cost('fwd'), 'linear_dgrad': _lin_cost('dgrad'), 'linear_wgrad': _lin_cost('wgrad'),
+    'conv2d_fwd': _conv_cost('conv2d_fwd'), 'conv2d_dgrad': _conv_cost('conv2d_dgrad'),
+    'conv2d_wgrad': _conv_cost('conv2d_wgrad'), 'convT2d_fwd': _conv_cost('convT2d_fwd'),
+    'convT2d_dgrad': _conv_cost('convT2d_dgrad'), 'convT2d_wgrad': _conv_cost('convT2d_wgrad'),
+}
+HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bwd', 'embedding_swish_fwd',
+           'embedding_swish_bwd', 'poe_fwd', 'poe_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'bce_rowsum_fwd',
+           'bce_rowsum_bwd', 'ce_fwd', 'ce_bwd', 'group_sums', 'randn_', 'bernoulli_', 'adam_step', 'fill_',
+           'dropout_fanout_fwd', 'dropout_fanin_bwd', 'bce_elem_fwd', 'bce_elem_bwd']
+
+
+class KernelProfile(object):
+    def __init__(self):
+        self.records = []
+        self._saved = {}
+
+    def _wrap(self, name, fn, cost):
+        def wrapped(*a, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            if cost is not None:
+                flops, key = cost(*a, **kw)
+                nbytes = 0
+            else:
+                flops, key, nbytes = 0.0, '', _numel_bytes(a, kw)
+            self.records.append((name, key, flops, nbytes, e0, e1))
+            return out
+        return wrapped
+
+    def __enter__(self):
+        for name in list(GEMM_COSTS) + HBM_OPS:
+            fn = getattr(K, name)
+            self._saved[name] = fn
+            setattr(K, name, self._wrap(name, fn, GEMM_COSTS.get(name)))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(K, name, fn)
+        self._saved = {}
+        return False
+
+    def summary(self):
+        """[{name, key, calls, ms_total, ms_avg, flops, bytes, tflops, gbs}] sorted by total time."""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, key, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault((name, key), [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += flops
+            a[3] += nbytes
+        rows = []
+        for (name, key), (calls, ms, flops, nbytes) in agg.items():
+            rows.append(dict(name=name, key=key, calls=calls, ms_total=ms, ms_avg=ms / calls,
+                             flops=flops / calls, bytes=nbytes / calls,
+                             tflops=(flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                             gbs=(nbytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0))
+        rows.sort(key=lambda r: -r['ms_total'])
+        return rows

@@ -1,0 +1,199 @@
+"""Epoch driver shared by the four ``train.py`` drop-ins: the reference's ``__main__`` block
+(mnist/train.py:132-268) with the per-batch body replaced by the fused HIP step.
+
+Kept from the reference: every CLI flag and default, the KL-annealing schedule
+(mnist/train.py:180-186; fashionmnist's is one epoch ahead, fashionmnist/train.py:182), the log
+lines, AverageMeter (mnist/train.py:97-112), the checkpoint dict
+{'state_dict','best_loss','n_latents','optimizer'} (mnist/train.py:263-268) and
+load_checkpoint (mnist/train.py:124-129).  Opt-in additions: ``--synthetic`` (random-pixel /
+random-label batches, SURVEY.md section 8d -- the image has no datasets and no network),
+``--steps-per-epoch``, ``--no-graph``, and the ``RANK/WORLD_SIZE`` environment of
+``torch.distributed.run`` for data-parallel replicas.
+"""
+import os
+import shutil
+import sys
+
+import torch
+
+
+class AverageMeter(object):
+    """Computes and stores the average and current value (mnist/train.py:97-112)."""
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def save_checkpoint(state, is_best, folder='./', filename='checkpoint.pth.tar'):
+    if not os.path.isdir(folder):
+        os.mkdir(folder)
+    torch.save(state, os.path.join(folder, filename))
+    if is_best:
+        shutil.copyfile(os.path.join(folder, filename),
+                        os.path.join(folder, 'model_best.pth.tar'))
+
+
+def make_load_checkpoint(mvae_cls):
+    def load_checkpoint(file_path, use_cuda=False):
+        checkpoint = torch.load(file_path) if use_cuda else \
+            torch.load(file_path, map_location=lambda storage, location: storage)
+        model = mvae_cls(checkpoint['n_latents'])
+        model.load_state_dict(checkpoint['state_dict'])
+        return model
+    return load_checkpoint
+
+
+def add_extra_flags(parser):
+    parser.add_argument('--synthetic', action='store_true', default=False,
+                        help='random-pixel / random-label batches instead of the dataset')
+    parser.add_argument('--steps-per-epoch', type=int, default=100,
+                        help='mini-batches per epoch with --synthetic [default: 100]')
+    parser.add_argument('--no-graph', action='store_true', default=False,
+                        help='launch kernels eagerly instead of replaying the captured hipGraph')
+    parser.add_argument('--out-dir', type=str, default='./trained_models')
+
+
+class SyntheticLoader(object):
+    """len()/iteration surface of the DataLoader the reference builds (mnist/train.py:159-165)."""
+    def __init__(self, kind, batch_size, n_batches, seed, device):
+        self.kind, self.batch_size, self.n, self.seed, self.device = kind, batch_size, n_batches, seed, device
+        self.dataset = range(batch_size * n_batches)
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(self.n):
+            if self.kind in ('mnist', 'fashionmnist'):
+                image = torch.rand(self.batch_size, 1, 28, 28, generator=g)
+                label = torch.randint(0, 10, (self.batch_size,), generator=g)
+            else:
+                image = torch.rand(self.batch_size, 3, 64, 64, generator=g)
+                label = torch.randint(0, 2, (self.batch_size, 18), generator=g).float()
+            yield image.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
+
+
+def _real_loaders(kind, batch_size):
+    try:
+        from torchvision import transforms
+        from torchvision.datasets import MNIST
+    except ImportError:
+        raise SystemExit('torchvision is not installed: run with --synthetic (the reference reads '
+                         '%s through torchvision, mnist/train.py:159-165)' % kind)
+    if kind != 'mnist':
+        raise SystemExit('only the MNIST torchvision loader is wired up; use --synthetic')
+    mk = lambda train: torch.utils.data.DataLoader(  # noqa: E731
+        MNIST('./data', train=train, download=True, transform=transforms.ToTensor()),
+        batch_size=batch_size, shuffle=train, drop_last=True)
+    return mk(True), mk(False)
+
+
+def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0):
+    """The reference's main loop.  ``annealing_epoch_offset``: 0 for mnist/celeba
+    ((epoch - 1) * N, mnist/train.py:182), 1 for fashionmnist (epoch * N, fashionmnist/train.py:182)."""
+    import torch.distributed as dist
+    from .engine import BimodalStep
+    from .optim import FusedAdam
+    from .parallel import DataParallel
+
+    args.cuda = args.cuda and torch.cuda.is_available()
+    if not args.cuda:
+        raise SystemExit('this drop-in runs the MVAE step as HIP kernels: pass --cuda on a ROCm GPU box '
+                         '(the CPU path is the reference itself)')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+    if rank == 0 and not os.path.isdir(args.out_dir):
+        os.makedirs(args.out_dir)
+
+    if args.synthetic:
+        train_loader = SyntheticLoader(kind, args.batch_size, args.steps_per_epoch, 1234 + rank, device)
+        test_loader = SyntheticLoader(kind, args.batch_size, max(1, args.steps_per_epoch // 10), 4321, device)
+    else:
+        train_loader, test_loader = _real_loaders(kind, args.batch_size)
+    N_mini_batches = len(train_loader)
+
+    model = mvae_cls(args.n_latents)
+    model.cuda(device)
+    optimizer = FusedAdam(model.parameters(), lr=args.lr, grad_scale=1.0 / world)
+    engine = BimodalStep(model, args.batch_size, args.lambda_image, lambda_label, seed=1 + rank)
+    dp = DataParallel(model, engine) if world > 1 else None
+    captured = [False]
+
+    def train(epoch):
+        model.train()
+        train_loss_meter = AverageMeter()
+        pending = []          # device-side losses; read back only at the log interval
+        for batch_idx, (image, label) in enumerate(train_loader):
+            if epoch < args.annealing_epochs:
+                annealing_factor = (float(batch_idx + (epoch - 1 + annealing_epoch_offset) * N_mini_batches + 1) /
+                                    float(args.annealing_epochs * N_mini_batches))
+            else:
+                annealing_factor = 1.0
+            image, label = image.to(device), label.to(device)
+            if not args.no_graph:
+                if not captured[0]:
+                    engine.capture(optimizer, image.shape[1:], label, comm=dp)
+                    captured[0] = True
+                elbo = engine.replay(image, label, annealing_factor)
+            else:
+                elbo = engine.step(image, label, annealing_factor)
+                if dp is not None:
+                    dp.wait()
+                optimizer.step()
+            pending.append(elbo[-1].clone())
+            if batch_idx % args.log_interval == 0:
+                for v in torch.stack(pending).tolist():      # ONE device->host sync per log line
+                    train_loss_meter.update(v, len(image))
+                pending = []
+                if rank == 0:
+                    print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {:.6f}\tAnnealing-Factor: {:.3f}'.format(
+                        epoch, batch_idx * len(image), len(train_loader.dataset),
+                        100. * batch_idx / len(train_loader), train_loss_meter.avg, annealing_factor))
+        if pending:
+            for v in torch.stack(pending).tolist():
+                train_loss_meter.update(v, args.batch_size)
+        if rank == 0:
+            print('====> Epoch: {}\tLoss: {:.4f}'.format(epoch, train_loss_meter.avg))
+
+    def test(epoch):
+        model.eval()
+        test_loss_meter = AverageMeter()
+        with torch.no_grad():
+            for batch_idx, (image, label) in enumerate(test_loader):
+                image, label = image.to(device), label.to(device)
+                test_loss_meter.update(test_total(model, image, label, args).item(), len(image))
+        if rank == 0:
+            print('====> Test Loss: {:.4f}'.format(test_loss_meter.avg))
+        return test_loss_meter.avg
+
+    best_loss = sys.maxsize
+    for epoch in range(1, args.epochs + 1):
+        train(epoch)
+        test_loss = test(epoch)
+        is_best = test_loss < best_loss
+        best_loss = min(test_loss, best_loss)
+        if rank == 0:
+            save_checkpoint({
+                'state_dict': model.state_dict(),
+                'best_loss': best_loss,
+                'n_latents': args.n_latents,
+                'optimizer': optimizer.state_dict(),
+            }, is_best, folder=args.out_dir)
+    if world > 1:
+        dist.destroy_process_group()

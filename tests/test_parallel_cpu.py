@@ -1,0 +1,73 @@
+"""CPU: the N > 1 path with world_size 2 over gloo -- bucketed asynchronous gradient all-reduce
+on a flat arena, the averaged-gradient definition of SURVEY.md section 8(e), and the launch
+order the engine uses (bucket 0 = decoders before bucket 1 = encoders)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import mvae_amd
+    from mvae_amd.arena import ParamArena
+    from mvae_amd.parallel import GradBuckets, bucket_ranges
+
+    torch.manual_seed(100 + rank)                      # replicas start from DIFFERENT weights ...
+    model = mvae_amd.mnist.model.MVAE(16)
+    arena = ParamArena(model, order=model.arena_order(), adjacent=model.arena_adjacent())
+    dist.broadcast(arena.flat, src=0)                  # ... and are made identical, as DataParallel does
+    ranges = bucket_ranges(model, arena)
+    buckets = GradBuckets(arena.grad, ranges)
+
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(arena.numel, generator=g)
+    arena.grad.copy_(local)
+    buckets.launch(0)                                  # decoders' range first (ready first in backward)
+    buckets.launch(1)
+    buckets.wait()
+    averaged = arena.grad * (1.0 / world)              # FusedAdam's grad_scale
+    torch.save({'flat': arena.flat.clone(), 'avg': averaged, 'local': local, 'ranges': ranges},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % i)) for i in range(world)]
+    assert torch.equal(r[0]['flat'], r[1]['flat']), 'parameters must be identical after the broadcast'
+    expect = (r[0]['local'] + r[1]['local']) / world
+    for i in range(world):
+        assert torch.allclose(r[i]['avg'], expect, rtol=0, atol=1e-6)
+    (a0, a1), (b0, b1) = r[0]['ranges']
+    assert a0 == 0 and a1 == b0 and b1 == r[0]['flat'].numel()
+
+
+def test_bucket_ranges_must_tile_the_arena():
+    from mvae_amd.parallel import GradBuckets
+    flat = torch.zeros(100)
+    GradBuckets(flat, [(0, 40), (40, 100)])
+    with pytest.raises(ValueError):
+        GradBuckets(flat, [(0, 40), (50, 100)])
+    with pytest.raises(ValueError):
+        GradBuckets(flat, [(0, 40), (40, 90)])

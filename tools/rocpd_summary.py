@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace rocpd database (SQLite) as the per-kernel stats table
+rocprofv3 --stats would print: calls, total / average / min / max duration, share of GPU time.
+
+    python tools/rocpd_summary.py gpurun_out/prof_celeba/celeba_results.db > profiles/r01_celeba_kernel_stats.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'void ', '', name)
+    return name[:150]
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info('kernels')")]
+    rows = c.execute('select name, start, end from kernels').fetchall() if 'name' in cols else []
+    agg = {}
+    for name, s, e in rows:
+        a = agg.setdefault(short(name), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values()) or 1
+    print('# source: %s   (rocprofv3 --kernel-trace --stats, durations in microseconds)' % path)
+    print('%-8s %12s %10s %10s %10s %7s  %s' % ('calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'kernel'))
+    for name, (n, tot, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print('%-8d %12.1f %10.2f %10.2f %10.2f %6.2f%%  %s' % (n, tot / 1e3, tot / n / 1e3, mn / 1e3, mx / 1e3,
+                                                                 100.0 * tot / total, name))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
