@@ -157,27 +157,39 @@ def cpu_baseline(kind, batch, budget_s=15.0):
     """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
     host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s."""
     from oracle import models as OM, steps as OS
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    if kind == 'celeba19':
+        return None
+    cores = os.cpu_count() or 1
     cls, d = OM.MODELS[kind]
     torch.manual_seed(0)
     model = cls(d).train()
     opt = torch.optim.Adam(model.parameters(), lr=LR[kind])
     image, label = OS.synthetic_batch(kind, batch, 1234)
-    if kind == 'celeba19':
-        return None
-    n, t_total = 0, 0.0
-    for i in range(200):
+
+    def one_step():
         noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
         t0 = time.perf_counter()
         opt.zero_grad()
         total, _, _ = OS.bimodal_step(model, kind, image, label, noise, 1.0, LAMBDA_LABEL[kind], 0.5)
         total.backward()
         opt.step()
-        dt = time.perf_counter() - t0
-        if i >= 1:          # first step pays one-time allocations
-            n += 1; t_total += dt
-        if t_total > budget_s and n >= 2:
+        return time.perf_counter() - t0
+
+    # torch's CPU kernels do not scale to every core of a big host (oversubscribed small ops get
+    # slower): probe a few intra-op thread counts and time the sample at the fastest one
+    best = None
+    for th in [t for t in (8, 16, 32, 64) if t <= cores] or [cores]:
+        torch.set_num_threads(th)
+        one_step()                                   # warm this thread count
+        dt = one_step()
+        if best is None or dt < best[1]:
+            best = (th, dt)
+    threads = best[0]
+    torch.set_num_threads(threads)
+    n, t_total = 0, 0.0
+    while t_total < budget_s or n < 2:
+        t_total += one_step(); n += 1
+        if n >= 200:
             break
     return {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '

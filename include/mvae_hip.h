@@ -42,8 +42,15 @@ extern "C" {
 typedef void *mvae_stream_t;   /* hipStream_t */
 
 int mvae_abi_version(void);
-/* number of bytes of scratch any GEMM-shaped wgrad call below may need for this shape */
-size_t mvae_wgrad_ws_bytes(int rows_out, int cols_out, int reduce_len);
+/* bytes of scratch a GEMM-shaped call below may need for an output of rows_out x cols_out reduced
+ * over reduce_len (split reductions, or the repacked weights of a transposed conv: pass
+ * rows_out = Cin, cols_out = Cout*16 of the mirrored conv) */
+size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len);
+/* tuning hook: force the block tile (wm, wn in {1,2} = 64/128 rows/cols) and the number of
+ * reduction splits of every subsequent GEMM-shaped launch; 0 = automatic.  Debug only. */
+void mvae_debug_set_tiling(int wm, int wn, int splits);
+/* tuning hook: force the number of k-wave groups (1, 2, 4) of 64x64-tile launches; 0 = automatic */
+void mvae_debug_set_kwaves(int kw);
 
 /* ------------------------------------------------------------------------------------
  * K1  Linear (nn.Linear forward / backward): mnist/model.py:75-78,95-98,117-119,136-139;
@@ -57,15 +64,17 @@ size_t mvae_wgrad_ws_bytes(int rows_out, int cols_out, int reduce_len);
  * dgrad: dx[M,K] (+)= (dy[M,N] . w[N,K]) * (mask ? mask*mask_scale : 1) * swish'(pre_in)
  *        (pre_in = pre-activation that produced this layer's INPUT, NULL for none)
  * wgrad: dw[N,K] (+)= dy^T . x ;  db[N] (+)= sum_m dy   (db may be NULL)
+ * ws (mvae_gemm_ws_bytes): scratch for split reductions; NULL disables splitting.
  * ---------------------------------------------------------------------------------- */
 int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
                     float *pre, float *act, int ldy,
                     const float *mask, float mask_scale,
-                    int M, int N, int K, mvae_stream_t stream);
+                    int M, int N, int K, void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_linear_dgrad(const float *dy, int lddy, const float *w,
                       float *dx, int lddx,
                       const float *pre_in, const float *mask, float mask_scale,
-                      int M, int N, int K, int flags, mvae_stream_t stream);
+                      int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                      mvae_stream_t stream);
 int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
                       float *dw, float *db, int M, int N, int K, int flags,
                       void *ws, size_t ws_bytes, mvae_stream_t stream);
@@ -86,13 +95,13 @@ int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act,
                        mvae_stream_t stream);
 int mvae_conv2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in,
                          int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                         mvae_stream_t stream);
+                         void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_conv2d_k4_wgrad(const float *dy, const float *x, float *dw,
                          int B, int Cin, int H, int W, int Cout, int stride, int pad,
                          int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, float *act,
                         int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                        mvae_stream_t stream);
+                        void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in,
                           int B, int Cin, int H, int W, int Cout, int stride, int pad,
                           mvae_stream_t stream);

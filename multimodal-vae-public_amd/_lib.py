@@ -34,14 +34,16 @@ class ExpertGrads(ctypes.Structure):
 P = c_void_p
 _SIGNATURES = {
     'mvae_abi_version': (c_int, []),
-    'mvae_wgrad_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'mvae_linear_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_float, c_int, c_int, c_int, P]),
-    'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P]),
+    'mvae_gemm_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'mvae_debug_set_tiling': (None, [c_int, c_int, c_int]),
+    'mvae_debug_set_kwaves': (None, [c_int]),
+    'mvae_linear_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_float, c_int, c_int, c_int, P, c_size_t, P]),
+    'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_wgrad': (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_conv2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
-    'mvae_conv2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_conv2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P, c_size_t, P]),
     'mvae_conv2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),
-    'mvae_convT2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    'mvae_convT2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P, c_size_t, P]),
     'mvae_convT2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
     'mvae_convT2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),
     'mvae_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
@@ -98,7 +100,7 @@ def lib():
             fn = getattr(handle, name)   # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if handle.mvae_abi_version() != 1:
+        if handle.mvae_abi_version() != 2:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle
     return _lib

@@ -6,46 +6,50 @@
 //   * how the P and Q tiles are fetched from HBM (loader functors: row-major vector loads,
 //     implicit-im2col gathers, parity-decomposed transposed-conv gathers), and
 //   * what the epilogue does with the accumulator tile (bias / swish / dropout mask / swish'
-//     of the producer's pre-activation / accumulate / NCHW scatter / split-K partial).
+//     of the producer's pre-activation / accumulate / NCHW scatter).
 // The j axis is the lane axis of the MFMA result (32 consecutive j per store instruction),
 // so each op maps its memory-contiguous output axis to j.
 //
 // Tiling: 256 threads = 4 waves (2 x 2), each wave WM x WN MFMA tiles of 32x32
-// (block tile 64*WM x 64*WN), BK = 16.  Global -> registers -> LDS with the next tile's
-// loads in flight during the MFMAs of the current one; several blocks per CU hide the
-// barriers.  LDS tiles are [BK][tile + 4]: fragment reads are bank-conflict free
-// (ds_read_b32, lanes 0..31 consecutive), float4 tile rows stay 16-byte aligned.
+// (block tile 64*WM x 64*WN), BK = 32.  Software pipeline: global -> registers two k-tiles
+// ahead (two register sets), registers -> LDS one tile ahead (two LDS buffers), ONE barrier per
+// k-step; the fp32 MFMA (64 cycles each) of tile t hides the HBM/L2 latency of tile t+2.
+// LDS tiles are [BK][tile + 4]: fragment reads are bank-conflict free (ds_read_b32, lanes
+// 0..31 consecutive), float4 tile rows stay 16-byte aligned.
 //
-// Reductions over the batch (wgrad) are split across blockIdx.z into a caller-provided
-// workspace and summed by `splitk_reduce_kernel` in a fixed order: deterministic, no atomics.
+// Long reductions with a small output (weight gradients over the batch; Linear layers with
+// 6400 inputs or outputs) are split across blockIdx.z into a caller-provided workspace and
+// finished by `finish_kernel`, which sums the splits in a fixed order and applies the same
+// epilogue functor: deterministic, no atomics.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int LPAD = 4;
 constexpr int NTHREADS = 256;
 
 // ------------------------------------------------------------------------------------------
-// loaders.  Each exposes  init(tile0, t) / load(k0, kend, t) / store(lds, t)  and the tile
-// extent TILE along its non-reduced axis.  The LDS image is always [BK][TILE + LPAD].
+// loaders.  init(tile0, t) once; load(k0, kend, t, regs) global -> registers;
+// store(lds, t, regs) registers -> the LDS image [BK][TILE + LPAD].
 // ------------------------------------------------------------------------------------------
 
 // S[r * ld + k]: reduction axis contiguous (x and w of Linear fwd, dy of dgrad, conv weights).
 template <int TILE_>
 struct LdRowsK {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 64;
+    static constexpr int NV = TILE * BK / 4 / NTHREADS;
+    struct Regs { float4 v[NV]; };
     const float *src; int ld; int R; int vec;
-    int r0; float4 reg[NV];
-    __device__ void init(int tile0, int) { r0 = tile0; }
-    __device__ void load(int k0, int kend, int t) {
+    int r0;
+    __device__ void init(int tile0, int, int) { r0 = tile0; }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
-            const int r = r0 + (f >> 2), k = k0 + (f & 3) * 4;
+            const int r = r0 + f / (BK / 4), k = k0 + (f % (BK / 4)) * 4;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < R) {
                 const float *p = src + (size_t)r * ld + k;
@@ -58,30 +62,31 @@ struct LdRowsK {
                     if (k + 3 < kend) x.w = p[3];
                 }
             }
-            reg[v] = x;
+            rg.v[v] = x;
         }
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
-            const int r = f >> 2, kc = (f & 3) * 4;
-            L[kc + 0][r] = reg[v].x; L[kc + 1][r] = reg[v].y;
-            L[kc + 2][r] = reg[v].z; L[kc + 3][r] = reg[v].w;
+            const int r = f / (BK / 4), kc = (f % (BK / 4)) * 4;
+            L[kc + 0][r] = rg.v[v].x; L[kc + 1][r] = rg.v[v].y;
+            L[kc + 2][r] = rg.v[v].z; L[kc + 3][r] = rg.v[v].w;
         }
     }
 };
 
-// S[k * ld + r]: non-reduced axis contiguous (w of dgrad, dy and x of wgrad).
+// S[k * ld + r]: non-reduced axis contiguous (w of dgrad, dy and x of wgrad, repacked conv weights).
 template <int TILE_>
 struct LdRowsMN {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 64;
+    static constexpr int NV = TILE * BK / 4 / NTHREADS;
     static constexpr int V4 = TILE / 4;     // float4 per k row
-    const float *src; int ld; int R; int vec;
-    int r0; float4 reg[NV];
-    __device__ void init(int tile0, int) { r0 = tile0; }
-    __device__ void load(int k0, int kend, int t) {
+    struct Regs { float4 v[NV]; };
+    const float *src; int ld; int R; int vec; size_t cls_stride;   // cls_stride: per-class source offset
+    int r0;
+    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
@@ -98,14 +103,14 @@ struct LdRowsMN {
                     if (r + 3 < R) x.w = p[3];
                 }
             }
-            reg[v] = x;
+            rg.v[v] = x;
         }
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
-            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = reg[v];
+            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = rg.v[v];
         }
     }
 };
@@ -115,184 +120,192 @@ struct ConvGeom {
     int B, Cin, H, W, Cout, OH, OW, stride, pad;
 };
 
+// ---- gather loaders ----------------------------------------------------------------------
+// The k index of an element a thread fetches is  k0 + kq + STEP*v  with k0 a multiple of BK = 32,
+// kq = thread-constant (< STEP) and v the unrolled element counter.  STEP is a power of two, so the
+// (channel, tap-row, tap-col) fields of k are the OR of compile-time fields of STEP*v and the
+// thread-constant fields of kq: per element the address is ONE add of a wave-uniform offset, the
+// bounds test a compile-time shift of a precomputed bit mask.  (The first version decoded k and
+// re-tested the image bounds per element and was VALU-bound: 5 waves x ~250 VALU ops per k-step
+// against 1024 MFMA cycles.)
+
 // im2col of x for the forward conv: element (k = (ci,kh,kw), m = (b,oh,ow)); lanes along m.
 template <int TILE_>
 struct LdIm2col {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 16;              // elements per thread
-    static constexpr int KSTEP = NTHREADS / TILE;     // k rows covered per pass
+    static constexpr int NV = TILE * BK / NTHREADS;   // elements per thread
+    static constexpr int KSTEP = NTHREADS / TILE;     // 2 or 4: k rows covered per pass
+    struct Regs { float v[NV]; };
     const float *x; ConvGeom g; int Mtot;
-    int base; unsigned vh, vw; float reg[NV];
-    __device__ void init(int tile0, int t) {
+    int base, kq; unsigned vh, vwq;
+    __device__ void init(int tile0, int t, int) {
         const int m = tile0 + (t % TILE);
-        vh = vw = 0; base = 0;
+        kq = t / TILE;
+        unsigned vw = 0;
+        vh = 0; base = 0;
         if (m < Mtot) {
             const int ohw = g.OH * g.OW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
-            base = (b * g.Cin * g.H + ih0) * g.W + iw0;
+            base = (b * g.Cin * g.H + ih0) * g.W + iw0 + kq;      // kw = kq + (KSTEP*v & 3)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (ih0 + q >= 0 && ih0 + q < g.H) vh |= 1u << q;
                 if (iw0 + q >= 0 && iw0 + q < g.W) vw |= 1u << q;
             }
         }
+        vwq = vw >> kq;
     }
-    __device__ void load(int k0, int kend, int t) {
-        const int kb = k0 + t / TILE;
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int hw = g.H * g.W;
+        const float *src = x + base + (k0 >> 4) * hw;
+        const int krem = kend - k0 - kq;              // element valid iff KSTEP*v < krem
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int k = kb + v * KSTEP;
-            const int ci = k >> 4, kh = (k >> 2) & 3, kw = k & 3;
-            const bool ok = k < kend && ((vh >> kh) & 1u) && ((vw >> kw) & 1u);
-            reg[v] = ok ? x[base + ci * hw + kh * g.W + kw] : 0.f;
+            constexpr int dummy = 0; (void)dummy;
+            const int c = KSTEP * v;                  // compile-time after unrolling
+            const int kwl = c & 3, kh = (c >> 2) & 3, cil = c >> 4;
+            const bool ok = (c < krem) && ((vh >> kh) & 1u) && ((vwq >> kwl) & 1u);
+            rg.v[v] = ok ? src[cil * hw + kh * g.W + kwl] : 0.f;
         }
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = reg[v];
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v];
     }
 };
 
-// Transposed-conv (dgrad) gather of dy for ONE output parity class (ph,pw) of dx:
+// Transposed-conv (dgrad) gather of dy for the output parity class `cls` = (ph,pw) of dx:
 // element (k = (co,a,b), m = (n, ih', iw')) with ih = ih'*s + ph, kh = kh0 + s*a,
-// oh = (ih + pad - kh0)/s - a.  TPD = 4/s taps per dim; only the taps that can reach the
-// class are enumerated, so stride 2 does no multiply-by-zero work.
-template <int TILE_>
-struct LdDgradDy {
+// oh = (ih + pad - kh0)/s - a.  TPD = 4/s taps per dim (TLOG = log2 TPD); only the taps that can
+// reach the class are enumerated, so stride 2 does no multiply-by-zero work.
+template <int TILE_, int TLOG>
+struct LdDgradDyT {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 16;
+    static constexpr int NV = TILE * BK / NTHREADS;
     static constexpr int KSTEP = NTHREADS / TILE;
-    const float *dy; ConvGeom g; int Mtot; int H2, W2, ph, pw, kh0, kw0, tlog; // tlog = log2(TPD)
-    int base; unsigned vh, vw; float reg[NV];
-    __device__ void init(int tile0, int t) {
+    static constexpr int TMASK = (1 << TLOG) - 1;
+    struct Regs { float v[NV]; };
+    const float *dy; ConvGeom g; int Mtot; int H2, W2;
+    int base, kq; unsigned vhq, vwq;
+    __device__ void init(int tile0, int t, int cls) {
+        const int ph = cls / g.stride, pw = cls % g.stride;
+        const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
         const int m = tile0 + (t % TILE);
-        vh = vw = 0; base = 0;
+        kq = t / TILE;
+        const int aq = (kq >> TLOG) & TMASK, bq = kq & TMASK;     // thread-constant tap fields
+        unsigned vh = 0, vw = 0;
+        base = 0;
         if (m < Mtot) {
             const int hw2 = H2 * W2;
             const int n = m / hw2, rem = m - n * hw2;
             const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
             const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
             const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
-            base = (n * g.Cout * g.OH + ohb) * g.OW + owb;
-            const int tpd = 1 << tlog;
-            for (int a = 0; a < tpd; ++a) {
+            base = (n * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
+#pragma unroll
+            for (int a = 0; a <= TMASK; ++a) {
                 if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
                 if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
             }
         }
+        vhq = vh >> aq; vwq = vw >> bq;
     }
-    __device__ void load(int k0, int kend, int t) {
-        const int kb = k0 + t / TILE;
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int ohw = g.OH * g.OW;
-        const int tmask = (1 << tlog) - 1;
+        const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
+        const int krem = kend - k0 - kq;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int k = kb + v * KSTEP;
-            const int co = k >> (2 * tlog), a = (k >> tlog) & tmask, b = k & tmask;
-            const bool ok = k < kend && ((vh >> a) & 1u) && ((vw >> b) & 1u);
-            reg[v] = ok ? dy[base + co * ohw - a * g.OW - b] : 0.f;
+            const int c = KSTEP * v;
+            const int bl = c & TMASK, al = (c >> TLOG) & TMASK, col = c >> (2 * TLOG);
+            const bool ok = (c < krem) && ((vhq >> al) & 1u) && ((vwq >> bl) & 1u);
+            rg.v[v] = ok ? src[col * ohw - al * g.OW - bl] : 0.f;
         }
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = reg[v];
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v];
     }
 };
-
-// Weights for the same parity class: element (i = ci, k = (co,a,b)) = w[co][ci][kh0+s*a][kw0+s*b].
-template <int TILE_>
-struct LdDgradW {
-    static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 16;
-    static constexpr int KSTEP = NTHREADS / TILE;
-    const float *w; int Cin, stride, kh0, kw0, tlog;
-    int ci; float reg[NV];
-    __device__ void init(int tile0, int t) { ci = tile0 + (t % TILE); }
-    __device__ void load(int k0, int kend, int t) {
-        const int kb = k0 + t / TILE;
-        const int tmask = (1 << tlog) - 1;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int k = kb + v * KSTEP;
-            const int co = k >> (2 * tlog), a = (k >> tlog) & tmask, b = k & tmask;
-            const bool ok = k < kend && ci < Cin;
-            reg[v] = ok ? w[((co * Cin + ci) * 4 + kh0 + stride * a) * 4 + kw0 + stride * b] : 0.f;
-        }
-    }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
-        const int m = t % TILE, kb = t / TILE;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = reg[v];
-    }
-};
+template <int TILE_> using LdDgradDyS2 = LdDgradDyT<TILE_, 1>;   // stride 2: 2x2 taps per class
+template <int TILE_> using LdDgradDyS1 = LdDgradDyT<TILE_, 2>;   // stride 1: all 4x4 taps
 
 // wgrad operands: the reduction runs over k = (b,oh,ow); lanes along k (spatially contiguous).
 // P: element (i = co, k) = dy[b][co][oh][ow].
 template <int TILE_>
 struct LdWgradDy {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 16;
-    const float *dy; ConvGeom g; int i0;
-    float reg[NV];
-    __device__ void init(int tile0, int) { i0 = tile0; }
-    __device__ void load(int k0, int kend, int t) {
-        const int k = k0 + (t & 15);
+    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int ISTEP = NTHREADS / BK;
+    struct Regs { float v[NV]; };
+    const float *dy; ConvGeom g;
+    int ioff, nvalid;       // ioff = i * OHW of element 0; nvalid = how many of the NV rows are < Cout
+    __device__ void init(int tile0, int t, int) {
+        const int ib = tile0 + t / BK;
+        ioff = ib * g.OH * g.OW;
+        nvalid = (g.Cout - ib + ISTEP - 1) / ISTEP;     // rows ib + v*ISTEP < Cout  <=>  v < nvalid
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
-        const int ib = i0 + (t >> 4);
+        const float *src = dy + (size_t)b * g.Cout * ohw + sp + ioff;
+        const int nv = (k < kend) ? nvalid : 0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = ib + v * 16;
-            reg[v] = (k < kend && i < g.Cout) ? dy[(size_t)(b * g.Cout + i) * ohw + sp] : 0.f;
-        }
+        for (int v = 0; v < NV; ++v) rg.v[v] = (v < nv) ? src[v * ISTEP * ohw] : 0.f;
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
-        const int kl = t & 15, ib = t >> 4;
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
+        const int kl = t % BK, ib = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][ib + v * 16] = reg[v];
+        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v];
     }
 };
 
-// Q: element (k, j = (ci,kh,kw)) = x[b][ci][oh*s-p+kh][ow*s-p+kw].
+// Q: element (k, j = (ci,kh,kw)) = x[b][ci][oh*s-p+kh][ow*s-p+kw];  j = j0 + jq + 8*v, jq = t/32 < 8.
 template <int TILE_>
 struct LdWgradX {
     static constexpr int TILE = TILE_;
-    static constexpr int NV = TILE / 16;
-    const float *x; ConvGeom g; int J; int j0;
-    float reg[NV];
-    __device__ void init(int tile0, int) { j0 = tile0; }
-    __device__ void load(int k0, int kend, int t) {
-        const int k = k0 + (t & 15);
+    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int JSTEP = NTHREADS / BK;       // 8
+    struct Regs { float v[NV]; };
+    const float *x; ConvGeom g; int J;
+    int joff, jq, nvalid;
+    __device__ void init(int tile0, int t, int) {
+        jq = t / BK;                                  // kw = jq & 3, kh = (jq >> 2) + 2*(v & 1), ci = j0/16 + (v >> 1)
+        joff = (tile0 >> 4) * g.H * g.W + (jq >> 2) * g.W + (jq & 3);
+        nvalid = (J - tile0 - jq + JSTEP - 1) / JSTEP;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
         const int oh = sp / g.OW, ow = sp - oh * g.OW;
         const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
         const int hw = g.H * g.W;
-        const int base = b * g.Cin * hw + ih0 * g.W + iw0;
-        const int jb = j0 + (t >> 4);
+        const float *src = x + (size_t)b * g.Cin * hw + ih0 * g.W + iw0 + joff;
+        const int iw = iw0 + (jq & 3), ihq = ih0 + (jq >> 2);
+        const bool okw = k < kend && iw >= 0 && iw < g.W;
+        const bool ok0 = okw && ihq >= 0 && ihq < g.H;            // kh = jq>>2       (v even)
+        const bool ok1 = okw && ihq + 2 >= 0 && ihq + 2 < g.H;    // kh = (jq>>2) + 2 (v odd)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const int j = jb + v * 16;
-            const int ci = j >> 4, kh = (j >> 2) & 3, kw = j & 3;
-            const int ih = ih0 + kh, iw = iw0 + kw;
-            const bool ok = k < kend && j < J && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            reg[v] = ok ? x[base + ci * hw + kh * g.W + kw] : 0.f;
+            const bool ok = ((v & 1) ? ok1 : ok0) && v < nvalid;
+            rg.v[v] = ok ? src[(v >> 1) * hw + 2 * (v & 1) * g.W] : 0.f;
         }
     }
-    __device__ void store(float (*L)[TILE + LPAD], int t) {
-        const int kl = t & 15, jb = t >> 4;
+    __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
+        const int kl = t % BK, jb = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][jb + v * 16] = reg[v];
+        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v];
     }
 };
 
 // ------------------------------------------------------------------------------------------
-// epilogues:  col(j) prepares the lane's column, put(i, j, v, split) consumes one element.
+// epilogues:  col(j) prepares the lane's column, put(i, j, v) consumes one element.
 // ------------------------------------------------------------------------------------------
 
 // Row-major destination D[i * ld + j] with the Linear fusions.
@@ -302,8 +315,9 @@ struct EpRowMajor {
     const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
     const float *mask; int ldm; float mask_scale;   // dropout keep-mask (fwd on act, bwd on the product)
     int I, J; int accumulate;
+    __device__ void set_class(int) {}
     __device__ bool col(int j) const { return j < J; }
-    __device__ void put(int i, int j, float v, int) const {
+    __device__ void put(int i, int j, float v) const {
         if (i >= I) return;
         if (bias) v += bias[j];
         float m = 1.f;
@@ -317,11 +331,12 @@ struct EpRowMajor {
 };
 
 // NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
-// address = (n * C + i) * HW + (row' * sy + py) * Wfull + col' * sx + px.
+// address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
     int off;   // per-lane column offset, set by col()
+    __device__ void set_class(int cls) { if (sy > 1) { py = cls / sy; px = cls % sy; } }
     __device__ bool col(int j) {
         if (j >= J) return false;
         const int hw2 = H2 * W2;
@@ -330,7 +345,7 @@ struct EpNCHW {
         off = n * C * HW + (r * sy + py) * Wfull + c * sy + px;
         return true;
     }
-    __device__ void put(int i, int, float v, int) const {
+    __device__ void put(int i, int, float v) const {
         if (i >= C) return;
         const int idx = off + i * HW;
         if (dpre) v *= swish_grad_(dpre[idx]);
@@ -339,40 +354,46 @@ struct EpNCHW {
     }
 };
 
-// Split-K partial: ws[(split * I + i) * J + j]; or, with one split, the final row-major result.
-struct EpPartial {
-    float *ws; int I, J; size_t split_stride;
-    float *direct; int accumulate;            // used when gridDim.z == 1
-    __device__ bool col(int j) const { return j < J; }
-    __device__ void put(int i, int j, float v, int split) const {
-        if (i >= I) return;
-        const size_t idx = (size_t)i * J + j;
-        if (direct) {
-            if (accumulate) v += direct[idx];
-            direct[idx] = v;
-        } else {
-            ws[split * split_stride + idx] = v;
-        }
-    }
+// Where the raw partial tiles of a split reduction go (row-major [I][J] per split), plus the
+// optional row sums of P (bias gradient of a Linear wgrad).
+struct SplitSink {
+    float *ws; size_t stride; int I, J;       // partial (split, i, j) at ws[split*stride + i*J + j]
+    float *rowsum; size_t rowsum_stride; int rowsum_accumulate;   // (split, i) at rowsum[split*rowsum_stride + i]
+    int ncls;                                 // parity classes folded into gridDim.x (transposed conv)
 };
 
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <class P, class Q, class E, int WM, int WN, bool ROWSUM>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(P p, Q q, E e, int K, int klen,
-                                                         float *rowsum_out, size_t rowsum_stride,
-                                                         int rowsum_rows, int rowsum_accumulate) {
+// KW > 1 (64x64 tiles only): KW groups of 4 waves share the tile; group kg takes every KW-th
+// k-pair of each LDS tile, the partial accumulators are summed through LDS at the end.  Small
+// GEMMs (the 512-wide MLP layers at batch 512-1024) have < 256 tiles, i.e. fewer than one wave per
+// SIMD: the extra wave groups put all 1024 SIMDs to work and shorten each block's serial MFMA
+// chain KW-fold without a second launch.  Waves >= 4 only issue MFMAs; waves 0-3 also move data.
+template <class P, class Q, class E, int WM, int WN, bool ROWSUM, int KW>
+__global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel(P p, Q q, E e, int K, int klen,
+                                                                               SplitSink sink) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     static_assert(P::TILE == BM && Q::TILE == BN, "loader tile mismatch");
-    __shared__ __attribute__((aligned(16))) float Ps[BK][BM + LPAD];
-    __shared__ __attribute__((aligned(16))) float Qs[BK][BN + LPAD];
+    // dynamic LDS (the 128x128 tile needs 66 KiB, above the 64 KiB static limit); the only LDS
+    // object of the kernel, so its base is 16-byte aligned (cdna_hip_programming.md G17)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    typedef float (*PTile)[BM + LPAD];
+    typedef float (*QTile)[BN + LPAD];
+    PTile Ps[2] = {reinterpret_cast<PTile>(lds_raw), reinterpret_cast<PTile>(lds_raw + BK * (BM + LPAD))};
+    float *qbase = lds_raw + 2 * BK * (BM + LPAD);
+    QTile Qs[2] = {reinterpret_cast<QTile>(qbase), reinterpret_cast<QTile>(qbase + BK * (BN + LPAD))};
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN, split = blockIdx.z;
+    const int kg = wave >> 2;                       // k-group of this wave (0 when KW == 1)
+    const int wi = (wave & 3) >> 1, wj = wave & 1;
+    const bool mover = (KW == 1) || t < NTHREADS;   // waves 0-3 fetch and stage the tiles
+    const int tiles_j = gridDim.x / sink.ncls;
+    const int cls = blockIdx.x / tiles_j;
+    const int i0 = blockIdx.y * BM, j0 = (blockIdx.x - cls * tiles_j) * BN, split = blockIdx.z;
     const int kbeg = split * klen;
     const int kend = min(K, kbeg + klen);
+    const int nsteps = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -382,65 +403,126 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(P p, Q q, E e, int K, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    p.init(i0, t);
-    q.init(j0, t);
-    p.load(kbeg, kend, t);
-    q.load(kbeg, kend, t);
+    p.init(i0, t, cls);
+    q.init(j0, t, cls);
+    e.set_class(cls);
+    typename P::Regs pr0, pr1;
+    typename Q::Regs qr0, qr1;
     float rsum = 0.f;
-
     const int lrow = lane >> 5, lcol = lane & 31;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        p.store(Ps, t);
-        q.store(Qs, t);
-        __syncthreads();
-        if (k0 + BK < kend) {
-            p.load(k0 + BK, kend, t);
-            q.load(k0 + BK, kend, t);
-        }
-        if (ROWSUM) {   // db = sum over the reduction axis of P (dy^T): bias gradient for free
-            if (blockIdx.x == 0 && t < BM) {
+
+    auto compute = [&](int buf) {
+        if (ROWSUM) {   // db = sum over the reduction axis of P (dy^T): the bias gradient for free
+            if (blockIdx.x == 0 && t < BM) {      // (t < BM <= 256: always a wave of k-group 0)
 #pragma unroll
-                for (int kk = 0; kk < BK; ++kk) rsum += Ps[kk][t];
+                for (int kk = 0; kk < BK; ++kk) rsum += Ps[buf][kk][t];
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int kq = 0; kq < BK / 2 / KW; ++kq) {
+            const int kk = kq * KW + kg;
             float a[WM], b[WN];
 #pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = Ps[kk * 2 + lrow][(wi * WM + x) * 32 + lcol];
+            for (int x = 0; x < WM; ++x) a[x] = Ps[buf][kk * 2 + lrow][(wi * WM + x) * 32 + lcol];
 #pragma unroll
-            for (int y = 0; y < WN; ++y) b[y] = Qs[kk * 2 + lrow][(wj * WN + y) * 32 + lcol];
+            for (int y = 0; y < WN; ++y) b[y] = Qs[buf][kk * 2 + lrow][(wj * WN + y) * 32 + lcol];
 #pragma unroll
             for (int x = 0; x < WM; ++x)
 #pragma unroll
                 for (int y = 0; y < WN; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
         }
+    };
+
+    // prologue: tiles 0 and 1 in flight, tile 0 staged
+    if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
+    if (mover && nsteps > 1) { p.load(kbeg + BK, kend, t, pr1); q.load(kbeg + BK, kend, t, qr1); }
+    if (mover && nsteps > 0) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+        // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
+        if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BK, kend, t, pr0); q.load(kbeg + (s + 2) * BK, kend, t, qr0); }
+        compute(0);
+        if (mover && s + 1 < nsteps) { p.store(Ps[1], t, pr1); q.store(Qs[1], t, qr1); }
+        __syncthreads();
+        if (s + 1 >= nsteps) break;
+        // odd step
+        if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BK, kend, t, pr1); q.load(kbeg + (s + 3) * BK, kend, t, qr1); }
+        compute(1);
+        if (mover && s + 2 < nsteps) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+        __syncthreads();
+    }
+    if (KW > 1) {
+        // sum the k-groups' accumulators through LDS (the tile buffers are free after the last barrier)
+        constexpr int PER_WAVE = WM * WN * 16 * 64;
+        float *red = lds_raw;
+        if (kg > 0) {
+            float *dst = red + ((kg - 1) * 4 + (wave & 3)) * PER_WAVE + lane;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((x * WN + y) * 16 + r) * 64] = acc[x][y][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g2 = 0; g2 < KW - 1; ++g2) {
+            const float *src = red + (g2 * 4 + wave) * PER_WAVE + lane;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][y][r] += src[((x * WN + y) * 16 + r) * 64];
+        }
     }
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool partial = gridDim.z > 1;
 #pragma unroll
     for (int y = 0; y < WN; ++y) {
         const int j = j0 + (wj * WN + y) * 32 + lcol;
-        if (!e.col(j)) continue;
+        if (partial) {
+            if (j >= sink.J) continue;
+        } else if (!e.col(j)) {
+            continue;
+        }
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
             const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e.put(ib + (r & 3) + 8 * (r >> 2), j, acc[x][y][r], split);
+            for (int r = 0; r < 16; ++r) {
+                const int i = ib + (r & 3) + 8 * (r >> 2);
+                if (partial) {
+                    if (i < sink.I) sink.ws[(size_t)split * sink.stride + (size_t)i * sink.J + j] = acc[x][y][r];
+                } else {
+                    e.put(i, j, acc[x][y][r]);
+                }
+            }
         }
     }
     if (ROWSUM) {
-        if (blockIdx.x == 0 && t < BM && i0 + t < rowsum_rows) {
-            float *dst = rowsum_out + (size_t)split * rowsum_stride + i0 + t;
-            if (gridDim.z == 1 && rowsum_accumulate) rsum += *dst;
+        if (blockIdx.x == 0 && t < BM && i0 + t < sink.I) {
+            float *dst = sink.rowsum + (size_t)split * sink.rowsum_stride + i0 + t;
+            if (!partial && sink.rowsum_accumulate) rsum += *dst;
             *dst = rsum;
         }
     }
 }
 
-// out[idx] (+)= sum_s ws[s * stride + idx]
+// Sum the split partials in a fixed order and run the epilogue on the result.
+template <class E>
+__global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits, E e) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (!e.col(j) || j >= sink.J) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
+    e.put(i, j, s);
+}
+
+// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient partials)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *out, int n,
                                                             int splits, size_t stride, int accumulate) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -451,65 +533,120 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, flo
     out[idx] = s;
 }
 
+// wr[cls][(co,a,b)][ci] = w[co][ci][kh0 + s*a][kw0 + s*b]: the weights of one output parity class of
+// a transposed conv, reduction index major / input channel contiguous, so the dgrad-form GEMM
+// fetches them with coalesced float4 loads instead of a 64-byte-stride gather.
+__global__ __launch_bounds__(256) void repack_dgrad_weights_kernel(const float *w, float *wr, int Cout, int Cin,
+                                                                   int stride, int pad) {
+    const int tlog = (stride == 2) ? 1 : 2, tpd = 1 << tlog;
+    const int kc = Cout * tpd * tpd;                 // reduction length per class
+    const int total = stride * stride * kc * Cin;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ci = idx % Cin;
+        int rest = idx / Cin;
+        const int k = rest % kc, cls = rest / kc;
+        const int ph = cls / stride, pw = cls % stride;
+        const int kh0 = (ph + pad) % stride, kw0 = (pw + pad) % stride;
+        const int co = k >> (2 * tlog), a = (k >> tlog) & (tpd - 1), b = k & (tpd - 1);
+        wr[idx] = w[((co * Cin + ci) * 4 + kh0 + stride * a) * 4 + kw0 + stride * b];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct TileChoice { int wm, wn; };
+struct Plan { int wm, wn, splits, klen, kw; };
 
-// Prefer 128-wide tiles; fall back to 64 where the extent is small or the grid would leave
-// most of the 256 CUs idle.
-inline TileChoice choose_tile(int I, int J, int splits_hint) {
-    TileChoice c{2, 2};
-    if (I <= 64) c.wm = 1;
-    if (J <= 64) c.wn = 1;
-    auto blocks = [&](const TileChoice &t) {
-        return (long)((I + 64 * t.wm - 1) / (64 * t.wm)) * ((J + 64 * t.wn - 1) / (64 * t.wn)) * splits_hint;
-    };
-    while (blocks(c) < 512 && (c.wm > 1 || c.wn > 1)) {
-        if (c.wm > 1 && (c.wn == 1 || I >= J)) c.wm = 1; else c.wn = 1;
+int g_force_wm = 0, g_force_wn = 0, g_force_splits = 0, g_force_kw = 0;   // tuning hook (mvae_debug_set_tiling)
+
+// Tile and split choice, from the measurements in profiles/r01_gemm_tiles.txt (tools/gemm_bench.py):
+// the gather-fed forward / dgrad forms and the Linear layers run best on 64x64 tiles (5 waves per
+// SIMD hide the gather latency; 128-wide tiles drop to 2-3 waves), the conv weight-gradient form
+// (two gathers feeding a small output over a huge reduction) wants the arithmetic intensity of
+// 128-wide tiles.  Reductions are split until ~4 blocks per CU exist (>= 2 k-steps per split).
+enum PlanKind { PLAN_FWD = 0, PLAN_CONV_WGRAD = 1, PLAN_LIN_WGRAD = 2 };
+
+inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLAN_FWD, int ncls = 1) {
+    Plan p;
+    p.wm = 1; p.wn = 1;
+    if (kind == PLAN_CONV_WGRAD) {
+        if (J >= 128) p.wn = 2;
+        if (I >= 128 && J >= 128) p.wm = 2;
     }
-    return c;
+    if (g_force_wm) p.wm = g_force_wm;
+    if (g_force_wn) p.wn = g_force_wn;
+    const long tiles = (long)((I + 64 * p.wm - 1) / (64 * p.wm)) * ((J + 64 * p.wn - 1) / (64 * p.wn)) * ncls;
+    // fewer than one wave per SIMD (256 CUs x 4): let KW wave groups share each 64x64 tile
+    p.kw = 1;
+    if (p.wm == 1 && p.wn == 1 && K >= 4 * BK) {
+        if (tiles * 4 <= 256) p.kw = 4;
+        else if (tiles * 2 <= 256) p.kw = 2;
+    }
+    if (g_force_kw) p.kw = (p.wm == 1 && p.wn == 1) ? g_force_kw : 1;
+    long want = 1;
+    if (allow_split) {
+        const long target_blocks = 1024 / p.kw;
+        want = (target_blocks + tiles - 1) / tiles;
+        const long maxs = (K + 2 * BK - 1) / (2 * BK);
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        if (want > 64) want = 64;
+        if (g_force_splits) want = g_force_splits;
+    }
+    p.klen = (int)(((K + want - 1) / want + BK - 1) / BK * BK);
+    p.splits = (K + p.klen - 1) / p.klen;
+    return p;
 }
 
 template <template <int> class PL, template <int> class QL, class E, bool ROWSUM, class PF, class QF>
-int launch_igemm(TileChoice tc, PF make_p, QF make_q, E e, int I, int J, int K, int splits, int klen,
-                 float *rowsum_out, size_t rowsum_stride, int rowsum_rows, int rowsum_acc, hipStream_t st) {
-#define MVAE_LAUNCH(WM, WN)                                                                      \
+int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitSink sink, hipStream_t st) {
+#define MVAE_LAUNCH(WM, WN, KW)                                                                  \
     {                                                                                            \
         PL<64 * WM> p; make_p(p);                                                                \
         QL<64 * WN> q; make_q(q);                                                                \
-        dim3 grid((J + 64 * WN - 1) / (64 * WN), (I + 64 * WM - 1) / (64 * WM), splits);         \
-        hipLaunchKernelGGL((igemm_kernel<PL<64 * WM>, QL<64 * WN>, E, WM, WN, ROWSUM>), grid,    \
-                           dim3(NTHREADS), 0, st, p, q, e, K, klen, rowsum_out, rowsum_stride,   \
-                           rowsum_rows, rowsum_acc);                                             \
+        dim3 grid(((J + 64 * WN - 1) / (64 * WN)) * sink.ncls, (I + 64 * WM - 1) / (64 * WM),    \
+                  pl.splits);                                                                    \
+        constexpr size_t tile_b = 2 * BK * (64 * WM + LPAD + 64 * WN + LPAD) * sizeof(float);    \
+        constexpr size_t red_b = (size_t)(KW - 1) * 4 * WM * WN * 16 * 64 * sizeof(float);       \
+        constexpr size_t lds = tile_b > red_b ? tile_b : red_b;                                  \
+        auto kern = igemm_kernel<PL<64 * WM>, QL<64 * WN>, E, WM, WN, ROWSUM, KW>;               \
+        static bool attr_done = false;                                                           \
+        if (!attr_done) {                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            attr_done = true;                                                                    \
+        }                                                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(NTHREADS * KW), lds, st, p, q, e, K, pl.klen, sink); \
     }
-    if (tc.wm == 2 && tc.wn == 2) MVAE_LAUNCH(2, 2)
-    else if (tc.wm == 2 && tc.wn == 1) MVAE_LAUNCH(2, 1)
-    else if (tc.wm == 1 && tc.wn == 2) MVAE_LAUNCH(1, 2)
-    else MVAE_LAUNCH(1, 1)
+    if (pl.wm == 2 && pl.wn == 2) MVAE_LAUNCH(2, 2, 1)
+    else if (pl.wm == 2 && pl.wn == 1) MVAE_LAUNCH(2, 1, 1)
+    else if (pl.wm == 1 && pl.wn == 2) MVAE_LAUNCH(1, 2, 1)
+    else if (pl.kw == 4) MVAE_LAUNCH(1, 1, 4)
+    else if (pl.kw == 2) MVAE_LAUNCH(1, 1, 2)
+    else MVAE_LAUNCH(1, 1, 1)
 #undef MVAE_LAUNCH
+    if (pl.splits > 1) {
+        dim3 grid((J + 255) / 256, I);
+        hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+    }
     return mvae_launch_status();
 }
 
-// Split plan for batch reductions: enough blocks to fill the chip, splits aligned to BK.
-struct SplitPlan { int splits, klen; };
-inline SplitPlan plan_splits(int I, int J, int K, TileChoice tc) {
-    const long tiles = (long)((I + 64 * tc.wm - 1) / (64 * tc.wm)) * ((J + 64 * tc.wn - 1) / (64 * tc.wn));
-    long want = (512 + tiles - 1) / tiles;
-    const long maxs = (K + 4 * BK - 1) / (4 * BK);      // at least 4 k-steps per split
-    if (want > maxs) want = maxs;
-    if (want < 1) want = 1;
-    if (want > 256) want = 256;
-    int klen = (int)(((K + want - 1) / want + BK - 1) / BK * BK);
-    int splits = (K + klen - 1) / klen;
-    return {splits, klen};
+inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
+    SplitSink s;
+    s.ws = (float *)ws; s.I = I; s.J = J;
+    s.stride = (size_t)I * J + (rowsum ? I : 0);
+    s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1;
+    return s;
 }
 
-inline size_t wgrad_ws_floats(int I, int J, int K) {
-    // worst case over tile choices: plan with the smallest tiles -> most splits is bounded by 256
-    TileChoice tc = choose_tile(I, J, 4);
-    SplitPlan sp = plan_splits(I, J, K, tc);
-    return (size_t)sp.splits * ((size_t)I * J + I);
+inline size_t split_ws_floats(int I, int J, int K) {
+    size_t best = 0;      // the caller does not say which op it sizes for: take the largest plan
+    for (int kind = 0; kind < 3; ++kind) {
+        Plan pl = make_plan(I, J, K, true, (PlanKind)kind);
+        if (pl.splits > 1 && (size_t)pl.splits > best) best = pl.splits;
+    }
+    return best * ((size_t)I * J + I);
 }
 
 inline ConvGeom make_geom(int B, int Cin, int H, int W, int Cout, int stride, int pad) {
@@ -533,69 +670,139 @@ inline bool conv_args_ok(int B, int Cin, int H, int W, int Cout, int stride, int
 int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const float *dpre,
                   ConvGeom g, hipStream_t st) {
     const int I = g.Cout, J = g.B * g.OH * g.OW, K = g.Cin * 16;
-    TileChoice tc = choose_tile(I, J, 1);
+    Plan pl = make_plan(I, J, K, false);
     EpNCHW e;
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
     e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.vec = aligned16(w) ? 1 : 0; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
-    return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(tc, mp, mq, e, I, J, K, 1, (K + BK - 1) / BK * BK,
-                                                          nullptr, 0, 0, 0, st);
+    return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
 }
 
+// ---- direct transposed conv for <= 4 OUTPUT channels (ConvTranspose2d(32,3) / (64,1), stride 2,
+//      pad 1: celeba/model.py:126, fashionmnist/model.py:114).  As a GEMM these have a 3-row output
+//      tile (5 % MFMA utilisation); they are HBM/L1-bound streaming ops instead: one thread owns the
+//      2x2 output quad (2a..2a+1, 2b..2b+1) of every channel, which depends on the 3x3 dy
+//      neighbourhood (a-1..a+1, b-1..b+1) of each of the Cout input maps; weights sit in LDS. ----
+template <int C>
+__global__ __launch_bounds__(256) void convT_small_kernel(const float *dy, const float *w, float *out, float *act,
+                                                          const float *dpre, ConvGeom g, int total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [Cout][C][4][4]
+    for (int i = threadIdx.x; i < g.Cout * C * 16; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int OH = g.OH, OW = g.OW;                  // dy is [B][Cout][OH][OW]; out [B][C][2*OH][2*OW]
+    const int b = idx % OW, a = (idx / OW) % OH, n = idx / (OW * OH);
+    float acc[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f; }
+    const bool rm = a > 0, rp = a + 1 < OH, cm = b > 0, cp = b + 1 < OW;
+    const float *src = dy + ((size_t)n * g.Cout * OH + a) * OW + b;
+    for (int co = 0; co < g.Cout; ++co, src += OH * OW) {
+        float d[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool ok = (r == 1 || (r == 0 ? rm : rp)) && (q == 1 || (q == 0 ? cm : cp));
+                d[r][q] = ok ? src[(r - 1) * OW + (q - 1)] : 0.f;
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 *wp = reinterpret_cast<const float4 *>(wl + (co * C + c) * 16);
+            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];    // rows kh = 0..3, fields kw
+            // (ph,pw) = (0,0): kh in {1,3} <-> rows a, a-1 ; kw in {1,3} <-> cols b, b-1
+            acc[c][0] += w1.y * d[1][1] + w1.w * d[1][0] + w3.y * d[0][1] + w3.w * d[0][0];
+            // (0,1): kw in {0,2} <-> cols b+1, b
+            acc[c][1] += w1.x * d[1][2] + w1.z * d[1][1] + w3.x * d[0][2] + w3.z * d[0][1];
+            // (1,0): kh in {0,2} <-> rows a+1, a
+            acc[c][2] += w0.y * d[2][1] + w0.w * d[2][0] + w2.y * d[1][1] + w2.w * d[1][0];
+            acc[c][3] += w0.x * d[2][2] + w0.z * d[2][1] + w2.x * d[1][2] + w2.z * d[1][1];
+        }
+    }
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t o = (((size_t)n * C + c) * H + 2 * a + ph) * W + 2 * b;
+            float v0 = acc[c][ph * 2], v1 = acc[c][ph * 2 + 1];
+            if (dpre) { v0 *= swish_grad_(dpre[o]); v1 *= swish_grad_(dpre[o + 1]); }
+            if (out) *reinterpret_cast<float2 *>(out + o) = make_float2(v0, v1);
+            if (act) *reinterpret_cast<float2 *>(act + o) = make_float2(swishf_(v0), swishf_(v1));
+        }
+    }
+}
+
+inline bool conv_dgrad_small_ok(const ConvGeom &g) {
+    return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && g.H == 2 * g.OH && g.W == 2 * g.OW &&
+           (size_t)g.Cout * g.Cin * 16 * sizeof(float) <= 48 * 1024;
+}
+
+inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *act, const float *dpre,
+                            ConvGeom g, hipStream_t st) {
+    const int total = g.B * g.OH * g.OW;
+    const size_t lds = (size_t)g.Cout * g.Cin * 16 * sizeof(float);
+    const dim3 grid((total + 255) / 256), blk(256);
+    switch (g.Cin) {
+        case 1: hipLaunchKernelGGL(convT_small_kernel<1>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        case 2: hipLaunchKernelGGL(convT_small_kernel<2>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        case 3: hipLaunchKernelGGL(convT_small_kernel<3>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        default: hipLaunchKernelGGL(convT_small_kernel<4>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+    }
+    return mvae_launch_status();
+}
+
+inline size_t dgrad_ws_floats(const ConvGeom &g) { return (size_t)g.Cout * g.Cin * 16; }
+
 // ---- conv dgrad form: dx[n][ci][ih][iw] = sum_(co,kh,kw) w[co][ci][kh][kw] * dy[n][co][oh][ow],
-//      one launch per output parity class (4 for stride 2, 1 for stride 1) ----
+//      one launch per output parity class (4 for stride 2, 1 for stride 1) on repacked weights ----
 int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, const float *dpre,
-                    ConvGeom g, hipStream_t st) {
+                    ConvGeom g, void *ws, size_t ws_bytes, hipStream_t st) {
     const int s = g.stride, tlog = (s == 2) ? 1 : 2;
     const int H2 = g.H / s, W2 = g.W / s;
     const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << (2 * tlog);
-    TileChoice tc = choose_tile(I, J, s * s);
-    for (int ph = 0; ph < s; ++ph)
-        for (int pw = 0; pw < s; ++pw) {
-            const int kh0 = (ph + g.pad) % s, kw0 = (pw + g.pad) % s;
-            EpNCHW e;
-            e.out = dx; e.act = act; e.dpre = dpre;
-            e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
-            e.sy = s; e.py = ph; e.px = pw; e.J = J; e.off = 0;
-            auto mp = [&](auto &p) {
-                p.w = w; p.Cin = g.Cin; p.stride = s; p.kh0 = kh0; p.kw0 = kw0; p.tlog = tlog;
-            };
-            auto mq = [&](auto &q) {
-                q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; q.ph = ph; q.pw = pw;
-                q.kh0 = kh0; q.kw0 = kw0; q.tlog = tlog;
-            };
-            int rc = launch_igemm<LdDgradW, LdDgradDy, EpNCHW, false>(tc, mp, mq, e, I, J, K, 1,
-                                                                      (K + BK - 1) / BK * BK, nullptr, 0, 0, 0, st);
-            if (rc) return rc;
-        }
-    return MVAE_OK;
+    if (conv_dgrad_small_ok(g) && !g_force_wm) return conv_dgrad_small(dy, w, dx, act, dpre, g, st);
+    if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
+    float *wr = (float *)ws;
+    {
+        const int total = s * s * K * g.Cin;
+        int blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(repack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wr, g.Cout, g.Cin, s, g.pad);
+    }
+    Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
+    const bool vec = (g.Cin % 4 == 0) && aligned16(wr);
+    EpNCHW e;
+    e.out = dx; e.act = act; e.dpre = dpre;
+    e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
+    e.sy = s; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+    auto mp = [&](auto &p) {
+        p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.vec = vec ? 1 : 0; p.cls_stride = (size_t)K * g.Cin;
+    };
+    auto mq = [&](auto &q) { q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; };
+    SplitSink sink = make_sink(nullptr, I, J, false);
+    sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
+    if (s == 2) return launch_igemm<LdRowsMN, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    return launch_igemm<LdRowsMN, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
 // ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----
 int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int flags, void *ws,
                     size_t ws_bytes, hipStream_t st) {
     const int I = g.Cout, J = g.Cin * 16, K = g.B * g.OH * g.OW;
-    TileChoice tc = choose_tile(I, J, 4);
-    SplitPlan sp = plan_splits(I, J, K, tc);
-    const size_t stride = (size_t)I * J;
-    if (sp.splits > 1 && ws_bytes < sp.splits * stride * sizeof(float)) return MVAE_ERR_WS;
-    EpPartial e;
-    e.ws = (float *)ws; e.I = I; e.J = J; e.split_stride = stride;
-    e.direct = sp.splits == 1 ? dw : nullptr; e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+    Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
+    SplitSink sink = make_sink(ws, I, J, false);
+    if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
+    EpRowMajor e;
+    e.out = dw; e.act = nullptr; e.ld = J; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
+    e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = I; e.J = J;
+    e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
     auto mp = [&](auto &p) { p.dy = dy; p.g = g; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.J = J; };
-    int rc = launch_igemm<LdWgradDy, LdWgradX, EpPartial, false>(tc, mp, mq, e, I, J, K, sp.splits, sp.klen,
-                                                                 nullptr, 0, 0, 0, st);
-    if (rc) return rc;
-    if (sp.splits > 1) {
-        const int n = I * J;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
-                           (const float *)ws, dw, n, sp.splits, stride, e.accumulate);
-        return mvae_launch_status();
-    }
-    return MVAE_OK;
+    return launch_igemm<LdWgradDy, LdWgradX, EpRowMajor, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
 }  // namespace
@@ -603,43 +810,55 @@ int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int 
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-MVAE_EXPORT int mvae_abi_version(void) { return 1; }
+MVAE_EXPORT int mvae_abi_version(void) { return 2; }
 
-MVAE_EXPORT size_t mvae_wgrad_ws_bytes(int rows_out, int cols_out, int reduce_len) {
+MVAE_EXPORT void mvae_debug_set_tiling(int wm, int wn, int splits) {
+    g_force_wm = wm; g_force_wn = wn; g_force_splits = splits;
+}
+
+MVAE_EXPORT void mvae_debug_set_kwaves(int kw) { g_force_kw = kw; }
+
+MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len) {
     if (rows_out <= 0 || cols_out <= 0 || reduce_len <= 0) return 0;
-    return wgrad_ws_floats(rows_out, cols_out, reduce_len) * sizeof(float);
+    size_t n = split_ws_floats(rows_out, cols_out, reduce_len);
+    const size_t repack = (size_t)rows_out * cols_out;      // dgrad-form weight repack: Cin x (Cout*16)
+    if (g_force_splits) n = (size_t)g_force_splits * ((size_t)rows_out * cols_out + rows_out);
+    return (n > repack ? n : repack) * sizeof(float);
 }
 
 MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
                                 float *pre, float *act, int ldy, const float *mask, float mask_scale,
-                                int M, int N, int K, mvae_stream_t stream) {
+                                int M, int N, int K, void *ws, size_t ws_bytes, mvae_stream_t stream) {
     if (!x || !w || (!pre && !act) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    TileChoice tc = choose_tile(M, N, 1);
+    Plan pl = make_plan(M, N, K, ws != nullptr);
+    SplitSink sink = make_sink(ws, M, N, false);
+    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = pre; e.act = act; e.ld = ldy; e.bias = bias; e.dpre = nullptr; e.ldp = 0;
     e.mask = mask; e.ldm = N; e.mask_scale = mask_scale; e.I = M; e.J = N; e.accumulate = 0;
     auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0; };
     auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0; };
-    return launch_igemm<LdRowsK, LdRowsK, EpRowMajor, false>(tc, mp, mq, e, M, N, K, 1, (K + BK - 1) / BK * BK,
-                                                             nullptr, 0, 0, 0, st);
+    return launch_igemm<LdRowsK, LdRowsK, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
 }
 
 MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,
                                   const float *pre_in, const float *mask, float mask_scale,
-                                  int M, int N, int K, int flags, mvae_stream_t stream) {
+                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                  mvae_stream_t stream) {
     if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     // D[i = m][j = k] = sum_n dy[m][n] * w[n][k]
-    TileChoice tc = choose_tile(M, K, 1);
+    Plan pl = make_plan(M, K, N, ws != nullptr);
+    SplitSink sink = make_sink(ws, M, K, false);
+    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = dx; e.act = nullptr; e.ld = lddx; e.bias = nullptr; e.dpre = pre_in; e.ldp = K;
     e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
     e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
     auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.vec = (aligned16(dy) && lddy % 4 == 0) ? 1 : 0; };
-    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0; };
-    return launch_igemm<LdRowsK, LdRowsMN, EpRowMajor, false>(tc, mp, mq, e, M, K, N, 1, (N + BK - 1) / BK * BK,
-                                                              nullptr, 0, 0, 0, st);
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0; q.cls_stride = 0; };
+    return launch_igemm<LdRowsK, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
 }
 
 MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db,
@@ -648,37 +867,33 @@ MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int
     if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     // D[i = n][j = k] = sum_m dy[m][n] * x[m][k]
-    TileChoice tc = choose_tile(N, K, 4);
-    SplitPlan sp = plan_splits(N, K, M, tc);
-    const size_t stride = (size_t)N * K + N;          // dw partial followed by db partial
-    if (sp.splits > 1 && (!ws || ws_bytes < sp.splits * stride * sizeof(float))) return MVAE_ERR_WS;
+    Plan pl = make_plan(N, K, M, ws != nullptr, PLAN_LIN_WGRAD);
+    SplitSink sink = make_sink(ws, N, K, db != nullptr);
+    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
-    EpPartial e;
-    e.ws = (float *)ws; e.I = N; e.J = K; e.split_stride = stride;
-    e.direct = sp.splits == 1 ? dw : nullptr; e.accumulate = acc;
-    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.vec = (aligned16(dy) && lddy % 4 == 0) ? 1 : 0; };
-    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0; };
+    EpRowMajor e;
+    e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
+    e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = N; e.J = K; e.accumulate = acc;
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.vec = (aligned16(dy) && lddy % 4 == 0) ? 1 : 0; p.cls_stride = 0; };
+    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0; q.cls_stride = 0; };
     int rc;
     if (db) {
         // row sums of P = dy^T are the bias gradient; partials live right after each dw partial
-        float *rs = sp.splits == 1 ? db : (float *)ws + (size_t)N * K;
-        rc = launch_igemm<LdRowsMN, LdRowsMN, EpPartial, true>(tc, mp, mq, e, N, K, M, sp.splits, sp.klen, rs,
-                                                               stride, N, acc, st);
-    } else {
-        rc = launch_igemm<LdRowsMN, LdRowsMN, EpPartial, false>(tc, mp, mq, e, N, K, M, sp.splits, sp.klen,
-                                                                nullptr, 0, 0, 0, st);
-    }
-    if (rc) return rc;
-    if (sp.splits > 1) {
-        const int n = N * K;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float *)ws, dw,
-                           n, sp.splits, stride, acc);
-        if (db)
+        if (pl.splits == 1) {
+            sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc;
+        } else {
+            sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
+        }
+        rc = launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
+        if (rc) return rc;
+        if (pl.splits > 1) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st,
-                               (const float *)ws + (size_t)N * K, db, N, sp.splits, stride, acc);
-        return mvae_launch_status();
+                               (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
+            return mvae_launch_status();
+        }
+        return MVAE_OK;
     }
-    return MVAE_OK;
+    return launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
 }
 
 MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
@@ -688,10 +903,10 @@ MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, f
 }
 
 MVAE_EXPORT int mvae_conv2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,
-                                     int Cin, int H, int W, int Cout, int stride, int pad,
-                                     mvae_stream_t stream) {
+                                     int Cin, int H, int W, int Cout, int stride, int pad, void *ws,
+                                     size_t ws_bytes, mvae_stream_t stream) {
     if (!dy || !w || !dx || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
-    return conv_dgrad_impl(dy, w, dx, nullptr, pre_in, make_geom(B, Cin, H, W, Cout, stride, pad),
+    return conv_dgrad_impl(dy, w, dx, nullptr, pre_in, make_geom(B, Cin, H, W, Cout, stride, pad), ws, ws_bytes,
                            (hipStream_t)stream);
 }
 
@@ -713,10 +928,11 @@ static inline bool convT_geom(int B, int Cin, int H, int W, int Cout, int stride
 }
 
 MVAE_EXPORT int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
-                                    int H, int W, int Cout, int stride, int pad, mvae_stream_t stream) {
+                                    int H, int W, int Cout, int stride, int pad, void *ws, size_t ws_bytes,
+                                    mvae_stream_t stream) {
     ConvGeom g;
     if (!x || !w || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
-    return conv_dgrad_impl(x, w, pre, act, nullptr, g, (hipStream_t)stream);
+    return conv_dgrad_impl(x, w, pre, act, nullptr, g, ws, ws_bytes, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,

@@ -39,22 +39,32 @@ __global__ __launch_bounds__(256) void embedding_swish_fwd_kernel(const void *id
     }
 }
 
-// dw[c,j] (+)= swish'(w[c,j]) * sum_{r: idx[r]==c} dact[r,j]  -- one thread per (c,j), rows in order:
+// dw[c,j] (+)= swish'(w[c,j]) * sum_{r: idx[r]==c} dact[r,j].  Block = 64 columns x 4 row lanes of
+// class c; each lane sums its rows in order and the 4 partials are added in a fixed order:
 // deterministic (the reference's index_add_ backward is not).
 __global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *idx, int is_float, const float *w,
                                                                   const float *dact, float *dw, int R,
                                                                   int n_classes, int width, int accumulate) {
-    const int j = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (j >= width) return;
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx, c = blockIdx.y;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) {
-        int cr = read_index(idx, is_float, r);
-        cr = min(max(cr, 0), n_classes - 1);
-        if (cr == c) s += dact[(size_t)r * width + j];
+    if (j < width) {
+        const int per = (R + 3) / 4, r0 = ty * per, r1 = min(R, r0 + per);
+        for (int r = r0; r < r1; ++r) {
+            int cr = read_index(idx, is_float, r);
+            cr = min(max(cr, 0), n_classes - 1);
+            if (cr == c) s += dact[(size_t)r * width + j];
+        }
     }
-    const size_t o = (size_t)c * width + j;
-    s *= swish_grad_(w[o]);
-    dw[o] = accumulate ? dw[o] + s : s;
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < width) {
+        s = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+        const size_t o = (size_t)c * width + j;
+        s *= swish_grad_(w[o]);
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
 }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter = (element group, launch offset), key = seed ----
@@ -186,7 +196,7 @@ MVAE_EXPORT int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, cons
                                          float *dw, int R, int n_classes, int width, int flags,
                                          mvae_stream_t stream) {
     if (!idx || !w || !dact || !dw || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
-    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 255) / 256, n_classes), dim3(256), 0,
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes), dim3(256), 0,
                        (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
                        (flags & MVAE_ACCUMULATE) ? 1 : 0);
     return mvae_launch_status();

@@ -4,53 +4,70 @@
 // statistics, so the G `model()` calls the reference issues per train step on the same layer
 // (celeba/train.py:193-195: 3 decoder passes; celeba19/train.py:264-302: 21) run as one launch.
 //
-// Statistics are computed as (count, mean, M2) per slice with a two-pass sum inside the slice
-// (the slice is L2-resident for the second pass) and merged with Chan's formula -- no
-// E[x^2]-E[x]^2 cancellation.  All cross-block reductions go through the caller's workspace in
-// a fixed order: deterministic, no atomics.
+// Work split: block (s, c, g) owns a slice of batch rows of channel c in group g and sweeps each
+// row's HW contiguous floats with float4 loads (lanes along the spatial axis; rows in parallel when
+// HW/4 < 256), no integer division in the loop.  Statistics are (count, mean, M2) per slice
+// with a two-pass sum inside the slice (the slice is L2-resident for the second pass) merged with
+// Chan's formula -- no E[x^2]-E[x]^2 cancellation.  All cross-block reductions go through the
+// caller's workspace in a fixed order: deterministic, no atomics.
 #include "common.h"
 
 namespace {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_SLICES = 64;
+constexpr int BN_SLICE_ELEMS = 8192;
 
-__host__ __device__ inline int bn_slices(int n_per_group) {
-    int s = n_per_group / 4096;
-    if (s < 1) s = 1;
-    if (s > BN_MAX_SLICES) s = BN_MAX_SLICES;
-    return s;
+struct BnShape {
+    int G, B, C, HW, S, n;      // n = B * HW elements per (group, channel); S slices of `rows` batch rows
+    int rows, vec, tx;          // vec: HW % 4 == 0 (float4 path); tx = threads along a row (power of two)
+};
+
+__host__ __device__ inline int bn_max_slices(int n_per_group) { return n_per_group / BN_SLICE_ELEMS + 2; }
+
+// f4(offset) is called with the element offset of each aligned float4 of the slice (vec path),
+// f1(offset) with each scalar element (HW not a multiple of 4, e.g. 5x5 maps and BatchNorm1d).
+template <class F4, class F1>
+__device__ __forceinline__ void bn_slice_loop(const BnShape &sh, int g, int c, int s, F4 f4, F1 f1) {
+    const int b_lo = s * sh.rows, b_hi = min(sh.B, b_lo + sh.rows);
+    if (sh.vec) {
+        const int hw4 = sh.HW >> 2, tx = threadIdx.x & (sh.tx - 1), ty = threadIdx.x / sh.tx;
+        const int ny = BN_THREADS / sh.tx;
+        for (int b = b_lo + ty; b < b_hi; b += ny) {
+            const size_t base = ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW;
+            for (int q = tx; q < hw4; q += sh.tx) f4(base + 4 * (size_t)q);
+        }
+    } else {
+        const int n_lo = b_lo * sh.HW, n_hi = b_hi * sh.HW;
+        for (int n = n_lo + threadIdx.x; n < n_hi; n += BN_THREADS) {
+            const int b = n / sh.HW, sp = n - b * sh.HW;
+            f1(((size_t)(g * sh.B + b) * sh.C + c) * sh.HW + sp);
+        }
+    }
 }
 
-struct BnShape { int G, B, C, HW, S, n; };  // n = B * HW elements per (group, channel)
-
-__device__ __forceinline__ size_t bn_addr(const BnShape &sh, int g, int c, int n) {
-    const int b = n / sh.HW, sp = n - b * sh.HW;
-    return ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW + sp;
-}
-
-__device__ __forceinline__ void slice_range(const BnShape &sh, int s, int *lo, int *hi) {
-    const int len = (sh.n + sh.S - 1) / sh.S;
-    *lo = s * len;
-    *hi = min(sh.n, *lo + len);
-}
+__device__ __forceinline__ float4 ld4(const float *p, size_t o) { return *reinterpret_cast<const float4 *>(p + o); }
+__device__ __forceinline__ void st4(float *p, size_t o, float4 v) { *reinterpret_cast<float4 *>(p + o) = v; }
 
 // ws[((g*C + c)*S + s)*3 + {0,1,2}] = (count, mean, M2) of the slice
 __global__ __launch_bounds__(BN_THREADS) void bn_partial_stats_kernel(const float *x, float *ws, BnShape sh) {
     __shared__ float red[16];
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
-    int lo, hi;
-    slice_range(sh, s, &lo, &hi);
     float sum = 0.f;
-    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) sum += x[bn_addr(sh, g, c, n)];
+    bn_slice_loop(sh, g, c, s,
+                  [&](size_t o) { const float4 v = ld4(x, o); sum += (v.x + v.y) + (v.z + v.w); },
+                  [&](size_t o) { sum += x[o]; });
     sum = block_sum(sum, red);
-    const float cnt = (float)max(hi - lo, 0);
+    const int b_lo = s * sh.rows, b_hi = min(sh.B, b_lo + sh.rows);
+    const float cnt = (float)(max(b_hi - b_lo, 0) * sh.HW);
     const float mean = cnt > 0.f ? sum / cnt : 0.f;
     float m2 = 0.f;
-    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
-        const float d = x[bn_addr(sh, g, c, n)] - mean;
-        m2 += d * d;
-    }
+    bn_slice_loop(sh, g, c, s,
+                  [&](size_t o) {
+                      const float4 v = ld4(x, o);
+                      const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+                      m2 += (a * a + b * b) + (cc * cc + d * d);
+                  },
+                  [&](size_t o) { const float d = x[o] - mean; m2 += d * d; });
     m2 = block_sum(m2, red);
     if (threadIdx.x == 0) {
         float *o = ws + ((size_t)(g * sh.C + c) * sh.S + s) * 3;
@@ -74,7 +91,7 @@ __device__ inline void bn_merge(const float *ws, const BnShape &sh, int g, int c
     *var = n > 0.f ? m2 / n : 0.f;
 }
 
-// y = swish?(gamma * (x - mean) * invstd + beta); also saves mean/invstd and advances the
+// y = swish?(gamma * ((x - mean) * invstd) + beta); also saves mean/invstd and advances the
 // running statistics (one block per channel does that, sequentially over groups).
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x, const float *gamma,
                                                                   const float *beta, float *y, const float *ws,
@@ -107,13 +124,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x
         }
     }
     const float ga = gamma[c], be = beta[c];
-    int lo, hi;
-    slice_range(sh, s, &lo, &hi);
-    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
-        const size_t a = bn_addr(sh, g, c, n);
-        const float h = ga * ((x[a] - mean) * invstd) + be;   // same expression as the backward's
-        y[a] = swish ? swishf_(h) : h;
-    }
+    auto one = [&](float v) {
+        const float h = ga * ((v - mean) * invstd) + be;   // same expression as the backward's
+        return swish ? swishf_(h) : h;
+    };
+    bn_slice_loop(sh, g, c, s,
+                  [&](size_t o) {
+                      const float4 v = ld4(x, o);
+                      st4(y, o, make_float4(one(v.x), one(v.y), one(v.z), one(v.w)));
+                  },
+                  [&](size_t o) { y[o] = one(x[o]); });
 }
 
 // ws[((g*C + c)*S + s)*2 + {0,1}] = (sum dh, sum dh * xhat), dh = dy * swish'(h)
@@ -126,17 +146,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
     const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
     const float ga = gamma[c], be = beta[c];
-    int lo, hi;
-    slice_range(sh, s, &lo, &hi);
     float s1 = 0.f, s2 = 0.f;
-    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
-        const size_t a = bn_addr(sh, g, c, n);
-        const float xh = (x[a] - mean) * invstd;
-        float d = dy[a];
+    auto one = [&](float xv, float d) {
+        const float xh = (xv - mean) * invstd;
         if (swish) d *= swish_grad_(ga * xh + be);
         s1 += d;
         s2 += d * xh;
-    }
+    };
+    bn_slice_loop(sh, g, c, s,
+                  [&](size_t o) {
+                      const float4 xv = ld4(x, o), dv = ld4(dy, o);
+                      one(xv.x, dv.x); one(xv.y, dv.y); one(xv.z, dv.z); one(xv.w, dv.w);
+                  },
+                  [&](size_t o) { one(x[o], dy[o]); });
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
@@ -169,15 +191,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *d
     const float ga = gamma[c], be = beta[c];
     const float inv_n = 1.f / (float)sh.n;
     const float m1 = s1 * inv_n, m2 = s2 * inv_n, k = ga * invstd;
-    int lo, hi;
-    slice_range(sh, s, &lo, &hi);
-    for (int n = lo + threadIdx.x; n < hi; n += BN_THREADS) {
-        const size_t a = bn_addr(sh, g, c, n);
-        const float xh = (x[a] - mean) * invstd;
-        float d = dy[a];
+    auto one = [&](float xv, float d) {
+        const float xh = (xv - mean) * invstd;
         if (swish) d *= swish_grad_(ga * xh + be);
-        dx[a] = k * (d - m1 - xh * m2);
-    }
+        return k * (d - m1 - xh * m2);
+    };
+    bn_slice_loop(sh, g, c, s,
+                  [&](size_t o) {
+                      const float4 xv = ld4(x, o), dv = ld4(dy, o);
+                      st4(dx, o, make_float4(one(xv.x, dv.x), one(xv.y, dv.y), one(xv.z, dv.z), one(xv.w, dv.w)));
+                  },
+                  [&](size_t o) { dx[o] = one(x[o], dy[o]); });
 }
 
 __global__ __launch_bounds__(256) void bn_eval_kernel(const float *x, const float *gamma, const float *beta,
@@ -190,18 +214,26 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float *x, const floa
     }
 }
 
-inline bool bn_shape(int G, int B, int C, int HW, BnShape *sh) {
+inline bool bn_shape(int G, int B, int C, int HW, const void *a, const void *b, const void *c, BnShape *sh) {
     if (G <= 0 || B <= 0 || C <= 0 || HW <= 0) return false;
     if ((long)G * B * C * HW >= (1L << 40) || (long)B * HW >= (1L << 31)) return false;
-    sh->G = G; sh->B = B; sh->C = C; sh->HW = HW; sh->n = B * HW; sh->S = bn_slices(B * HW);
-    return true;
+    sh->G = G; sh->B = B; sh->C = C; sh->HW = HW; sh->n = B * HW;
+    sh->rows = BN_SLICE_ELEMS / HW;
+    if (sh->rows < 1) sh->rows = 1;
+    if (sh->rows > B) sh->rows = B;
+    sh->S = (B + sh->rows - 1) / sh->rows;
+    sh->vec = (HW % 4 == 0) && aligned16(a) && (!b || aligned16(b)) && (!c || aligned16(c));
+    int tx = 1;
+    while (tx * 2 <= (HW >> 2) && tx * 2 <= BN_THREADS) tx *= 2;
+    sh->tx = tx;
+    return sh->S <= bn_max_slices(sh->n);
 }
 
 }  // namespace
 
 MVAE_EXPORT size_t mvae_bn_ws_bytes(int G, int C, int n_per_group) {
     if (G <= 0 || C <= 0 || n_per_group <= 0) return 0;
-    return (size_t)G * C * bn_slices(n_per_group) * 3 * sizeof(float);
+    return (size_t)G * C * bn_max_slices(n_per_group) * 3 * sizeof(float);
 }
 
 MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, float *y,
@@ -210,7 +242,8 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
                                   int n_updates, const int *n_updates_dev, int flags, void *ws,
                                   size_t ws_bytes, mvae_stream_t stream) {
     BnShape sh;
-    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, &sh)) return MVAE_ERR_ARG;
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, x, y, nullptr, &sh))
+        return MVAE_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
     if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     hipStream_t st = (hipStream_t)stream;
@@ -228,7 +261,7 @@ MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *
                                   size_t ws_bytes, mvae_stream_t stream) {
     BnShape sh;
     if (!dy || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta ||
-        !bn_shape(G, B, C, HW, &sh))
+        !bn_shape(G, B, C, HW, x, dy, dx, &sh))
         return MVAE_ERR_ARG;
     if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     hipStream_t st = (hipStream_t)stream;

@@ -124,9 +124,14 @@ class _StepBase(object):
         snap = _snapshot(self.model, optimizer, self.counter)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
+        bns = [m for m in self.model.modules() if isinstance(m, L._BatchNormMixin)]
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for it in range(warmup):
+                before = [m._nbt_pending for m in bns]
                 self._body_a(); self._phase_b(); optimizer.step()
+                # graph replays skip the host code that counts BatchNorm calls: remember the
+                # per-step increments of num_batches_tracked and re-apply them in replay()
+                self._bn_inc = [(m, m._nbt_pending - b) for m, b in zip(bns, before)]
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(dev)
         if comm is None:
@@ -154,7 +159,12 @@ class _StepBase(object):
         self.draw_noise()
         self._phase_a(self.static_image, self.static_label)
 
+    def _bump_bn_counters(self):
+        for m, inc in self._bn_inc:
+            m._nbt_pending += inc
+
     def replay(self, image, label, annealing_factor):
+        self._bump_bn_counters()
         self.static_image.copy_(image, non_blocking=True)
         self.static_label.copy_(label, non_blocking=True)
         self.set_coefficients(annealing_factor)
@@ -485,6 +495,13 @@ class Celeba19Step(_StepBase):
 
     def terms_in_reference_order(self, elbo):
         return elbo
+
+    def _bump_bn_counters(self):
+        # the image-encoder trunk's BatchNorms advance once per term that contains the image,
+        # which varies with the sampled subsets; everything else is static
+        trunk = set(id(op.mod) for op in self.trunk if op.kind == 'bn')
+        for m, inc in self._bn_inc:
+            m._nbt_pending += self.n_img_present if id(m) in trunk else inc
 
     # ------------------------------------------------------------------ the step
     def _phase_a(self, image, attrs):

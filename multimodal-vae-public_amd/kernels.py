@@ -63,24 +63,26 @@ def linear_fwd(x, w, bias, pre=None, act=None, mask=None, mask_scale=1.0, ldx=No
     ldx = ldx if ldx is not None else x.stride(0)
     out = pre if pre is not None else act
     ldy = ldy if ldy is not None else out.stride(0)
+    ws, wsb = _ws_args(_lib.lib().mvae_gemm_ws_bytes(M, N, K), x.device)
     check(_lib.lib().mvae_linear_fwd(_ptr(x), ldx, _ptr(w), _ptr(bias), _ptr(pre), _ptr(act), ldy,
-                                     _ptr(mask), mask_scale, M, N, K, _stream()), 'mvae_linear_fwd')
+                                     _ptr(mask), mask_scale, M, N, K, ws, wsb, _stream()), 'mvae_linear_fwd')
 
 
 def linear_dgrad(dy, w, dx, pre_in=None, mask=None, mask_scale=1.0, accumulate=False):
     _need_gpu(dy, w, dx, pre_in, mask)
     M, N = dy.shape
     K = w.shape[1]
+    ws, wsb = _ws_args(_lib.lib().mvae_gemm_ws_bytes(M, K, N), dy.device)
     check(_lib.lib().mvae_linear_dgrad(_ptr(dy), dy.stride(0), _ptr(w), _ptr(dx), dx.stride(0),
                                        _ptr(pre_in), _ptr(mask), mask_scale, M, N, K,
-                                       ACCUMULATE if accumulate else 0, _stream()), 'mvae_linear_dgrad')
+                                       ACCUMULATE if accumulate else 0, ws, wsb, _stream()), 'mvae_linear_dgrad')
 
 
 def linear_wgrad(dy, x, dw, db=None, accumulate=False):
     _need_gpu(dy, x, dw, db)
     M, N = dy.shape
     K = x.shape[1]
-    nbytes = _lib.lib().mvae_wgrad_ws_bytes(N, K, M)
+    nbytes = _lib.lib().mvae_gemm_ws_bytes(N, K, M)
     ws, wsb = _ws_args(nbytes, dy.device)
     check(_lib.lib().mvae_linear_wgrad(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), _ptr(db),
                                        M, N, K, ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
@@ -88,9 +90,14 @@ def linear_wgrad(dy, x, dw, db=None, accumulate=False):
 
 
 # ---------------------------------------------------------------------------- Conv 4x4
-def _conv_call(name, a, b, c, d, B, Cin, H, W, Cout, stride, pad):
-    check(getattr(_lib.lib(), name)(_ptr(a), _ptr(b), _ptr(c), _ptr(d), B, Cin, H, W, Cout, stride, pad,
-                                    _stream()), name)
+def _conv_call(name, a, b, c, d, B, Cin, H, W, Cout, stride, pad, repack=False):
+    if repack:      # dgrad-form launches repack the weights (Cout*Cin*16 floats) into scratch first
+        ws, wsb = _ws_args(Cout * Cin * 16 * 4, a.device)
+        check(getattr(_lib.lib(), name)(_ptr(a), _ptr(b), _ptr(c), _ptr(d), B, Cin, H, W, Cout, stride, pad,
+                                        ws, wsb, _stream()), name)
+    else:
+        check(getattr(_lib.lib(), name)(_ptr(a), _ptr(b), _ptr(c), _ptr(d), B, Cin, H, W, Cout, stride, pad,
+                                        _stream()), name)
 
 
 def conv2d_fwd(x, w, pre, act, stride, pad):
@@ -102,14 +109,14 @@ def conv2d_fwd(x, w, pre, act, stride, pad):
 def conv2d_dgrad(dy, w, dx, pre_in, stride, pad):
     _need_gpu(dy, w, dx, pre_in); _f32c(dy, w, dx, pre_in)
     B, Cin, H, W = dx.shape
-    _conv_call('mvae_conv2d_k4_dgrad', dy, w, dx, pre_in, B, Cin, H, W, w.shape[0], stride, pad)
+    _conv_call('mvae_conv2d_k4_dgrad', dy, w, dx, pre_in, B, Cin, H, W, w.shape[0], stride, pad, repack=True)
 
 
 def conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False):
     _need_gpu(dy, x, dw); _f32c(dy, x, dw)
     B, Cin, H, W = x.shape
     Cout = dw.shape[0]
-    nbytes = _lib.lib().mvae_wgrad_ws_bytes(Cout, Cin * 16, B * dy.shape[2] * dy.shape[3])
+    nbytes = _lib.lib().mvae_gemm_ws_bytes(Cout, Cin * 16, B * dy.shape[2] * dy.shape[3])
     ws, wsb = _ws_args(nbytes, dy.device)
     check(_lib.lib().mvae_conv2d_k4_wgrad(_ptr(dy), _ptr(x), _ptr(dw), B, Cin, H, W, Cout, stride, pad,
                                           ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
@@ -120,7 +127,7 @@ def convT2d_fwd(x, w, pre, act, stride, pad):
     """x[B,Cin,H,W], w[Cin,Cout,4,4] -> [B,Cout,(H-1)s-2p+4, ...]"""
     _need_gpu(x, w, pre, act); _f32c(x, w, pre, act)
     B, Cin, H, W = x.shape
-    _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad)
+    _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad, repack=True)
 
 
 def convT2d_dgrad(dy, w, dx, pre_in, stride, pad):
@@ -133,7 +140,7 @@ def convT2d_wgrad(dy, x, dw, stride, pad, accumulate=False):
     _need_gpu(dy, x, dw); _f32c(dy, x, dw)
     B, Cin, H, W = x.shape
     Cout = dw.shape[1]
-    nbytes = _lib.lib().mvae_wgrad_ws_bytes(Cin, Cout * 16, B * H * W)
+    nbytes = _lib.lib().mvae_gemm_ws_bytes(Cin, Cout * 16, B * H * W)
     ws, wsb = _ws_args(nbytes, dy.device)
     check(_lib.lib().mvae_convT2d_k4_wgrad(_ptr(dy), _ptr(x), _ptr(dw), B, Cin, H, W, Cout, stride, pad,
                                            ACCUMULATE if accumulate else 0, ws, wsb, _stream()),

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
-    assert handle.mvae_abi_version() == 1
+    assert handle.mvae_abi_version() == 2
 
 
 def test_binding_table_matches_header():
@@ -37,15 +37,15 @@ def test_binding_table_matches_header():
 
 def test_workspace_queries_are_pure_host_calls():
     lib = _lib.lib()
-    assert lib.mvae_wgrad_ws_bytes(512, 784, 1024) > 0
-    assert lib.mvae_wgrad_ws_bytes(0, 784, 1024) == 0
-    assert lib.mvae_bn_ws_bytes(3, 64, 256 * 256) == 3 * 64 * 16 * 3 * 4
+    assert lib.mvae_gemm_ws_bytes(512, 784, 1024) > 0
+    assert lib.mvae_gemm_ws_bytes(0, 784, 1024) == 0
+    assert lib.mvae_bn_ws_bytes(3, 64, 256 * 256) == 3 * 64 * 10 * 3 * 4
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu():
     lib = _lib.lib()
     # null pointers / bad shapes are rejected on the host before any launch
-    assert lib.mvae_linear_fwd(None, 4, None, None, None, None, 4, None, 1.0, 4, 4, 4, None) == -1
+    assert lib.mvae_linear_fwd(None, 4, None, None, None, None, 4, None, 1.0, 4, 4, 4, None, 0, None) == -1
     assert lib.mvae_conv2d_k4_fwd(None, None, None, None, 1, 1, 8, 8, 1, 3, 1, None) == -1
     assert lib.mvae_fill(None, 4, 0.0, None) == -1
 

@@ -1,0 +1,116 @@
+"""GPU parity of the 19-modality step (celeba19/train.py:236-316): fused engine vs the golden
+fixture captured from the real reference and vs the live oracle; reference-surface calls."""
+import numpy as np
+import pytest
+import torch
+
+import mvae_amd
+from mvae_amd.engine import Celeba19Step, sample_subsets
+from oracle import models as OM, steps as OS
+from test_engine_gpu import build_pair, check_bn_vs, check_grads_vs_golden, check_grads_vs_oracle
+from util import assert_close, golden_noise, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_fused_step_matches_reference_golden(golden_dir):
+    fx, meta = load_golden(golden_dir, 'celeba19_b4')
+    _, model, d = build_pair('celeba19', meta['weight_seed'])
+    B = meta['batch']
+    image, attrs = OS.synthetic_batch('celeba19', B, meta['input_seed'])
+    combos = fx['combos'].astype(bool)
+    T = 20 + meta['approx_m']
+    eng = Celeba19Step(model, B, meta['lambda_image'], meta['lambda_label'], approx_m=meta['approx_m'])
+    elbo = eng.step(image.to(DEV), attrs.to(DEV), meta['beta'], noise=golden_noise(fx, T), combos=combos).cpu()
+    assert_close(elbo[:T], fx['terms'], 'ELBO terms')
+    assert_close(elbo[T].item(), fx['total'], 'total loss')
+    mu, lv, z = eng.last_latents
+    for c in (0, 1, 2, T - 1):
+        assert_close(mu[c], fx['mu%d' % c], 'mu%d' % c)
+        assert_close(lv[c], fx['logvar%d' % c], 'logvar%d' % c)
+        assert_close(z[c], fx['z%d' % c], 'z%d' % c)
+    check_grads_vs_golden(model, fx)
+    check_bn_vs(model, {k[3:]: v for k, v in fx.items() if k.startswith('bn/')})
+
+
+@pytest.mark.parametrize('approx_m,batch,with_image', [(1, 6, True), (1, 6, False), (3, 4, None)])
+def test_fused_step_matches_live_oracle(approx_m, batch, with_image):
+    oracle, model, d = build_pair('celeba19', weight_seed=23)
+    image, attrs = OS.synthetic_batch('celeba19', batch, seed=81)
+    rng = np.random.RandomState(5 + approx_m)
+    combos = sample_subsets(rng, 19, approx_m)
+    if with_image is not None:
+        combos[:, 0] = with_image
+        if combos[0].sum() < 2:
+            combos[0, 1:3] = True
+    terms = OS.celeba19_terms(combos)
+    torch.manual_seed(9)
+    noise = OS.draw_celeba19_noise(batch, d, terms)
+    lam_i, lam_a, beta = 1.0, 10.0, 0.3
+    total, elbos, lat = OS.celeba19_step(oracle, image, attrs, terms, noise, lam_i, lam_a, beta)
+    total.backward()
+    eng = Celeba19Step(model, batch, lam_i, lam_a, approx_m=approx_m)
+    elbo = eng.step(image.to(DEV), attrs.to(DEV), beta, noise=noise, combos=combos).cpu()
+    T = len(terms)
+    assert_close(elbo[:T], torch.stack(elbos).detach(), 'ELBO terms')
+    assert_close(elbo[T], total.detach(), 'total')
+    worst = check_grads_vs_oracle(model, oracle)
+    check_bn_vs(model, oracle.state_dict())
+    print('celeba19 M=%d worst gradient rel err %.2e' % (approx_m, worst))
+
+
+def test_module_surface_two_terms():
+    """model(image, attrs) + elbo_loss on lists, as celeba19/train.py:264-283 calls them."""
+    import mvae_amd.functional as MF
+    from oracle import functional as OF
+    oracle, model, d = build_pair('celeba19', weight_seed=29)
+    B = 5
+    image, attrs2d = OS.synthetic_batch('celeba19', B, seed=83)
+    attrs = [attrs2d[:, i] for i in range(18)]
+    g = torch.Generator().manual_seed(3)
+    eps = [torch.randn(B, d, generator=g) for _ in range(2)]
+    mask = (torch.rand(B, 512, generator=g) < 0.9).float()
+    ri, ra, mu, lv, _ = oracle(image, attrs, eps=eps[0], dropout_mask=mask)
+    e1 = OF.elbo_loss_multi([ri] + ra, [image] + attrs, mu, lv, 1.0, 10.0, 0.5)
+    only3 = [attrs[k] if k == 3 else None for k in range(18)]
+    _, ra2, mu2, lv2, _ = oracle(None, only3, eps=eps[1])
+    e2 = OF.elbo_loss_multi([ra2[3]], [attrs[3]], mu2, lv2, annealing_factor=0.5)
+    (e1 + e2).backward()
+
+    img = image.to(DEV); at = [a.to(DEV) for a in attrs]
+    model.zero_grad()
+    hi, ha, hmu, hlv = model(img, at, eps=eps[0].to(DEV), dropout_mask=mask.to(DEV))
+    h1 = MF.elbo_loss_multi([hi] + ha, [img] + at, hmu, hlv, lambda_image=1.0, lambda_attrs=10.0,
+                            annealing_factor=0.5)
+    _, ha2, hmu2, hlv2 = model(attrs=[at[k] if k == 3 else None for k in range(18)], eps=eps[1].to(DEV))
+    h2 = MF.elbo_loss_multi([ha2[3]], [at[3]], hmu2, hlv2, annealing_factor=0.5)
+    (h1 + h2).backward()
+    assert_close(torch.stack([h1, h2]).detach(), torch.stack([e1, e2]).detach(), 'ELBO terms')
+    assert_close(hmu, mu.detach(), 'mu')
+    og = dict(oracle.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in og.values() if p.grad is not None)
+    for name, p in model.named_parameters():
+        ref = og[name].grad
+        if ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, name
+            continue
+        scale = max(ref.abs().max().item(), 1e-2 * gmax)
+        err = (p.grad.cpu() - ref).abs().max().item() / scale
+        assert err <= 1e-4, 'grad %s: %.3e' % (name, err)
+
+
+def test_graph_replay_with_changing_subsets():
+    from mvae_amd.optim import FusedAdam
+    _, model, d = build_pair('celeba19', weight_seed=31)
+    B = 4
+    eng = Celeba19Step(model, B, 1.0, 10.0, approx_m=1)
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    image, attrs = OS.synthetic_batch('celeba19', B, seed=85)
+    eng.capture(opt, image.shape[1:], attrs)
+    before = model.arena.flat.clone()
+    losses = []
+    for i in range(3):
+        losses.append(eng.replay(image.to(DEV), attrs.to(DEV), 0.5)[-1].item())
+    assert all(np.isfinite(losses))
+    assert not torch.equal(before, model.arena.flat)

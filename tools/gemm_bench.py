@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the GEMM-shaped launches at the shapes of the bench workloads, for the
+automatic tile/split plan and for forced tilings (mvae_debug_set_tiling).  Tuning aid:
+
+    python tools/gemm_bench.py            # celeba B=256 + mnist B=512 shapes
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import mvae_amd  # noqa: E402
+from mvae_amd import _lib, kernels as K  # noqa: E402
+
+DEV = 'cuda'
+PEAK = 157.3
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def r(*shape):
+    return torch.randn(*shape, device=DEV)
+
+
+def conv_cases(B, Cin, H, Cout, s, p, tag):
+    OH = (H + 2 * p - 4) // s + 1
+    x, w = r(B, Cin, H, H), r(Cout, Cin, 4, 4)
+    y, dy, dx, dw = torch.empty(B, Cout, OH, OH, device=DEV), r(B, Cout, OH, OH), torch.empty_like(x), torch.empty_like(w)
+    fl = 2.0 * B * Cout * OH * OH * Cin * 16
+    return [('%s conv fwd' % tag, fl, lambda: K.conv2d_fwd(x, w, y, None, s, p)),
+            ('%s conv dgrad' % tag, fl, lambda: K.conv2d_dgrad(dy, w, dx, None, s, p)),
+            ('%s conv wgrad' % tag, fl, lambda: K.conv2d_wgrad(dy, x, dw, s, p))]
+
+
+def convT_cases(B, Cin, H, Cout, s, p, tag):
+    OH = (H - 1) * s - 2 * p + 4
+    x, w = r(B, Cin, H, H), r(Cin, Cout, 4, 4)
+    y, dy, dx, dw = torch.empty(B, Cout, OH, OH, device=DEV), r(B, Cout, OH, OH), torch.empty_like(x), torch.empty_like(w)
+    fl = 2.0 * B * Cin * H * H * Cout * 16
+    return [('%s convT fwd' % tag, fl, lambda: K.convT2d_fwd(x, w, y, None, s, p)),
+            ('%s convT dgrad' % tag, fl, lambda: K.convT2d_dgrad(dy, w, dx, None, s, p)),
+            ('%s convT wgrad' % tag, fl, lambda: K.convT2d_wgrad(dy, x, dw, s, p))]
+
+
+def lin_cases(M, N, Kd, tag):
+    x, w, b = r(M, Kd), r(N, Kd), r(N)
+    pre, act, dy, dx, dw, db = (torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV), r(M, N),
+                                torch.empty(M, Kd, device=DEV), torch.empty(N, Kd, device=DEV),
+                                torch.empty(N, device=DEV))
+    fl = 2.0 * M * N * Kd
+    return [('%s lin fwd' % tag, fl, lambda: K.linear_fwd(x, w, b, pre, act)),
+            ('%s lin dgrad' % tag, fl, lambda: K.linear_dgrad(dy, w, dx)),
+            ('%s lin wgrad' % tag, fl, lambda: K.linear_wgrad(dy, x, dw, db))]
+
+
+def main():
+    cases = []
+    B = 256
+    cases += conv_cases(B, 3, 64, 32, 2, 1, 'enc1 3->32 64x64')
+    cases += conv_cases(B, 32, 32, 64, 2, 1, 'enc2 32->64 32x32')
+    cases += conv_cases(B, 64, 16, 128, 2, 1, 'enc3 64->128 16x16')
+    cases += conv_cases(B, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1')
+    cases += convT_cases(2 * B, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1')
+    cases += convT_cases(2 * B, 128, 8, 64, 2, 1, 'dec2 128->64 8x8')
+    cases += convT_cases(2 * B, 64, 16, 32, 2, 1, 'dec3 64->32 16x16')
+    cases += convT_cases(2 * B, 32, 32, 3, 2, 1, 'dec4 32->3 32x32')
+    cases += lin_cases(B, 512, 6400, 'celeba 6400->512 M256')
+    cases += lin_cases(2 * B, 6400, 100, 'celeba 100->6400 M512')
+    cases += lin_cases(3 * B, 512, 512, 'celeba attr 512->512 M768')
+    cases += lin_cases(1024, 512, 512, 'mnist 512->512 M1024')
+    cases += lin_cases(512, 512, 784, 'mnist 784->512 M512')
+    cases += lin_cases(1024, 784, 512, 'mnist 512->784 M1024')
+    cases += lin_cases(512, 128, 512, 'mnist heads 512->128 M512')
+    lib = _lib.lib()
+    # (label, (wm, wn, splits), kwaves)
+    configs = [('auto', (0, 0, 0), 0), ('64x64 kw1', (1, 1, 0), 1), ('64x64 s1kw1', (1, 1, 1), 1),
+               ('s1 kw2', (1, 1, 1), 2), ('s1 kw4', (1, 1, 1), 4), ('s2 kw4', (1, 1, 2), 4),
+               ('s4 kw1', (1, 1, 4), 1), ('128x128', (2, 2, 0), 1), ('64x128', (1, 2, 0), 1)]
+    print('%-34s %8s | ' % ('op', 'GFLOP') + ' '.join('%11s' % c[0] for c in configs) + '   (TFLOP/s; us for auto)')
+    tot_auto = 0.0
+    for name, fl, fn in cases:
+        row = []
+        for cname, (wm, wn, sp), kw in configs:
+            lib.mvae_debug_set_tiling(wm, wn, sp)
+            lib.mvae_debug_set_kwaves(kw)
+            try:
+                ms = timeit(fn)
+                row.append(fl / (ms * 1e-3) / 1e12)
+                if cname == 'auto':
+                    t_auto = ms
+            except RuntimeError:
+                row.append(float('nan'))
+        lib.mvae_debug_set_tiling(0, 0, 0)
+        lib.mvae_debug_set_kwaves(0)
+        tot_auto += t_auto
+        print('%-34s %8.2f | ' % (name, fl / 1e9) + ' '.join('%11.1f' % v for v in row) + '   %8.1f us' % (t_auto * 1e3))
+    print('sum of auto times: %.3f ms' % tot_auto)
+
+
+if __name__ == '__main__':
+    main()
