@@ -36,13 +36,21 @@ constexpr int NTHREADS = 256;
 // store(lds, t, regs) registers -> the LDS image [BK][TILE + LPAD].
 // ------------------------------------------------------------------------------------------
 
+// All loads below are UNCONDITIONAL from clamped (always legal) addresses and the out-of-range lanes
+// are zeroed by MULTIPLYING with a 0/1 mask.  A load under a branch -- and hipcc turns
+// `ok ? load : 0` and even `load; if (!ok) x = 0` into one -- makes it drain the memory queue
+// (s_waitcnt vmcnt(0)) after every load, which serialises the two-tile prefetch; the multiply keeps
+// the load in straight-line code (x * 0.f cannot be folded without fast-math).
+__device__ __forceinline__ float mask0(bool ok) { return ok ? 1.f : 0.f; }
+
 // S[r * ld + k]: reduction axis contiguous (x and w of Linear fwd, dy of dgrad, conv weights).
-template <int TILE_>
-struct LdRowsK {
+// VEC: base 16-byte aligned, ld % 4 == 0 and Klen % 4 == 0 (float4 loads never straddle the end).
+template <int TILE_, bool VEC>
+struct LdRowsKT {
     static constexpr int TILE = TILE_;
     static constexpr int NV = TILE * BK / 4 / NTHREADS;
-    struct Regs { float4 v[NV]; };
-    const float *src; int ld; int R; int vec;
+    struct Regs { float4 v[NV]; float4 m[NV]; };      // raw data + 0/1 masks (applied when staged)
+    const float *src; int ld; int R; int Klen;
     int r0;
     __device__ void init(int tile0, int, int) { r0 = tile0; }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
@@ -50,17 +58,18 @@ struct LdRowsK {
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
             const int r = r0 + f / (BK / 4), k = k0 + (f % (BK / 4)) * 4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R) {
-                const float *p = src + (size_t)r * ld + k;
-                if (vec && k + 3 < kend) {
-                    x = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    if (k < kend) x.x = p[0];
-                    if (k + 1 < kend) x.y = p[1];
-                    if (k + 2 < kend) x.z = p[2];
-                    if (k + 3 < kend) x.w = p[3];
-                }
+            const float *row = src + (size_t)min(r, R - 1) * ld;
+            float4 x;
+            if (VEC) {
+                x = *reinterpret_cast<const float4 *>(row + min(k, Klen - 4));
+                const float m = mask0(r < R && k < kend);
+                rg.m[v] = make_float4(m, m, m, m);
+            } else {
+                x.x = row[min(k, Klen - 1)];     x.y = row[min(k + 1, Klen - 1)];
+                x.z = row[min(k + 2, Klen - 1)]; x.w = row[min(k + 3, Klen - 1)];
+                const bool rin = r < R;
+                rg.m[v] = make_float4(mask0(rin && k < kend), mask0(rin && k + 1 < kend),
+                                      mask0(rin && k + 2 < kend), mask0(rin && k + 3 < kend));
             }
             rg.v[v] = x;
         }
@@ -70,20 +79,23 @@ struct LdRowsK {
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
             const int r = f / (BK / 4), kc = (f % (BK / 4)) * 4;
-            L[kc + 0][r] = rg.v[v].x; L[kc + 1][r] = rg.v[v].y;
-            L[kc + 2][r] = rg.v[v].z; L[kc + 3][r] = rg.v[v].w;
+            L[kc + 0][r] = rg.v[v].x * rg.m[v].x; L[kc + 1][r] = rg.v[v].y * rg.m[v].y;
+            L[kc + 2][r] = rg.v[v].z * rg.m[v].z; L[kc + 3][r] = rg.v[v].w * rg.m[v].w;
         }
     }
 };
+template <int T> using LdRowsK = LdRowsKT<T, true>;
+template <int T> using LdRowsKS = LdRowsKT<T, false>;
 
 // S[k * ld + r]: non-reduced axis contiguous (w of dgrad, dy and x of wgrad, repacked conv weights).
-template <int TILE_>
-struct LdRowsMN {
+// VEC: base 16-byte aligned, ld % 4 == 0 and R % 4 == 0.
+template <int TILE_, bool VEC>
+struct LdRowsMNT {
     static constexpr int TILE = TILE_;
     static constexpr int NV = TILE * BK / 4 / NTHREADS;
     static constexpr int V4 = TILE / 4;     // float4 per k row
-    struct Regs { float4 v[NV]; };
-    const float *src; int ld; int R; int vec; size_t cls_stride;   // cls_stride: per-class source offset
+    struct Regs { float4 v[NV]; float4 m[NV]; };
+    const float *src; int ld; int R; int Klen; size_t cls_stride;   // cls_stride: per-class source offset
     int r0;
     __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
@@ -91,17 +103,18 @@ struct LdRowsMN {
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
             const int k = k0 + f / V4, r = r0 + (f % V4) * 4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < kend) {
-                const float *p = src + (size_t)k * ld + r;
-                if (vec && r + 3 < R) {
-                    x = *reinterpret_cast<const float4 *>(p);
-                } else {
-                    if (r < R) x.x = p[0];
-                    if (r + 1 < R) x.y = p[1];
-                    if (r + 2 < R) x.z = p[2];
-                    if (r + 3 < R) x.w = p[3];
-                }
+            const float *row = src + (size_t)min(k, Klen - 1) * ld;
+            float4 x;
+            if (VEC) {
+                x = *reinterpret_cast<const float4 *>(row + min(r, R - 4));
+                const float m = mask0(k < kend && r < R);
+                rg.m[v] = make_float4(m, m, m, m);
+            } else {
+                x.x = row[min(r, R - 1)];     x.y = row[min(r + 1, R - 1)];
+                x.z = row[min(r + 2, R - 1)]; x.w = row[min(r + 3, R - 1)];
+                const bool kin = k < kend;
+                rg.m[v] = make_float4(mask0(kin && r < R), mask0(kin && r + 1 < R),
+                                      mask0(kin && r + 2 < R), mask0(kin && r + 3 < R));
             }
             rg.v[v] = x;
         }
@@ -110,10 +123,13 @@ struct LdRowsMN {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
-            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = rg.v[v];
+            const float4 x = rg.v[v], m = rg.m[v];
+            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = make_float4(x.x * m.x, x.y * m.y, x.z * m.z, x.w * m.w);
         }
     }
 };
+template <int T> using LdRowsMN = LdRowsMNT<T, true>;
+template <int T> using LdRowsMNS = LdRowsMNT<T, false>;
 
 // Geometry of a 4x4 convolution y[B,Cout,OH,OW] = conv(x[B,Cin,H,W], w[Cout,Cin,4,4]).
 struct ConvGeom {
@@ -135,7 +151,7 @@ struct LdIm2col {
     static constexpr int TILE = TILE_;
     static constexpr int NV = TILE * BK / NTHREADS;   // elements per thread
     static constexpr int KSTEP = NTHREADS / TILE;     // 2 or 4: k rows covered per pass
-    struct Regs { float v[NV]; };
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int Mtot;
     int base, kq; unsigned vh, vwq;
     __device__ void init(int tile0, int t, int) {
@@ -160,20 +176,24 @@ struct LdIm2col {
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int hw = g.H * g.W;
         const float *src = x + base + (k0 >> 4) * hw;
+        const int safe = (int)(x - src);              // offset of x[0]: always a legal address
         const int krem = kend - k0 - kq;              // element valid iff KSTEP*v < krem
+        unsigned okbits = 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            constexpr int dummy = 0; (void)dummy;
             const int c = KSTEP * v;                  // compile-time after unrolling
             const int kwl = c & 3, kh = (c >> 2) & 3, cil = c >> 4;
             const bool ok = (c < krem) && ((vh >> kh) & 1u) && ((vwq >> kwl) & 1u);
-            rg.v[v] = ok ? src[cil * hw + kh * g.W + kwl] : 0.f;
+            const float val = src[ok ? cil * hw + kh * g.W + kwl : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
         }
+        rg.ok = okbits;
     }
     __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v];
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 
@@ -187,7 +207,7 @@ struct LdDgradDyT {
     static constexpr int NV = TILE * BK / NTHREADS;
     static constexpr int KSTEP = NTHREADS / TILE;
     static constexpr int TMASK = (1 << TLOG) - 1;
-    struct Regs { float v[NV]; };
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
     __device__ void init(int tile0, int t, int cls) {
@@ -216,19 +236,24 @@ struct LdDgradDyT {
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int ohw = g.OH * g.OW;
         const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
+        const int safe = (int)(dy - src);
         const int krem = kend - k0 - kq;
+        unsigned okbits = 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = KSTEP * v;
             const int bl = c & TMASK, al = (c >> TLOG) & TMASK, col = c >> (2 * TLOG);
             const bool ok = (c < krem) && ((vhq >> al) & 1u) && ((vwq >> bl) & 1u);
-            rg.v[v] = ok ? src[col * ohw - al * g.OW - bl] : 0.f;
+            const float val = src[ok ? col * ohw - al * g.OW - bl : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
         }
+        rg.ok = okbits;
     }
     __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v];
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 template <int TILE_> using LdDgradDyS2 = LdDgradDyT<TILE_, 1>;   // stride 2: 2x2 taps per class
@@ -241,7 +266,7 @@ struct LdWgradDy {
     static constexpr int TILE = TILE_;
     static constexpr int NV = TILE * BK / NTHREADS;
     static constexpr int ISTEP = NTHREADS / BK;
-    struct Regs { float v[NV]; };
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g;
     int ioff, nvalid;       // ioff = i * OHW of element 0; nvalid = how many of the NV rows are < Cout
     __device__ void init(int tile0, int t, int) {
@@ -254,14 +279,21 @@ struct LdWgradDy {
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
         const float *src = dy + (size_t)b * g.Cout * ohw + sp + ioff;
+        const int safe = (int)(dy - src);
         const int nv = (k < kend) ? nvalid : 0;
+        unsigned okbits = 0;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) rg.v[v] = (v < nv) ? src[v * ISTEP * ohw] : 0.f;
+        for (int v = 0; v < NV; ++v) {
+            const float val = src[(v < nv) ? v * ISTEP * ohw : safe];
+            rg.v[v] = val;
+            okbits |= ((v < nv) ? 1u : 0u) << v;
+        }
+        rg.ok = okbits;
     }
     __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int kl = t % BK, ib = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v];
+        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 
@@ -271,7 +303,7 @@ struct LdWgradX {
     static constexpr int TILE = TILE_;
     static constexpr int NV = TILE * BK / NTHREADS;
     static constexpr int JSTEP = NTHREADS / BK;       // 8
-    struct Regs { float v[NV]; };
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int J;
     int joff, jq, nvalid;
     __device__ void init(int tile0, int t, int) {
@@ -287,20 +319,25 @@ struct LdWgradX {
         const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
         const int hw = g.H * g.W;
         const float *src = x + (size_t)b * g.Cin * hw + ih0 * g.W + iw0 + joff;
+        const int safe = (int)(x - src);
         const int iw = iw0 + (jq & 3), ihq = ih0 + (jq >> 2);
         const bool okw = k < kend && iw >= 0 && iw < g.W;
         const bool ok0 = okw && ihq >= 0 && ihq < g.H;            // kh = jq>>2       (v even)
         const bool ok1 = okw && ihq + 2 >= 0 && ihq + 2 < g.H;    // kh = (jq>>2) + 2 (v odd)
+        unsigned okbits = 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const bool ok = ((v & 1) ? ok1 : ok0) && v < nvalid;
-            rg.v[v] = ok ? src[(v >> 1) * hw + 2 * (v & 1) * g.W] : 0.f;
+            const float val = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
         }
+        rg.ok = okbits;
     }
     __device__ void store(float (*L)[TILE + LPAD], int t, const Regs &rg) const {
         const int kl = t % BK, jb = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v];
+        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 
@@ -418,19 +455,37 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
                 for (int kk = 0; kk < BK; ++kk) rsum += Ps[buf][kk][t];
             }
         }
+        // software-pipelined fragment reads: the ds_reads of k-pair kq+1 are issued before the MFMAs
+        // of k-pair kq, so the LDS latency hides behind 64-cycle matrix instructions
+        constexpr int NKK = BK / 2 / KW;
+        float a0[WM], b0[WN];
 #pragma unroll
-        for (int kq = 0; kq < BK / 2 / KW; ++kq) {
-            const int kk = kq * KW + kg;
-            float a[WM], b[WN];
+        for (int x = 0; x < WM; ++x) a0[x] = Ps[buf][kg * 2 + lrow][(wi * WM + x) * 32 + lcol];
 #pragma unroll
-            for (int x = 0; x < WM; ++x) a[x] = Ps[buf][kk * 2 + lrow][(wi * WM + x) * 32 + lcol];
+        for (int y = 0; y < WN; ++y) b0[y] = Qs[buf][kg * 2 + lrow][(wj * WN + y) * 32 + lcol];
 #pragma unroll
-            for (int y = 0; y < WN; ++y) b[y] = Qs[buf][kk * 2 + lrow][(wj * WN + y) * 32 + lcol];
+        for (int kq = 0; kq < NKK; ++kq) {
+            float a1[WM], b1[WN];
+            if (kq + 1 < NKK) {
+                const int kk = (kq + 1) * KW + kg;
+#pragma unroll
+                for (int x = 0; x < WM; ++x) a1[x] = Ps[buf][kk * 2 + lrow][(wi * WM + x) * 32 + lcol];
+#pragma unroll
+                for (int y = 0; y < WN; ++y) b1[y] = Qs[buf][kk * 2 + lrow][(wj * WN + y) * 32 + lcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < WM; ++x)
 #pragma unroll
                 for (int y = 0; y < WN; ++y)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[x], b0[y], acc[x][y], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kq + 1 < NKK) {
+#pragma unroll
+                for (int x = 0; x < WM; ++x) a0[x] = a1[x];
+#pragma unroll
+                for (int y = 0; y < WN; ++y) b0[y] = b1[y];
+            }
         }
     };
 
@@ -512,25 +567,45 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
     }
 }
 
-// Sum the split partials in a fixed order and run the epilogue on the result.
+// Sum the split partials and run the epilogue on the result.  Block = 32 consecutive outputs x 8
+// split groups: group q adds splits q, q+8, ... (independent loads in flight instead of one serial
+// chain of `splits` dependent round trips), the 8 group sums are combined in a fixed order.
 template <class E>
 __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits, E e) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    if (!e.col(j) || j >= sink.J) return;
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + o, i = blockIdx.y;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
-    e.put(i, j, s);
+    if (j < sink.J) {
+        const float *src = sink.ws + (size_t)i * sink.J + j;
+        for (int z = grp; z < splits; z += 8) s += src[(size_t)z * sink.stride];
+    }
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && j < sink.J && e.col(j)) {
+        s = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) +
+            ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]));
+        e.put(i, j, s);
+    }
 }
 
-// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient partials)
+// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient and block partials), same scheme
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *out, int n,
                                                             int splits, size_t stride, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
+    __shared__ float part[8][32];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * stride + idx];
-    if (accumulate) s += out[idx];
-    out[idx] = s;
+    if (idx < n)
+        for (int z = grp; z < splits; z += 8) s += ws[(size_t)z * stride + idx];
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && idx < n) {
+        s = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) +
+            ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]));
+        if (accumulate) s += out[idx];
+        out[idx] = s;
+    }
 }
 
 // wr[cls][(co,a,b)][ci] = w[co][ci][kh0 + s*a][kw0 + s*b]: the weights of one output parity class of
@@ -590,7 +665,7 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
         const long maxs = (K + 2 * BK - 1) / (2 * BK);
         if (want > maxs) want = maxs;
         if (want < 1) want = 1;
-        if (want > 64) want = 64;
+        if (want > (tiles <= 4 ? 512 : 64)) want = (tiles <= 4 ? 512 : 64);   // tiny outputs may split deeper
         if (g_force_splits) want = g_force_splits;
     }
     p.klen = (int)(((K + want - 1) / want + BK - 1) / BK * BK);
@@ -626,7 +701,7 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
     else MVAE_LAUNCH(1, 1, 1)
 #undef MVAE_LAUNCH
     if (pl.splits > 1) {
-        dim3 grid((J + 255) / 256, I);
+        dim3 grid((J + 31) / 32, I);
         hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
     }
     return mvae_launch_status();
@@ -646,6 +721,7 @@ inline size_t split_ws_floats(int I, int J, int K) {
         Plan pl = make_plan(I, J, K, true, (PlanKind)kind);
         if (pl.splits > 1 && (size_t)pl.splits > best) best = pl.splits;
     }
+    if (I <= 64 && J <= 64 && best < 512) best = 512;     // block partials of conv_wgrad_small_kernel
     return best * ((size_t)I * J + I);
 }
 
@@ -675,9 +751,11 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
     e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
-    auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.vec = aligned16(w) ? 1 : 0; };
+    auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
-    return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+    if (aligned16(w))
+        return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+    return launch_igemm<LdRowsKS, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
 }
 
 // ---- direct transposed conv for <= 4 OUTPUT channels (ConvTranspose2d(32,3) / (64,1), stride 2,
@@ -755,6 +833,133 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
     return mvae_launch_status();
 }
 
+// ---- stride-1 transposed conv as a DENSE GEMM + in-register/LDS col2im (ConvTranspose2d(256,128,4,1,0)
+//      5x5 -> 8x8 and the dgrad of Conv2d(128,256,4,1,0): celeba/model.py:85,117).  In the gather
+//      form only 39 % of the (output pixel, tap) pairs are inside the 5x5 input, so 61 % of the MFMA
+//      work multiplies zeros.  Here the GEMM is  col[(n,oh,ow)][(ci,kh,kw)] = sum_co dy[n,co,oh,ow] *
+//      w[co,ci,kh,kw]  (every product is real; the 25 positions of an image are padded to one 32-row
+//      MFMA tile = 78 % utilisation), and the scatter-add  dx[n,ci,oh+kh,ow+kw] += col  happens inside
+//      the wave that owns the tile: a wave holds one image x 2 input channels x 16 taps, i.e.
+//      everything two output planes need.  Block = 2 images x 4 channels; k loop over Cout. ----
+__global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
+                                                          const float *dpre, ConvGeom g) {
+    constexpr int BMX = 64, BNX = 64;
+    __shared__ __attribute__((aligned(16))) float Ps[2][BK][BMX + LPAD];
+    __shared__ __attribute__((aligned(16))) float Qs[2][BK][BNX + LPAD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int P = g.OH * g.OW;                      // positions per image (<= 32)
+    const int n0 = blockIdx.y * 2, ci0 = blockIdx.x * 4;
+    const int K = g.Cout, J = g.Cin * 16;
+    // P loader: lanes along the position axis, 4 k rows per pass
+    const int pi = t & 63, pkq = t >> 6;
+    const int pimg = pi >> 5, ppos = pi & 31;
+    const bool pok = ppos < P && n0 + pimg < g.B;
+    const float *psrc = dy + ((size_t)(pok ? n0 + pimg : 0) * K) * P + (pok ? ppos : 0);
+    // Q loader: weight rows are contiguous in (ci, tap): 16 float4 per k row, 2 per thread
+    const float *qsrc = w + (size_t)ci0 * 16;
+    float pr[8], pm[8];
+    float4 qr[2];
+    float qm[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int k = k0 + pkq + 4 * v;
+            pm[v] = (pok && k < K) ? 1.f : 0.f;
+            pr[v] = psrc[(size_t)min(k, K - 1) * P];
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int f = t + 256 * v, k = k0 + (f >> 4), c4 = (f & 15) * 4;
+            qm[v] = (k < K) ? 1.f : 0.f;
+            qr[v] = *reinterpret_cast<const float4 *>(qsrc + (size_t)min(k, K - 1) * J + c4);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) Ps[buf][pkq + 4 * v][pi] = pr[v] * pm[v];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int f = t + 256 * v;
+            *reinterpret_cast<float4 *>(&Qs[buf][f >> 4][(f & 15) * 4]) =
+                make_float4(qr[v].x * qm[v], qr[v].y * qm[v], qr[v].z * qm[v], qr[v].w * qm[v]);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int nsteps = (K + BK - 1) / BK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load((s + 1) * BK);
+        float a0 = Ps[buf][lrow][wi * 32 + lcol], b0 = Qs[buf][lrow][wj * 32 + lcol];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a1 = 0.f, b1 = 0.f;
+            if (kk + 1 < BK / 2) {
+                a1 = Ps[buf][(kk + 1) * 2 + lrow][wi * 32 + lcol];
+                b1 = Qs[buf][(kk + 1) * 2 + lrow][wj * 32 + lcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1; b0 = b1;
+        }
+        if (s + 1 < nsteps) store(buf ^ 1);
+        __syncthreads();
+    }
+    // col2im inside the wave: park the 32 (positions) x 32 (2 channels x 16 taps) tile in LDS ...
+    float *sc = &Ps[0][0][0] + wave * (32 * 33);        // 4 x 4224 B <= the P tile buffers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        sc[row * 33 + lcol] = acc[r];
+    }
+    __syncthreads();
+    // ... and let each lane gather the <= 16 taps of its output pixels
+    const int n = n0 + wi;
+    if (n >= g.B) return;
+    const int HW = g.H * g.W;
+    for (int cl = 0; cl < 2; ++cl) {
+        const int ci = ci0 + wj * 2 + cl;
+        if (ci >= g.Cin) break;
+        for (int px = lane; px < HW; px += 64) {
+            const int ih = px / g.W, iw = px - ih * g.W;
+            float v = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oh = ih - kh;
+                if (oh < 0 || oh >= g.OH) continue;
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ow = iw - kw;
+                    if (ow < 0 || ow >= g.OW) continue;
+                    v += sc[(oh * g.OW + ow) * 33 + cl * 16 + kh * 4 + kw];
+                }
+            }
+            const size_t o = ((size_t)n * g.Cin + ci) * HW + px;
+            if (dpre) v *= swish_grad_(dpre[o]);
+            if (out) out[o] = v;
+            if (act) act[o] = swishf_(v);
+        }
+    }
+}
+
+inline bool conv_dgrad_s1_ok(const ConvGeom &g, const float *w) {
+    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && aligned16(w);
+}
+
+inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act, const float *dpre, ConvGeom g,
+                         hipStream_t st) {
+    dim3 grid(g.Cin / 4, (g.B + 1) / 2);
+    hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g);
+    return mvae_launch_status();
+}
+
 inline size_t dgrad_ws_floats(const ConvGeom &g) { return (size_t)g.Cout * g.Cin * 16; }
 
 // ---- conv dgrad form: dx[n][ci][ih][iw] = sum_(co,kh,kw) w[co][ci][kh][kw] * dy[n][co][oh][ow],
@@ -765,6 +970,7 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     const int H2 = g.H / s, W2 = g.W / s;
     const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << (2 * tlog);
     if (conv_dgrad_small_ok(g) && !g_force_wm) return conv_dgrad_small(dy, w, dx, act, dpre, g, st);
+    if (conv_dgrad_s1_ok(g, w) && !g_force_wm) return conv_dgrad_s1(dy, w, dx, act, dpre, g, st);
     if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
     float *wr = (float *)ws;
     {
@@ -780,19 +986,104 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
     e.sy = s; e.py = 0; e.px = 0; e.J = J; e.off = 0;
     auto mp = [&](auto &p) {
-        p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.vec = vec ? 1 : 0; p.cls_stride = (size_t)K * g.Cin;
+        p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.Klen = K; p.cls_stride = (size_t)K * g.Cin;
     };
     auto mq = [&](auto &q) { q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; };
     SplitSink sink = make_sink(nullptr, I, J, false);
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
-    if (s == 2) return launch_igemm<LdRowsMN, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
-    return launch_igemm<LdRowsMN, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    if (vec) {
+        if (s == 2) return launch_igemm<LdRowsMN, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+        return launch_igemm<LdRowsMN, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    }
+    if (s == 2) return launch_igemm<LdRowsMNS, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    return launch_igemm<LdRowsMNS, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+}
+
+// ---- direct weight gradient for <= 3 INPUT channels (Conv2d(3,32) / (1,64) and the mirrored
+//      ConvTranspose2d(32,3) / (64,1), stride 2, pad 1).  The output is 32x48 (or 64x16): as a GEMM
+//      tile it is 37 % full and fed by two gathers; here a block walks chunks of 64 output positions,
+//      stages dy^T [64][CO] and the im2col patch [64][CIN*16] in LDS, and every thread keeps
+//      CIN*16*CO/256 accumulators (one co, a run of taps).  Block partials go to scratch and are
+//      summed in block order by splitk_reduce_kernel: deterministic. ----
+template <int CO, int CIN>
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const float *dy, const float *x, float *part,
+                                                               ConvGeom g, int npos, int nchunks) {
+    constexpr int NJ = CIN * 16, NG = 256 / CO, JPT = NJ / NG, P = 64;
+    __shared__ float dyT[P][CO + 1];
+    __shared__ float patch[P][NJ + 1];
+    const int t = threadIdx.x, co = t % CO, jg = t / CO;
+    const int pl = t & 63, cw = t >> 6;
+    const int ohw = g.OH * g.OW, hw = g.H * g.W;
+    float acc[JPT];
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) acc[q] = 0.f;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int pos = chunk * P + pl;
+        const bool pin = pos < npos;
+        const int n = pin ? pos / ohw : 0, sp = pin ? pos - n * ohw : 0;
+        const int oh = sp / g.OW, ow = sp - oh * g.OW;
+        const float pm = pin ? 1.f : 0.f;
+        const float *dsrc = dy + (size_t)n * CO * ohw + sp;
+#pragma unroll
+        for (int cc = 0; cc < CO / 4; ++cc) {
+            const int c = cw + 4 * cc;
+            dyT[pl][c] = dsrc[c * ohw] * pm;
+        }
+        const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
+        const float *xsrc = x + (size_t)n * CIN * hw;
+#pragma unroll
+        for (int jj = 0; jj < NJ / 4; ++jj) {
+            const int j = cw + 4 * jj;
+            const int ci = j >> 4, ih = ih0 + ((j >> 2) & 3), iw = iw0 + (j & 3);
+            const bool ok = pin && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+            const float v = xsrc[ok ? ci * hw + ih * g.W + iw : 0];
+            patch[pl][j] = v * (ok ? 1.f : 0.f);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int pp = 0; pp < P; ++pp) {
+            const float a = dyT[pp][co];
+#pragma unroll
+            for (int q = 0; q < JPT; ++q) acc[q] += a * patch[pp][jg * JPT + q];
+        }
+        __syncthreads();
+    }
+    float *dst = part + (size_t)blockIdx.x * CO * NJ + co * NJ + jg * JPT;
+#pragma unroll
+    for (int q = 0; q < JPT; ++q) dst[q] = acc[q];
+}
+
+constexpr int WGRAD_SMALL_BLOCKS = 512;
+
+inline bool conv_wgrad_small_ok(const ConvGeom &g) {
+    return g.stride == 2 && g.pad == 1 && (g.Cin == 1 || g.Cin == 3) && (g.Cout == 32 || g.Cout == 64);
+}
+
+inline int conv_wgrad_small(const float *dy, const float *x, float *dw, ConvGeom g, int accumulate, void *ws,
+                            size_t ws_bytes, hipStream_t st) {
+    const int npos = g.B * g.OH * g.OW, nchunks = (npos + 63) / 64;
+    const int nblk = nchunks < WGRAD_SMALL_BLOCKS ? nchunks : WGRAD_SMALL_BLOCKS;
+    const int n = g.Cout * g.Cin * 16;
+    if (!ws || ws_bytes < (size_t)nblk * n * sizeof(float)) return MVAE_ERR_WS;
+    float *part = (float *)ws;
+#define MVAE_WG(CO, CI) hipLaunchKernelGGL((conv_wgrad_small_kernel<CO, CI>), dim3(nblk), dim3(256), 0, st, dy, x, \
+                                           part, g, npos, nchunks)
+    if (g.Cout == 32 && g.Cin == 3) MVAE_WG(32, 3);
+    else if (g.Cout == 32 && g.Cin == 1) MVAE_WG(32, 1);
+    else if (g.Cout == 64 && g.Cin == 3) MVAE_WG(64, 3);
+    else MVAE_WG(64, 1);
+#undef MVAE_WG
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float *)part, dw, n,
+                       nblk, (size_t)n, accumulate);
+    return mvae_launch_status();
 }
 
 // ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----
 int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int flags, void *ws,
                     size_t ws_bytes, hipStream_t st) {
     const int I = g.Cout, J = g.Cin * 16, K = g.B * g.OH * g.OW;
+    if (conv_wgrad_small_ok(g) && !g_force_wm)
+        return conv_wgrad_small(dy, x, dw, g, (flags & MVAE_ACCUMULATE) ? 1 : 0, ws, ws_bytes, st);
     Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
     SplitSink sink = make_sink(ws, I, J, false);
     if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
@@ -837,9 +1128,11 @@ MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const f
     EpRowMajor e;
     e.out = pre; e.act = act; e.ld = ldy; e.bias = bias; e.dpre = nullptr; e.ldp = 0;
     e.mask = mask; e.ldm = N; e.mask_scale = mask_scale; e.I = M; e.J = N; e.accumulate = 0;
-    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0; };
-    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0; };
-    return launch_igemm<LdRowsK, LdRowsK, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
+    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; };
+    if (aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0)
+        return launch_igemm<LdRowsK, LdRowsK, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
+    return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
 }
 
 MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,
@@ -856,9 +1149,11 @@ MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, flo
     e.out = dx; e.act = nullptr; e.ld = lddx; e.bias = nullptr; e.dpre = pre_in; e.ldp = K;
     e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
     e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
-    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.vec = (aligned16(dy) && lddy % 4 == 0) ? 1 : 0; };
-    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.vec = (aligned16(w) && K % 4 == 0) ? 1 : 0; q.cls_stride = 0; };
-    return launch_igemm<LdRowsK, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.Klen = N; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.Klen = N; q.cls_stride = 0; };
+    if (aligned16(dy) && aligned16(w) && lddy % 4 == 0 && N % 4 == 0 && K % 4 == 0)
+        return launch_igemm<LdRowsK, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
+    return launch_igemm<LdRowsKS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
 }
 
 MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db,
@@ -874,8 +1169,9 @@ MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int
     EpRowMajor e;
     e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
     e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = N; e.J = K; e.accumulate = acc;
-    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.vec = (aligned16(dy) && lddy % 4 == 0) ? 1 : 0; p.cls_stride = 0; };
-    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.vec = (aligned16(x) && ldx % 4 == 0) ? 1 : 0; q.cls_stride = 0; };
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = 0; };
+    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = 0; };
+    const bool vec = aligned16(dy) && aligned16(x) && lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0;
     int rc;
     if (db) {
         // row sums of P = dy^T are the bias gradient; partials live right after each dw partial
@@ -884,16 +1180,18 @@ MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int
         } else {
             sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
         }
-        rc = launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
+        rc = vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st)
+                 : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
         if (rc) return rc;
         if (pl.splits > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st,
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st,
                                (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
             return mvae_launch_status();
         }
         return MVAE_OK;
     }
-    return launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
+    return vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st)
+               : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
 }
 
 MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
