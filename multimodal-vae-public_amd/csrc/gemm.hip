@@ -589,7 +589,27 @@ __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits,
     }
 }
 
-// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient and block partials), same scheme
+// few splits: one thread per output, the chain is short
+template <class E>
+__global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int splits, E e) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= sink.J || !e.col(j)) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
+    e.put(i, j, s);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_few_kernel(const float *ws, float *out, int n, int splits,
+                                                                size_t stride, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * stride + idx];
+    if (accumulate) s += out[idx];
+    out[idx] = s;
+}
+
+// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient partials), same scheme as finish_kernel
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *out, int n,
                                                             int splits, size_t stride, int accumulate) {
     __shared__ float part[8][32];
@@ -701,8 +721,13 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
     else MVAE_LAUNCH(1, 1, 1)
 #undef MVAE_LAUNCH
     if (pl.splits > 1) {
-        dim3 grid((J + 31) / 32, I);
-        hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        if (pl.splits > 16) {
+            dim3 grid((J + 31) / 32, I);
+            hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        } else {
+            dim3 grid((J + 255) / 256, I);
+            hipLaunchKernelGGL((finish_few_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        }
     }
     return mvae_launch_status();
 }
@@ -721,7 +746,6 @@ inline size_t split_ws_floats(int I, int J, int K) {
         Plan pl = make_plan(I, J, K, true, (PlanKind)kind);
         if (pl.splits > 1 && (size_t)pl.splits > best) best = pl.splits;
     }
-    if (I <= 64 && J <= 64 && best < 512) best = 512;     // block partials of conv_wgrad_small_kernel
     return best * ((size_t)I * J + I);
 }
 
@@ -999,91 +1023,10 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     return launch_igemm<LdRowsMNS, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
-// ---- direct weight gradient for <= 3 INPUT channels (Conv2d(3,32) / (1,64) and the mirrored
-//      ConvTranspose2d(32,3) / (64,1), stride 2, pad 1).  The output is 32x48 (or 64x16): as a GEMM
-//      tile it is 37 % full and fed by two gathers; here a block walks chunks of 64 output positions,
-//      stages dy^T [64][CO] and the im2col patch [64][CIN*16] in LDS, and every thread keeps
-//      CIN*16*CO/256 accumulators (one co, a run of taps).  Block partials go to scratch and are
-//      summed in block order by splitk_reduce_kernel: deterministic. ----
-template <int CO, int CIN>
-__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const float *dy, const float *x, float *part,
-                                                               ConvGeom g, int npos, int nchunks) {
-    constexpr int NJ = CIN * 16, NG = 256 / CO, JPT = NJ / NG, P = 64;
-    __shared__ float dyT[P][CO + 1];
-    __shared__ float patch[P][NJ + 1];
-    const int t = threadIdx.x, co = t % CO, jg = t / CO;
-    const int pl = t & 63, cw = t >> 6;
-    const int ohw = g.OH * g.OW, hw = g.H * g.W;
-    float acc[JPT];
-#pragma unroll
-    for (int q = 0; q < JPT; ++q) acc[q] = 0.f;
-    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int pos = chunk * P + pl;
-        const bool pin = pos < npos;
-        const int n = pin ? pos / ohw : 0, sp = pin ? pos - n * ohw : 0;
-        const int oh = sp / g.OW, ow = sp - oh * g.OW;
-        const float pm = pin ? 1.f : 0.f;
-        const float *dsrc = dy + (size_t)n * CO * ohw + sp;
-#pragma unroll
-        for (int cc = 0; cc < CO / 4; ++cc) {
-            const int c = cw + 4 * cc;
-            dyT[pl][c] = dsrc[c * ohw] * pm;
-        }
-        const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-        const float *xsrc = x + (size_t)n * CIN * hw;
-#pragma unroll
-        for (int jj = 0; jj < NJ / 4; ++jj) {
-            const int j = cw + 4 * jj;
-            const int ci = j >> 4, ih = ih0 + ((j >> 2) & 3), iw = iw0 + (j & 3);
-            const bool ok = pin && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
-            const float v = xsrc[ok ? ci * hw + ih * g.W + iw : 0];
-            patch[pl][j] = v * (ok ? 1.f : 0.f);
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int pp = 0; pp < P; ++pp) {
-            const float a = dyT[pp][co];
-#pragma unroll
-            for (int q = 0; q < JPT; ++q) acc[q] += a * patch[pp][jg * JPT + q];
-        }
-        __syncthreads();
-    }
-    float *dst = part + (size_t)blockIdx.x * CO * NJ + co * NJ + jg * JPT;
-#pragma unroll
-    for (int q = 0; q < JPT; ++q) dst[q] = acc[q];
-}
-
-constexpr int WGRAD_SMALL_BLOCKS = 512;
-
-inline bool conv_wgrad_small_ok(const ConvGeom &g) {
-    return g.stride == 2 && g.pad == 1 && (g.Cin == 1 || g.Cin == 3) && (g.Cout == 32 || g.Cout == 64);
-}
-
-inline int conv_wgrad_small(const float *dy, const float *x, float *dw, ConvGeom g, int accumulate, void *ws,
-                            size_t ws_bytes, hipStream_t st) {
-    const int npos = g.B * g.OH * g.OW, nchunks = (npos + 63) / 64;
-    const int nblk = nchunks < WGRAD_SMALL_BLOCKS ? nchunks : WGRAD_SMALL_BLOCKS;
-    const int n = g.Cout * g.Cin * 16;
-    if (!ws || ws_bytes < (size_t)nblk * n * sizeof(float)) return MVAE_ERR_WS;
-    float *part = (float *)ws;
-#define MVAE_WG(CO, CI) hipLaunchKernelGGL((conv_wgrad_small_kernel<CO, CI>), dim3(nblk), dim3(256), 0, st, dy, x, \
-                                           part, g, npos, nchunks)
-    if (g.Cout == 32 && g.Cin == 3) MVAE_WG(32, 3);
-    else if (g.Cout == 32 && g.Cin == 1) MVAE_WG(32, 1);
-    else if (g.Cout == 64 && g.Cin == 3) MVAE_WG(64, 3);
-    else MVAE_WG(64, 1);
-#undef MVAE_WG
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float *)part, dw, n,
-                       nblk, (size_t)n, accumulate);
-    return mvae_launch_status();
-}
-
 // ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----
 int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int flags, void *ws,
                     size_t ws_bytes, hipStream_t st) {
     const int I = g.Cout, J = g.Cin * 16, K = g.B * g.OH * g.OW;
-    if (conv_wgrad_small_ok(g) && !g_force_wm)
-        return conv_wgrad_small(dy, x, dw, g, (flags & MVAE_ACCUMULATE) ? 1 : 0, ws, ws_bytes, st);
     Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
     SplitSink sink = make_sink(ws, I, J, false);
     if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
@@ -1184,8 +1127,12 @@ MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int
                  : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
         if (rc) return rc;
         if (pl.splits > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st,
-                               (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
+            if (pl.splits > 16)
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st,
+                                   (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
+            else
+                hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((N + 255) / 256), dim3(256), 0, st,
+                                   (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
             return mvae_launch_status();
         }
         return MVAE_OK;
