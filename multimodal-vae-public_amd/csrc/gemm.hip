@@ -407,10 +407,12 @@ struct SplitSink {
 // GEMMs (the 512-wide MLP layers at batch 512-1024) have < 256 tiles, i.e. fewer than one wave per
 // SIMD: the extra wave groups put all 1024 SIMDs to work and shorten each block's serial MFMA
 // chain KW-fold without a second launch.  Waves >= 4 only issue MFMAs; waves 0-3 also move data.
-template <class P, class Q, class E, int WM, int WN, bool ROWSUM, int KW>
+// NARROW (WM = WN = 1): the four waves sit side by side along j, block tile 32 x 128 -- for outputs
+// with <= 32 rows (32-channel conv layers, the 32x48 weight gradients) a 64-row tile is half padding.
+template <class P, class Q, class E, int WM, int WN, bool ROWSUM, int KW, bool NARROW>
 __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel(P p, Q q, E e, int K, int klen,
                                                                                SplitSink sink) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = NARROW ? 32 : 64 * WM, BN = NARROW ? 128 : 64 * WN;
     static_assert(P::TILE == BM && Q::TILE == BN, "loader tile mismatch");
     // dynamic LDS (the 128x128 tile needs 66 KiB, above the 64 KiB static limit); the only LDS
     // object of the kernel, so its base is 16-byte aligned (cdna_hip_programming.md G17)
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kg = wave >> 2;                       // k-group of this wave (0 when KW == 1)
-    const int wi = (wave & 3) >> 1, wj = wave & 1;
+    const int wi = NARROW ? 0 : (wave & 3) >> 1, wj = NARROW ? (wave & 3) : (wave & 1);
     const bool mover = (KW == 1) || t < NTHREADS;   // waves 0-3 fetch and stage the tiles
     const int tiles_j = gridDim.x / sink.ncls;
     const int cls = blockIdx.x / tiles_j;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(256) void repack_dgrad_weights_kernel(const float *
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, splits, klen, kw; };
+struct Plan { int wm, wn, splits, klen, kw, narrow; };
 
 int g_force_wm = 0, g_force_wn = 0, g_force_splits = 0, g_force_kw = 0;   // tuning hook (mvae_debug_set_tiling)
 
@@ -664,16 +666,18 @@ enum PlanKind { PLAN_FWD = 0, PLAN_CONV_WGRAD = 1, PLAN_LIN_WGRAD = 2 };
 inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLAN_FWD, int ncls = 1) {
     Plan p;
     p.wm = 1; p.wn = 1;
-    if (kind == PLAN_CONV_WGRAD) {
+    p.narrow = (I <= 32 && J >= 128 && !g_force_wm && !g_force_wn && !g_force_kw) ? 1 : 0;
+    if (kind == PLAN_CONV_WGRAD && !p.narrow) {
         if (J >= 128) p.wn = 2;
         if (I >= 128 && J >= 128) p.wm = 2;
     }
     if (g_force_wm) p.wm = g_force_wm;
     if (g_force_wn) p.wn = g_force_wn;
-    const long tiles = (long)((I + 64 * p.wm - 1) / (64 * p.wm)) * ((J + 64 * p.wn - 1) / (64 * p.wn)) * ncls;
+    const long tiles = p.narrow ? (long)((J + 127) / 128) * ncls
+                                : (long)((I + 64 * p.wm - 1) / (64 * p.wm)) * ((J + 64 * p.wn - 1) / (64 * p.wn)) * ncls;
     // fewer than one wave per SIMD (256 CUs x 4): let KW wave groups share each 64x64 tile
     p.kw = 1;
-    if (p.wm == 1 && p.wn == 1 && K >= 4 * BK) {
+    if (!p.narrow && p.wm == 1 && p.wn == 1 && K >= 4 * BK) {
         if (tiles * 4 <= 256) p.kw = 4;
         else if (tiles * 2 <= 256) p.kw = 2;
     }
@@ -695,16 +699,16 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
 
 template <template <int> class PL, template <int> class QL, class E, bool ROWSUM, class PF, class QF>
 int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitSink sink, hipStream_t st) {
-#define MVAE_LAUNCH(WM, WN, KW)                                                                  \
+#define MVAE_LAUNCH(WM, WN, KW, NARROW)                                                          \
     {                                                                                            \
-        PL<64 * WM> p; make_p(p);                                                                \
-        QL<64 * WN> q; make_q(q);                                                                \
-        dim3 grid(((J + 64 * WN - 1) / (64 * WN)) * sink.ncls, (I + 64 * WM - 1) / (64 * WM),    \
-                  pl.splits);                                                                    \
-        constexpr size_t tile_b = 2 * BK * (64 * WM + LPAD + 64 * WN + LPAD) * sizeof(float);    \
+        constexpr int TM = NARROW ? 32 : 64 * WM, TN = NARROW ? 128 : 64 * WN;                   \
+        PL<TM> p; make_p(p);                                                                     \
+        QL<TN> q; make_q(q);                                                                     \
+        dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
+        constexpr size_t tile_b = 2 * BK * (TM + LPAD + TN + LPAD) * sizeof(float);              \
         constexpr size_t red_b = (size_t)(KW - 1) * 4 * WM * WN * 16 * 64 * sizeof(float);       \
         constexpr size_t lds = tile_b > red_b ? tile_b : red_b;                                  \
-        auto kern = igemm_kernel<PL<64 * WM>, QL<64 * WN>, E, WM, WN, ROWSUM, KW>;               \
+        auto kern = igemm_kernel<PL<TM>, QL<TN>, E, WM, WN, ROWSUM, KW, NARROW>;                 \
         static bool attr_done = false;                                                           \
         if (!attr_done) {                                                                        \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
@@ -713,12 +717,13 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
         }                                                                                        \
         hipLaunchKernelGGL(kern, grid, dim3(NTHREADS * KW), lds, st, p, q, e, K, pl.klen, sink); \
     }
-    if (pl.wm == 2 && pl.wn == 2) MVAE_LAUNCH(2, 2, 1)
-    else if (pl.wm == 2 && pl.wn == 1) MVAE_LAUNCH(2, 1, 1)
-    else if (pl.wm == 1 && pl.wn == 2) MVAE_LAUNCH(1, 2, 1)
-    else if (pl.kw == 4) MVAE_LAUNCH(1, 1, 4)
-    else if (pl.kw == 2) MVAE_LAUNCH(1, 1, 2)
-    else MVAE_LAUNCH(1, 1, 1)
+    if (pl.narrow) MVAE_LAUNCH(1, 1, 1, true)
+    else if (pl.wm == 2 && pl.wn == 2) MVAE_LAUNCH(2, 2, 1, false)
+    else if (pl.wm == 2 && pl.wn == 1) MVAE_LAUNCH(2, 1, 1, false)
+    else if (pl.wm == 1 && pl.wn == 2) MVAE_LAUNCH(1, 2, 1, false)
+    else if (pl.kw == 4) MVAE_LAUNCH(1, 1, 4, false)
+    else if (pl.kw == 2) MVAE_LAUNCH(1, 1, 2, false)
+    else MVAE_LAUNCH(1, 1, 1, false)
 #undef MVAE_LAUNCH
     if (pl.splits > 1) {
         if (pl.splits > 16) {

@@ -32,5 +32,24 @@ def main(path):
                                                                  100.0 * tot / total, name))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == '--pmc'):
     main(sys.argv[1])
+
+
+def pmc_summary(path):
+    """Per-kernel average of a --pmc counter pass (counters_collection view), values as reported
+    by rocprofv3 (FETCH_SIZE / WRITE_SIZE are kilobytes)."""
+    c = sqlite3.connect(path)
+    rows = c.execute('select kernel_name, counter_name, value from counters_collection').fetchall()
+    agg = {}
+    for name, counter, value in rows:
+        a = agg.setdefault((short(name), counter), [0, 0.0])
+        a[0] += 1; a[1] += value
+    print('# source: %s   (rocprofv3 --pmc, per-dispatch averages)' % path)
+    print('%-8s %-12s %14s %14s  %s' % ('calls', 'counter', 'avg', 'total', 'kernel'))
+    for (name, counter), (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print('%-8d %-12s %14.1f %14.1f  %s' % (n, counter, tot / n, tot, name))
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == '--pmc':
+    pmc_summary(sys.argv[1])
