@@ -1,0 +1,90 @@
+"""Drop-in for the reference's ``celeba19/train.py``: same CLI (--n-latents --batch-size --epochs
+--annealing-epochs --lr --log-interval --approx-m --lambda-image --lambda-attrs --cuda), same
+function names, log lines and checkpoint format.  The per-batch body -- complete + image-only +
+18 single-attribute + ``approx_m`` sampled-subset ELBO terms, celeba19/train.py:257-308 -- is
+``engine.Celeba19Step``: one batched HIP pass instead of 20 + M ``model()`` calls."""
+import os
+import sys
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    import mvae_amd  # noqa: F401
+    __package__ = 'multimodal-vae-public_amd.celeba19'
+
+import numpy as np  # noqa: E402
+
+from ..engine import Celeba19Step, sample_subsets  # noqa: E402
+from ..functional import binary_cross_entropy_with_logits  # noqa: E402,F401
+from ..functional import elbo_loss_multi as elbo_loss  # noqa: E402
+from ..train_common import AverageMeter, add_extra_flags, make_load_checkpoint, run, save_checkpoint  # noqa: E402,F401
+from .model import MVAE, N_ATTRS  # noqa: E402,F401
+
+load_checkpoint = make_load_checkpoint(MVAE)
+
+
+def tensor_2d_to_list(x):
+    """[B, 18] -> list of 18 [B] columns (celeba19/train.py:63-69)."""
+    return [x[:, i] for i in range(x.size(1))]
+
+
+def enumerate_combinations(n):
+    """All subsets of n modalities with 2 .. n-1 members as an [n_subsets, n] boolean matrix ordered by size
+    (celeba19/train.py:87-108).  The fused step never materialises this pool -- it draws the
+    members directly (``engine.sample_subsets``) -- the function is kept for callers that
+    index into it."""
+    from itertools import combinations
+    rows = []
+    for size in range(2, n):
+        picks = list(combinations(range(n), size))
+        block = np.zeros((len(picks), n), dtype=bool)
+        for r, members in enumerate(picks):
+            block[r, list(members)] = True
+        rows.append(block)
+    return np.concatenate(rows)
+
+
+def sample_combinations(pool, size=1):
+    """``size`` rows of the pool: a subset size uniformly, then a row of that size without
+    replacement (celeba19/train.py:111-142)."""
+    n = pool.shape[1]
+    return sample_subsets(np.random, n, size)
+
+
+def _test_total(model, image, attrs, args):
+    """celeba19/train.py:325-335: only the complete-data ELBO, default lambdas, beta = 1."""
+    cols = tensor_2d_to_list(attrs.float())
+    recon_image, recon_attrs, mu, logvar = model(image, cols)
+    return elbo_loss([recon_image] + recon_attrs, [image] + cols, mu, logvar)
+
+
+def _make_engine(model, args, rank):
+    return Celeba19Step(model, args.batch_size, args.lambda_image, args.lambda_attrs,
+                        approx_m=args.approx_m, seed=1 + rank)
+
+
+if __name__ == "__main__":
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--n-latents', type=int, default=100,
+                        help='size of the latent embedding [default: 100]')
+    parser.add_argument('--batch-size', type=int, default=100, metavar='N',
+                        help='input batch size for training [default: 100]')
+    parser.add_argument('--epochs', type=int, default=100, metavar='N',
+                        help='number of epochs to train [default: 100]')
+    parser.add_argument('--annealing-epochs', type=int, default=20, metavar='N',
+                        help='number of epochs to anneal KL for [default: 20]')
+    parser.add_argument('--lr', type=float, default=1e-4, metavar='LR',
+                        help='learning rate [default: 1e-4]')
+    parser.add_argument('--log-interval', type=int, default=10, metavar='N',
+                        help='how many batches to wait before logging training status [default: 10]')
+    parser.add_argument('--approx-m', type=int, default=1,
+                        help='number of ELBO terms to approx. the full MVAE objective [default: 1]')
+    parser.add_argument('--lambda-image', type=float, default=1.,
+                        help='multipler for image reconstruction [default: 1]')
+    parser.add_argument('--lambda-attrs', type=float, default=10.,
+                        help='multipler for attributes reconstruction [default: 10]')
+    parser.add_argument('--cuda', action='store_true', default=False,
+                        help='enables CUDA training [default: False]')
+    add_extra_flags(parser)
+    args = parser.parse_args()
+    run('celeba19', MVAE, _test_total, args, args.lambda_attrs, make_engine=_make_engine)

@@ -28,6 +28,9 @@ Results (per-term ELBOs, total, every gradient, BatchNorm running statistics) eq
 reference's multi-call step on the same noise; ``tests/test_engine_gpu.py`` checks that against
 the oracle and the golden fixtures.
 """
+import contextlib
+import os
+
 import torch
 
 from . import kernels as K
@@ -86,6 +89,40 @@ class _StepBase(object):
         self.on_bucket_ready = None     # parallel.py hooks gradient all-reduce launches here
         self._graphs = None
         self._comm = None
+        # independent stacks (image vs label side) run as two branches; each kernel here fills
+        # well under the 256 CUs, so the branches overlap instead of queueing
+        n_streams = int(os.environ.get('MVAE_STREAMS', '2'))
+        self.side = torch.cuda.Stream(device=self.dev) if n_streams >= 2 else None
+        # MVAE_STREAMS=4 also moves each branch's weight gradients to a further stream.  Measured
+        # SLOWER (MNIST B=512: 0.73 vs 0.55 ms/step): every fork is a cross-queue signal, and one
+        # per layer costs more than the overlap returns.  Coarse forks (3 per step) are the win.
+        self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else None
+        self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else None
+        self._forked = False
+        self._held = []      # gradients the side branch's weight-gradient stream reads
+
+    @contextlib.contextmanager
+    def _branch(self):
+        """Run the body on the side stream, ordered after everything launched so far.  Tensors it
+        allocates must stay referenced until the next fork (``_carry``)."""
+        if self.side is None:
+            yield
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        self._forked = True
+        with torch.cuda.stream(self.side):
+            yield
+
+    def _join(self):
+        if self._forked:
+            main = torch.cuda.current_stream(self.dev)
+            main.wait_stream(self.side)
+            if self.wg_side is not None:
+                # forked from the side stream but joined HERE: hipGraph capture (ROCm 7.0) crashes
+                # in EndCapture when a stream joins back into a parent that is itself a fork
+                # (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main')
+                main.wait_stream(self.wg_side)
+            self._forked = False
 
     # subclasses: _phase_a(image, label), _phase_b(), set_coefficients(beta), draw_noise()
     def forward_backward(self, image, label):
@@ -254,9 +291,13 @@ class BimodalStep(_StepBase):
         if image.shape[0] != B:
             raise ValueError('engine was built for batch %d, got %d' % (B, image.shape[0]))
         c = self._carry = {}
+        self._held = c['held'] = []
         image = image.contiguous()
         n_up = 2  # each encoder is called twice per step in the reference
-        # ---- encoders
+        # ---- encoders: label on the side stream, image on this one
+        lbl_in = label if m.LABEL_KIND == 'class' else label.float().contiguous()
+        with self._branch():
+            heads_lbl, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
         if self.has_dropout:
             h, c['tape_trunk'] = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
             hd = torch.empty(2 * B, h.shape[1], dtype=torch.float32, device=self.dev)
@@ -266,8 +307,7 @@ class BimodalStep(_StepBase):
         else:
             heads_img, c['tape_img'] = L.forward_tape(m.image_encoder.plan(), image, bn_updates=n_up)
             img_experts = [heads_img]
-        lbl_in = label if m.LABEL_KIND == 'class' else label.float().contiguous()
-        heads_lbl, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
+        self._join()
         experts = img_experts + [heads_lbl]
         mus = [e[:, :D] for e in experts]
         lvs = [e[:, D:] for e in experts]
@@ -278,46 +318,53 @@ class BimodalStep(_StepBase):
         kl = torch.empty(T, B, dtype=torch.float32, device=self.dev)
         K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, m.POE_VARIANT)
         self.last_latents = (mu, lv, z)
-        # ---- decoders
         i0, ni = self.img_terms
         l0, nl = self.lbl_terms
+        # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
+        with self._branch():
+            zl = z[l0:l0 + nl].reshape(nl * B, D)
+            logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
+            rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
+            dlog_lbl = torch.empty_like(logits_lbl)
+            if m.LABEL_KIND == 'class':
+                K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
+                         rows_per_group=B, label_rows=B)
+            else:
+                K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
+                                 dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
+            g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
+                                    defer_input_grad=True, wgrad_stream=self.wg_side,
+                                    wgrad_join=False, held=self._held)
+        # ---- image branch (this stream)
         zi = z[i0:i0 + ni].reshape(ni * B, D)
         logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
         if self.has_bn and ni < T:
             # the reference also decodes the image for the label-only call: no loss, but its
             # BatchNorm running statistics advance (celeba/train.py:195)
             L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni)
-        zl = z[l0:l0 + nl].reshape(nl * B, D)
-        logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
-        # ---- reconstruction terms, forward and gradient in one pass each
         P = logits_img[0].numel()
         li = logits_img.reshape(ni * B, P)
         rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
         dlog_img = torch.empty_like(li)
         K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
                          rows_per_group=B, target_rows=B)
-        rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
-        dlog_lbl = torch.empty_like(logits_lbl)
-        if m.LABEL_KIND == 'class':
-            K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
-                     rows_per_group=B, label_rows=B)
-        else:
-            K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
-                             rows_per_group=B, target_rows=B)
+        g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
+                                groups=ni, defer_input_grad=True, wgrad_stream=self.wg_main)
+        self._join()
         # ---- ELBO per term and total (mnist/train.py:57-58,214)
         elbo = self.elbo
         K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
         K.group_sums(rows_img, self.coef[0, i0:i0 + ni], elbo[i0:i0 + ni], elbo[T:], ni, B, accumulate=True)
         K.group_sums(rows_lbl, self.coef[1, l0:l0 + nl], elbo[l0:l0 + nl], elbo[T:], nl, B, accumulate=True)
-        # ---- backward: decoders -> dz
+        # ---- both decoders' first layers -> the shared dz
         dz = torch.empty(T, B, D, dtype=torch.float32, device=self.dev)
         K.fill_(dz, 0.0)
-        L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
-                        need_input_grad=True, groups=ni,
-                        input_grad_out=dz[i0:i0 + ni].reshape(ni * B, D), input_grad_accumulate=True)
-        L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, need_input_grad=True, groups=nl,
-                        input_grad_out=dz[l0:l0 + nl].reshape(nl * B, D), input_grad_accumulate=True)
-        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_lbl=heads_lbl)
+        L.first_linear_dgrad(m.image_decoder.plan(), g_img, dz[i0:i0 + ni].reshape(ni * B, D), True)
+        L.first_linear_dgrad(m.label_decoder.plan(), g_lbl, dz[l0:l0 + nl].reshape(nl * B, D), True)
+        # everything a branch allocated stays referenced until the next step's first fork
+        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_lbl=heads_lbl,
+                 keep=(z, kl, logits_lbl, tape_dl, rows_lbl, dlog_lbl, g_lbl, logits_img, tape_di,
+                       rows_img, dlog_img, g_img, lbl_in))
 
     def _phase_b(self):
         m, B, D = self.model, self.B, self.D
@@ -331,14 +378,19 @@ class BimodalStep(_StepBase):
                   self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
                   dkl_per_term=True)
         # ---- encoders backward
-        L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl)
+        with self._branch():
+            L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, wgrad_stream=self.wg_side,
+                            wgrad_join=False, held=self._held)
         if self.has_dropout:
-            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True)
+            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True,
+                                   wgrad_stream=self.wg_main)
             d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
             K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
-            L.backward_tape(self.trunk, c['tape_trunk'], d_h)
+            L.backward_tape(self.trunk, c['tape_trunk'], d_h, wgrad_stream=self.wg_main)
         else:
-            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img)
+            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, wgrad_stream=self.wg_main)
+        self._join()
+        c['keep_b'] = (g_heads_img, g_heads_lbl)
 
 
 # =====================================================================================
@@ -353,6 +405,8 @@ def sample_subsets(rng, n_modalities=19, size=1):
     The reference materialises all 524,267 subsets (:87-108) to index into; drawing the
     members directly is the same distribution without the 10 MB pool."""
     import numpy as np
+    if size <= 0:
+        return np.zeros((0, n_modalities), dtype=bool)
     out, seen = [], set()
     while len(out) < size:
         k = int(rng.randint(2, n_modalities))
@@ -510,17 +564,20 @@ class Celeba19Step(_StepBase):
         c = self._carry = {}
         image = image.contiguous()
         attrs = attrs.float().contiguous()
+        # ---- 18 attribute encoders, each once (no BatchNorm / Dropout: celeba19/model.py:173-178),
+        #      on the side stream: ~110 small launches that hide behind the image encoder
+        heads_attr, c['tape_enc'] = [], []
+        with self._branch():
+            for i in range(N_ATTRS):
+                ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
+                heads_attr.append(ha); c['tape_enc'].append(tp)
         # ---- image encoder: trunk once, n_img Dropout draws, head on n_img*B rows
         h, c['tape_trunk'] = L.forward_tape(self.trunk, image, bn_updates=self.n_img_present,
                                             bn_updates_dev=self.nimg_dev)
         hd = torch.empty(n_img * B, h.shape[1], dtype=torch.float32, device=dev)
         K.dropout_fanout_fwd(h, self.drop_masks, hd, 1.0 / KEEP)
         heads_img, c['tape_head'] = L.forward_tape(self.head, hd)
-        # ---- 18 attribute encoders, each once (no BatchNorm / Dropout: celeba19/model.py:173-178)
-        heads_attr, c['tape_enc'] = [], []
-        for i in range(N_ATTRS):
-            ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
-            heads_attr.append(ha); c['tape_enc'].append(tp)
+        self._join()
         experts = [heads_img[k * B:(k + 1) * B] for k in range(n_img)] + heads_attr
         mus = [e[:, :D] for e in experts]
         lvs = [e[:, D:] for e in experts]
@@ -529,55 +586,65 @@ class Celeba19Step(_StepBase):
         kl = torch.empty(T, B, dtype=torch.float32, device=dev)
         K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, m.POE_VARIANT)
         self.last_latents = (mu, lv, z)
+        t_s = 2 + N_ATTRS
+        # ---- attribute decoders (side stream): gather the z rows each one needs, one pass per
+        #      decoder, reconstruction term + gradient, backward into dzcat
+        with self._branch():
+            zcat = torch.empty(N_ATTRS, S * B, D, dtype=torch.float32, device=dev)
+            K.block_gather(z, self.term_of_slot, zcat, B * D)
+            logits_attr = torch.empty(N_ATTRS * S, B, dtype=torch.float32, device=dev)
+            tape_dec = []
+            for i in range(N_ATTRS):
+                _, tp = L.forward_tape(self.dec_plans[i], zcat[i], final_out=logits_attr[i * S:(i + 1) * S])
+                tape_dec.append(tp)
+            rows_attr = torch.empty(N_ATTRS * S, dtype=torch.float32, device=dev)
+            dlog_attr = torch.empty_like(logits_attr)
+            # logits row (i, s) holds B columns; its targets are column i of attrs[B, 18]
+            K.bce_rowsum_fwd(logits_attr, attrs, rows_attr, drow=self.coef_attr, dlogits=dlog_attr,
+                             rows_per_group=1, target_rows=N_ATTRS, target_div=S, target_strides=(1, N_ATTRS))
+            dzcat = torch.empty_like(zcat)
+            for i in range(N_ATTRS):
+                L.backward_tape(self.dec_plans[i], tape_dec[i], dlog_attr[i * S:(i + 1) * S].reshape(S * B, 1),
+                                need_input_grad=True, input_grad_out=dzcat[i], input_grad_accumulate=False)
         # ---- image decoder in term order: [0,1] kept, [2..19] statistics only, sampled kept
         dplan = m.image_decoder.plan()
-        t_s = 2 + N_ATTRS
         logit_a, tape_a = L.forward_tape(dplan, z[0:2].reshape(2 * B, D), groups=2)
         if self.faithful:
             L.forward_tape(dplan, z[2:t_s].reshape(N_ATTRS * B, D), groups=N_ATTRS)
-        logit_c, tape_c = L.forward_tape(dplan, z[t_s:T].reshape(M * B, D), groups=M)
+        if M > 0:
+            logit_c, tape_c = L.forward_tape(dplan, z[t_s:T].reshape(M * B, D), groups=M)
         P = logit_a[0].numel()
         img_flat = image.reshape(B, P)
         rows_a = torch.empty(2 * B, dtype=torch.float32, device=dev)
         dlog_a = torch.empty(2 * B, P, dtype=torch.float32, device=dev)
         K.bce_rowsum_fwd(logit_a.reshape(2 * B, P), img_flat, rows_a, drow=self.coef[0, 0:2], dlogits=dlog_a,
                          rows_per_group=B, target_rows=B)
-        rows_c = torch.empty(M * B, dtype=torch.float32, device=dev)
-        dlog_c = torch.empty(M * B, P, dtype=torch.float32, device=dev)
-        K.bce_rowsum_fwd(logit_c.reshape(M * B, P), img_flat, rows_c, drow=self.coef[0, t_s:T], dlogits=dlog_c,
-                         rows_per_group=B, target_rows=B)
-        # ---- attribute decoders: gather the z rows each one needs, one pass per decoder
-        zcat = torch.empty(N_ATTRS, S * B, D, dtype=torch.float32, device=dev)
-        K.block_gather(z, self.term_of_slot, zcat, B * D)
-        logits_attr = torch.empty(N_ATTRS * S, B, dtype=torch.float32, device=dev)
-        tape_dec = []
-        for i in range(N_ATTRS):
-            _, tp = L.forward_tape(self.dec_plans[i], zcat[i], final_out=logits_attr[i * S:(i + 1) * S])
-            tape_dec.append(tp)
-        rows_attr = torch.empty(N_ATTRS * S, dtype=torch.float32, device=dev)
-        dlog_attr = torch.empty_like(logits_attr)
-        # logits row (i, s) holds B columns; its targets are column i of attrs[B, 18]
-        K.bce_rowsum_fwd(logits_attr, attrs, rows_attr, drow=self.coef_attr, dlogits=dlog_attr,
-                         rows_per_group=1, target_rows=N_ATTRS, target_div=S, target_strides=(1, N_ATTRS))
-        # ---- ELBO per term and total (celeba19/train.py:59,265-302)
-        elbo = self.elbo
-        K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
-        K.group_sums(rows_a, self.coef[0, 0:2], elbo[0:2], elbo[T:], 2, B, accumulate=True)
-        K.group_sums(rows_c, self.coef[0, t_s:T], elbo[t_s:T], elbo[T:], M, B, accumulate=True)
-        K.scatter_sums(rows_attr, self.coef_attr, self.term_of_slot, elbo[:T], elbo[T:], accumulate_total=True)
-        # ---- backward: decoders -> dz
+        rows_c = dlog_c = None
+        if M > 0:
+            rows_c = torch.empty(M * B, dtype=torch.float32, device=dev)
+            dlog_c = torch.empty(M * B, P, dtype=torch.float32, device=dev)
+            K.bce_rowsum_fwd(logit_c.reshape(M * B, P), img_flat, rows_c, drow=self.coef[0, t_s:T],
+                             dlogits=dlog_c, rows_per_group=B, target_rows=B)
+        # ---- image decoder backward -> dz (only this stream touches dz before the join)
         dz = torch.empty(T, B, D, dtype=torch.float32, device=dev)
         K.fill_(dz, 0.0)
         L.backward_tape(dplan, tape_a, dlog_a.reshape(logit_a.shape), need_input_grad=True, groups=2,
                         input_grad_out=dz[0:2].reshape(2 * B, D), input_grad_accumulate=True)
-        L.backward_tape(dplan, tape_c, dlog_c.reshape(logit_c.shape), need_input_grad=True, groups=M,
-                        input_grad_out=dz[t_s:T].reshape(M * B, D), input_grad_accumulate=True)
-        dzcat = torch.empty_like(zcat)
-        for i in range(N_ATTRS):
-            L.backward_tape(self.dec_plans[i], tape_dec[i], dlog_attr[i * S:(i + 1) * S].reshape(S * B, 1),
-                            need_input_grad=True, input_grad_out=dzcat[i], input_grad_accumulate=False)
+        if M > 0:
+            L.backward_tape(dplan, tape_c, dlog_c.reshape(logit_c.shape), need_input_grad=True, groups=M,
+                            input_grad_out=dz[t_s:T].reshape(M * B, D), input_grad_accumulate=True)
+        self._join()
         K.block_scatter_add(dzcat, self.term_of_slot, dz, T, B * D)
-        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_attr=heads_attr)
+        # ---- ELBO per term and total (celeba19/train.py:59,265-302)
+        elbo = self.elbo
+        K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
+        K.group_sums(rows_a, self.coef[0, 0:2], elbo[0:2], elbo[T:], 2, B, accumulate=True)
+        if M > 0:
+            K.group_sums(rows_c, self.coef[0, t_s:T], elbo[t_s:T], elbo[T:], M, B, accumulate=True)
+        K.scatter_sums(rows_attr, self.coef_attr, self.term_of_slot, elbo[:T], elbo[T:], accumulate_total=True)
+        c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_attr=heads_attr,
+                 keep=(z, kl, zcat, logits_attr, tape_dec, rows_attr, dlog_attr, dzcat, attrs, image,
+                       rows_a, rows_c, dlog_a, dlog_c))
 
     def _phase_b(self):
         m, B, D, n_img = self.model, self.B, self.D, self.n_img
@@ -588,9 +655,12 @@ class Celeba19Step(_StepBase):
         K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
                   self.coef[2], [g[:, :D] for g in g_list], [g[:, D:] for g in g_list], m.POE_VARIANT,
                   dkl_per_term=True)
-        for i in range(N_ATTRS):
-            L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
+        with self._branch():
+            for i in range(N_ATTRS):
+                L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
         d_hd = L.backward_tape(self.head, c['tape_head'], g_img, need_input_grad=True)
         d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
         K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
         L.backward_tape(self.trunk, c['tape_trunk'], d_h)
+        self._join()
+        c['keep_b'] = (g_img, g_attr)

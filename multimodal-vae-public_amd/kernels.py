@@ -41,7 +41,9 @@ def _f32c(*tensors):
 def workspace(nbytes, device):
     """Scratch for split reductions.  Grows by allocating a new buffer; earlier buffers stay
     alive because captured graphs may hold their addresses."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    # one scratch per (device, stream): engine branches on different streams run concurrently
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     bufs = _WS.setdefault(key, [])
     if not bufs or bufs[-1].numel() * 4 < nbytes:
         n = max(int(nbytes), _WS_MIN_BYTES)

@@ -322,12 +322,36 @@ def _producer(plan, tape, i):
 
 
 def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out=None,
-                  input_grad_accumulate=False):
+                  input_grad_accumulate=False, defer_input_grad=False, wgrad_stream=None,
+                  wgrad_join=True, held=None):
     """Backward through the plan.  ``g`` = gradient w.r.t. the stack output.  Parameter
     gradients go to ``p.grad`` (the arena); returns the input gradient or None.
     ``input_grad_out`` (stacks that start with a Linear): write -- or with
     ``input_grad_accumulate`` add -- the input gradient into this buffer (the shared dz of the
-    decoders) instead of allocating one."""
+    decoders) instead of allocating one.  ``defer_input_grad`` (same stacks): skip the first
+    Linear's input gradient and return the gradient w.r.t. its OUTPUT; the caller finishes with
+    ``first_linear_dgrad`` -- used when two stacks run on different streams but share dz.
+    ``wgrad_stream``: launch the weight-gradient kernels there, so only the data-gradient
+    chain is serial; joined before returning unless ``wgrad_join`` is False -- then the caller
+    joins it and keeps ``held`` (a list that receives every gradient tensor the weight-gradient
+    kernels read) alive until it has."""
+    cur = torch.cuda.current_stream(g.device) if wgrad_stream is not None else None
+    if held is None:
+        held = []       # every gradient a wgrad reads stays allocated until the join
+
+    def side(fn):
+        if wgrad_stream is None:
+            fn()
+            return
+        wgrad_stream.wait_stream(cur)
+        with torch.cuda.stream(wgrad_stream):
+            fn()
+
+    def finish(out):
+        if wgrad_stream is not None and wgrad_join:
+            cur.wait_stream(wgrad_stream)
+        return out
+
     last = len(plan) - 1
     while last >= 0 and plan[last].kind == 'view':
         last -= 1
@@ -352,7 +376,10 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             g = g.reshape(x.shape[0], -1)
             if g.stride(1) != 1:
                 g = g.contiguous()
-            _lin_wgrad(op, g, x)
+            held.append(g)
+            side(lambda op=op, g=g, x=x: _lin_wgrad(op, g, x))
+            if defer_input_grad and i == first:
+                return finish(g)
             if want_dx:
                 w, _ = _lin_weights(op)
                 acc = False
@@ -370,7 +397,9 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             out_shape = _conv_out_shape(op, x)
             g = g.reshape(out_shape).contiguous()
             dw, acc = grad_target(m.weight)
-            (K.conv2d_wgrad if op.kind == 'conv' else K.convT2d_wgrad)(g, x, dw, s, p, accumulate=acc)
+            held.append(g)
+            side(lambda op=op, g=g, x=x, dw=dw, acc=acc, s=s, p=p:
+                 (K.conv2d_wgrad if op.kind == 'conv' else K.convT2d_wgrad)(g, x, dw, s, p, accumulate=acc))
             if want_dx:
                 dx = torch.empty_like(x)
                 (K.conv2d_dgrad if op.kind == 'conv' else K.convT2d_dgrad)(
@@ -395,7 +424,16 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             dw, acc = grad_target(m.weight)
             K.embedding_swish_bwd(saved[0], m.weight.detach(), g.contiguous(), dw, accumulate=acc)
             g = None
-    return g if need_input_grad else None
+    return finish(g if need_input_grad else None)
+
+
+def first_linear_dgrad(plan, g, out, accumulate):
+    """The step ``backward_tape(..., defer_input_grad=True)`` left out: out (+)= g @ W_first."""
+    first = 0
+    while plan[first].kind == 'view':
+        first += 1
+    w, _ = _lin_weights(plan[first])
+    K.linear_dgrad(g, w.detach(), out, None, None, 1.0, accumulate=accumulate)
 
 
 def _conv_out_shape(op, x):

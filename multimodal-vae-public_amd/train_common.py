@@ -100,9 +100,10 @@ def _real_loaders(kind, batch_size):
     return mk(True), mk(False)
 
 
-def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0):
+def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0, make_engine=None):
     """The reference's main loop.  ``annealing_epoch_offset``: 0 for mnist/celeba
-    ((epoch - 1) * N, mnist/train.py:182), 1 for fashionmnist (epoch * N, fashionmnist/train.py:182)."""
+    ((epoch - 1) * N, mnist/train.py:182), 1 for fashionmnist (epoch * N, fashionmnist/train.py:182).
+    ``make_engine(model, args, rank)``: the fused step to use instead of ``BimodalStep`` (celeba19)."""
     import torch.distributed as dist
     from .engine import BimodalStep
     from .optim import FusedAdam
@@ -131,7 +132,10 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
     model = mvae_cls(args.n_latents)
     model.cuda(device)
     optimizer = FusedAdam(model.parameters(), lr=args.lr, grad_scale=1.0 / world)
-    engine = BimodalStep(model, args.batch_size, args.lambda_image, lambda_label, seed=1 + rank)
+    if make_engine is not None:
+        engine = make_engine(model, args, rank)
+    else:
+        engine = BimodalStep(model, args.batch_size, args.lambda_image, lambda_label, seed=1 + rank)
     dp = DataParallel(model, engine) if world > 1 else None
     captured = [False]
 
