@@ -79,6 +79,21 @@ int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
                       float *dw, float *db, int M, int N, int K, int flags,
                       void *ws, size_t ws_bytes, mvae_stream_t stream);
 
+/* Grouped forms: G independent Linear problems of ONE shape in one launch.  celeba19 builds 18
+ * identical attribute encoders / decoders (celeba19/model.py:29-30, 173-196) and the reference runs
+ * them one after another (celeba19/model.py:78-81, 53-54); here operand g of every array is at
+ * base + g * <name>_gs floats (the expert's slice of the parameter arena / of a [G, rows, width]
+ * activation buffer).  No dropout mask, no split scratch.  Same maths as the single forms. */
+int mvae_linear_fwd_grouped(const float *x, int ldx, size_t x_gs, const float *w, size_t w_gs,
+                            const float *bias, size_t bias_gs, float *pre, float *act, int ldy,
+                            size_t y_gs, int G, int M, int N, int K, mvae_stream_t stream);
+int mvae_linear_dgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *w, size_t w_gs,
+                              float *dx, int lddx, size_t dx_gs, const float *pre_in, size_t pre_gs,
+                              int G, int M, int N, int K, int flags, mvae_stream_t stream);
+int mvae_linear_wgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *x, int ldx,
+                              size_t x_gs, float *dw, size_t dw_gs, float *db, size_t db_gs, int G,
+                              int M, int N, int K, int flags, mvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K2  Conv2d 4x4, bias=False, (stride,pad) in {(2,1),(1,0)}: fashionmnist/model.py:79,81;
  *     celeba/model.py:77,79,82,85; celeba19/model.py:103,105,108,111.
@@ -150,6 +165,14 @@ int mvae_embedding_swish_fwd(const void *idx, int idx_is_float, const float *w, 
 int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, const float *w,
                              const float *dact, float *dw,
                              int R, int n_classes, int width, int flags, mvae_stream_t stream);
+/* grouped: table / output / index g at base + g * <name>_gs elements (celeba19: idx = attrs[B,18],
+ * idx_is_float = 18 (row stride), idx_gs = 1 (column g)); dw shares w's group stride. */
+int mvae_embedding_swish_fwd_grouped(const void *idx, int idx_is_float, size_t idx_gs, const float *w,
+                                     size_t w_gs, float *act, size_t act_gs, int G, int R,
+                                     int n_classes, int width, mvae_stream_t stream);
+int mvae_embedding_swish_bwd_grouped(const void *idx, int idx_is_float, size_t idx_gs, const float *w,
+                                     size_t w_gs, const float *dact, size_t dact_gs, float *dw, int G,
+                                     int R, int n_classes, int width, int flags, mvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K8-K10, K12  prior expert + product of experts + reparameterise + analytic KL, fused:

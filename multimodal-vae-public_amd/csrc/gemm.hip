@@ -51,8 +51,9 @@ struct LdRowsKT {
     static constexpr int NV = TILE * BK / 4 / NTHREADS;
     struct Regs { float4 v[NV]; float4 m[NV]; };      // raw data + 0/1 masks (applied when staged)
     const float *src; int ld; int R; int Klen;
+    size_t cls_stride = 0;                            // per-class (group) source offset
     int r0;
-    __device__ void init(int tile0, int, int) { r0 = tile0; }
+    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -352,7 +353,13 @@ struct EpRowMajor {
     const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
     const float *mask; int ldm; float mask_scale;   // dropout keep-mask (fwd on act, bwd on the product)
     int I, J; int accumulate;
-    __device__ void set_class(int) {}
+    size_t out_cs = 0, bias_cs = 0, dpre_cs = 0;    // grouped Linear: per-group offsets of out/act, bias, dpre
+    __device__ void set_class(int cls) {
+        if (out) out += (size_t)cls * out_cs;
+        if (act) act += (size_t)cls * out_cs;
+        if (bias) bias += (size_t)cls * bias_cs;
+        if (dpre) dpre += (size_t)cls * dpre_cs;
+    }
     __device__ bool col(int j) const { return j < J; }
     __device__ void put(int i, int j, float v) const {
         if (i >= I) return;
@@ -396,7 +403,8 @@ struct EpNCHW {
 struct SplitSink {
     float *ws; size_t stride; int I, J;       // partial (split, i, j) at ws[split*stride + i*J + j]
     float *rowsum; size_t rowsum_stride; int rowsum_accumulate;   // (split, i) at rowsum[split*rowsum_stride + i]
-    int ncls;                                 // parity classes folded into gridDim.x (transposed conv)
+    int ncls;                                 // parity classes (transposed conv) / groups (grouped Linear) folded into gridDim.x
+    size_t rowsum_cls_stride;                 // grouped Linear wgrad: per-group offset of the bias gradient
 };
 
 // ------------------------------------------------------------------------------------------
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
 
     auto compute = [&](int buf) {
         if (ROWSUM) {   // db = sum over the reduction axis of P (dy^T): the bias gradient for free
-            if (blockIdx.x == 0 && t < BM) {      // (t < BM <= 256: always a wave of k-group 0)
+            if (blockIdx.x == cls * tiles_j && t < BM) {      // (t < BM <= 256: always a wave of k-group 0)
 #pragma unroll
                 for (int kk = 0; kk < BK; ++kk) rsum += Ps[buf][kk][t];
             }
@@ -561,8 +569,8 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
         }
     }
     if (ROWSUM) {
-        if (blockIdx.x == 0 && t < BM && i0 + t < sink.I) {
-            float *dst = sink.rowsum + (size_t)split * sink.rowsum_stride + i0 + t;
+        if (blockIdx.x == cls * tiles_j && t < BM && i0 + t < sink.I) {
+            float *dst = sink.rowsum + (size_t)cls * sink.rowsum_cls_stride + (size_t)split * sink.rowsum_stride + i0 + t;
             if (!partial && sink.rowsum_accumulate) rsum += *dst;
             *dst = rsum;
         }
@@ -741,7 +749,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     SplitSink s;
     s.ws = (float *)ws; s.I = I; s.J = J;
     s.stride = (size_t)I * J + (rowsum ? I : 0);
-    s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1;
+    s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
     return s;
 }
 
@@ -1065,66 +1073,72 @@ MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len
     return (n > repack ? n : repack) * sizeof(float);
 }
 
-MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
-                                float *pre, float *act, int ldy, const float *mask, float mask_scale,
-                                int M, int N, int K, void *ws, size_t ws_bytes, mvae_stream_t stream) {
-    if (!x || !w || (!pre && !act) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return MVAE_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    Plan pl = make_plan(M, N, K, ws != nullptr);
+// Linear layers.  G > 1: G independent problems of one shape in ONE launch (celeba19's 18 attribute
+// experts, celeba19/model.py:173-196) -- operand g lives at base + g * group stride; the group index
+// rides on the class slot of the grid, so a layer of all 18 experts is 18x the blocks instead of 18
+// under-filled launches.  Grouped launches never split the reduction.
+struct LinGroups { int G; size_t a, b, c, d; };     // meaning of a..d per entry point below
+
+static int linear_fwd_impl(const float *x, int ldx, const float *w, const float *bias, float *pre, float *act,
+                           int ldy, const float *mask, float mask_scale, int M, int N, int K, void *ws,
+                           size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // gr: a = x stride, b = w stride, c = bias stride, d = pre/act stride
+    Plan pl = make_plan(M, N, K, ws != nullptr && gr.G == 1, PLAN_FWD, gr.G);
     SplitSink sink = make_sink(ws, M, N, false);
+    sink.ncls = gr.G;
     if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = pre; e.act = act; e.ld = ldy; e.bias = bias; e.dpre = nullptr; e.ldp = 0;
     e.mask = mask; e.ldm = N; e.mask_scale = mask_scale; e.I = M; e.J = N; e.accumulate = 0;
-    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; };
-    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; };
-    if (aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0)
+    e.out_cs = gr.d; e.bias_cs = gr.c;
+    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; q.cls_stride = gr.b; };
+    if (aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 && gr.b % 4 == 0)
         return launch_igemm<LdRowsK, LdRowsK, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
     return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
 }
 
-MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,
-                                  const float *pre_in, const float *mask, float mask_scale,
-                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
-                                  mvae_stream_t stream) {
-    if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    // D[i = m][j = k] = sum_n dy[m][n] * w[n][k]
-    Plan pl = make_plan(M, K, N, ws != nullptr);
+static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *dx, int lddx, const float *pre_in,
+                             const float *mask, float mask_scale, int M, int N, int K, int flags, void *ws,
+                             size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // D[i = m][j = k] = sum_n dy[m][n] * w[n][k];  gr: a = dy stride, b = w stride, c = pre_in stride, d = dx stride
+    Plan pl = make_plan(M, K, N, ws != nullptr && gr.G == 1, PLAN_FWD, gr.G);
     SplitSink sink = make_sink(ws, M, K, false);
+    sink.ncls = gr.G;
     if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = dx; e.act = nullptr; e.ld = lddx; e.bias = nullptr; e.dpre = pre_in; e.ldp = K;
     e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
     e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
-    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.Klen = N; };
-    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.Klen = N; q.cls_stride = 0; };
-    if (aligned16(dy) && aligned16(w) && lddy % 4 == 0 && N % 4 == 0 && K % 4 == 0)
+    e.out_cs = gr.d; e.dpre_cs = gr.c;
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.Klen = N; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.Klen = N; q.cls_stride = gr.b; };
+    if (aligned16(dy) && aligned16(w) && lddy % 4 == 0 && N % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 && gr.b % 4 == 0)
         return launch_igemm<LdRowsK, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
     return launch_igemm<LdRowsKS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
 }
 
-MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db,
-                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
-                                  mvae_stream_t stream) {
-    if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    // D[i = n][j = k] = sum_m dy[m][n] * x[m][k]
-    Plan pl = make_plan(N, K, M, ws != nullptr, PLAN_LIN_WGRAD);
+static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db, int M, int N,
+                             int K, int flags, void *ws, size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // D[i = n][j = k] = sum_m dy[m][n] * x[m][k];  gr: a = dy stride, b = x stride, c = db stride, d = dw stride
+    Plan pl = make_plan(N, K, M, ws != nullptr && gr.G == 1, PLAN_LIN_WGRAD, gr.G);
     SplitSink sink = make_sink(ws, N, K, db != nullptr);
+    sink.ncls = gr.G;
     if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
     const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
     EpRowMajor e;
     e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
     e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = N; e.J = K; e.accumulate = acc;
-    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = 0; };
-    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = 0; };
-    const bool vec = aligned16(dy) && aligned16(x) && lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0;
+    e.out_cs = gr.d;
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = gr.b; };
+    const bool vec = aligned16(dy) && aligned16(x) && lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
+                     gr.a % 4 == 0 && gr.b % 4 == 0;
     int rc;
     if (db) {
         // row sums of P = dy^T are the bias gradient; partials live right after each dw partial
         if (pl.splits == 1) {
-            sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc;
+            sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc; sink.rowsum_cls_stride = gr.c;
         } else {
             sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
         }
@@ -1144,6 +1158,60 @@ MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int
     }
     return vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st)
                : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
+}
+
+static const LinGroups kOneGroup = {1, 0, 0, 0, 0};
+
+MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
+                                float *pre, float *act, int ldy, const float *mask, float mask_scale,
+                                int M, int N, int K, void *ws, size_t ws_bytes, mvae_stream_t stream) {
+    if (!x || !w || (!pre && !act) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return MVAE_ERR_ARG;
+    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, mask, mask_scale, M, N, K, ws, ws_bytes, kOneGroup,
+                           (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,
+                                  const float *pre_in, const float *mask, float mask_scale,
+                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                  mvae_stream_t stream) {
+    if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
+    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, mask, mask_scale, M, N, K, flags, ws, ws_bytes,
+                             kOneGroup, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db,
+                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                  mvae_stream_t stream) {
+    if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
+    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, ws, ws_bytes, kOneGroup, (hipStream_t)stream);
+}
+
+static inline bool groups_ok(int G) { return G >= 1 && G <= 4096; }
+
+MVAE_EXPORT int mvae_linear_fwd_grouped(const float *x, int ldx, size_t x_gs, const float *w, size_t w_gs,
+                                        const float *bias, size_t bias_gs, float *pre, float *act, int ldy,
+                                        size_t y_gs, int G, int M, int N, int K, mvae_stream_t stream) {
+    if (!x || !w || (!pre && !act) || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N)
+        return MVAE_ERR_ARG;
+    const LinGroups gr = {G, x_gs, w_gs, bias_gs, y_gs};
+    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, nullptr, 1.f, M, N, K, nullptr, 0, gr, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_dgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *w, size_t w_gs,
+                                          float *dx, int lddx, size_t dx_gs, const float *pre_in, size_t pre_gs,
+                                          int G, int M, int N, int K, int flags, mvae_stream_t stream) {
+    if (!dy || !w || !dx || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
+    const LinGroups gr = {G, dy_gs, w_gs, pre_gs, dx_gs};
+    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, nullptr, 1.f, M, N, K, flags, nullptr, 0, gr,
+                             (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_wgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *x, int ldx,
+                                          size_t x_gs, float *dw, size_t dw_gs, float *db, size_t db_gs, int G,
+                                          int M, int N, int K, int flags, mvae_stream_t stream) {
+    if (!dy || !x || !dw || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
+    const LinGroups gr = {G, dy_gs, x_gs, db_gs, dw_gs};
+    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, nullptr, 0, gr, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,

@@ -28,8 +28,14 @@ __device__ __forceinline__ int read_index(const void *idx, int is_float, int r) 
 }
 
 // act[r,:] = swish(w[idx[r],:])   (nn.Embedding + Swish, mnist/model.py:116,123)
+// blockIdx.y = group g (celeba19's 18 attribute encoders in one launch): index g reads element
+// offset g * idx_gs of the index array, table g * w_gs, output g * act_gs.
 __global__ __launch_bounds__(256) void embedding_swish_fwd_kernel(const void *idx, int is_float, const float *w,
-                                                                  float *act, int R, int n_classes, int width) {
+                                                                  float *act, int R, int n_classes, int width,
+                                                                  size_t idx_gs, size_t w_gs, size_t act_gs) {
+    const int g = blockIdx.y;
+    idx = is_float ? (const void *)((const float *)idx + g * idx_gs) : (const void *)((const int64_t *)idx + g * idx_gs);
+    w += g * w_gs; act += g * act_gs;
     const size_t total = (size_t)R * width;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / width), j = (int)(i - (size_t)r * width);
@@ -44,8 +50,12 @@ __global__ __launch_bounds__(256) void embedding_swish_fwd_kernel(const void *id
 // deterministic (the reference's index_add_ backward is not).
 __global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *idx, int is_float, const float *w,
                                                                   const float *dact, float *dw, int R,
-                                                                  int n_classes, int width, int accumulate) {
+                                                                  int n_classes, int width, int accumulate,
+                                                                  size_t idx_gs, size_t w_gs, size_t dact_gs) {
     __shared__ float part[4][64];
+    const int g = blockIdx.z;
+    idx = is_float ? (const void *)((const float *)idx + g * idx_gs) : (const void *)((const int64_t *)idx + g * idx_gs);
+    w += g * w_gs; dw += g * w_gs; dact += g * dact_gs;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tx, c = blockIdx.y;
     float s = 0.f;
@@ -184,21 +194,47 @@ MVAE_EXPORT int mvae_swish_bwd(const float *dy, const float *x, float *dx, size_
     return mvae_launch_status();
 }
 
+static int embedding_fwd_launch(const void *idx, int idx_is_float, const float *w, float *act, int R, int n_classes,
+                                int width, int G, size_t idx_gs, size_t w_gs, size_t act_gs, hipStream_t st) {
+    unsigned blocks = ew_blocks((size_t)R * width, 256);
+    if (G > 1 && blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(embedding_swish_fwd_kernel, dim3(blocks, G), dim3(256), 0, st, idx, idx_is_float, w, act, R,
+                       n_classes, width, idx_gs, w_gs, act_gs);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_embedding_swish_fwd(const void *idx, int idx_is_float, const float *w, float *act, int R,
                                          int n_classes, int width, mvae_stream_t stream) {
     if (!idx || !w || !act || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
-    hipLaunchKernelGGL(embedding_swish_fwd_kernel, dim3(ew_blocks((size_t)R * width, 256)), dim3(256), 0,
-                       (hipStream_t)stream, idx, idx_is_float, w, act, R, n_classes, width);
-    return mvae_launch_status();
+    return embedding_fwd_launch(idx, idx_is_float, w, act, R, n_classes, width, 1, 0, 0, 0, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_embedding_swish_fwd_grouped(const void *idx, int idx_is_float, size_t idx_gs, const float *w,
+                                                 size_t w_gs, float *act, size_t act_gs, int G, int R,
+                                                 int n_classes, int width, mvae_stream_t stream) {
+    if (!idx || !w || !act || G <= 0 || G > 65535 || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
+    return embedding_fwd_launch(idx, idx_is_float, w, act, R, n_classes, width, G, idx_gs, w_gs, act_gs,
+                                (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, const float *w, const float *dact,
                                          float *dw, int R, int n_classes, int width, int flags,
                                          mvae_stream_t stream) {
     if (!idx || !w || !dact || !dw || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
-    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes), dim3(256), 0,
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, 1), dim3(256), 0,
                        (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
-                       (flags & MVAE_ACCUMULATE) ? 1 : 0);
+                       (flags & MVAE_ACCUMULATE) ? 1 : 0, (size_t)0, (size_t)0, (size_t)0);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_embedding_swish_bwd_grouped(const void *idx, int idx_is_float, size_t idx_gs, const float *w,
+                                                 size_t w_gs, const float *dact, size_t dact_gs, float *dw, int G,
+                                                 int R, int n_classes, int width, int flags, mvae_stream_t stream) {
+    if (!idx || !w || !dact || !dw || G <= 0 || G > 65535 || R <= 0 || n_classes <= 0 || width <= 0)
+        return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, G), dim3(256), 0,
+                       (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
+                       (flags & MVAE_ACCUMULATE) ? 1 : 0, idx_gs, w_gs, dact_gs);
     return mvae_launch_status();
 }
 

@@ -457,6 +457,11 @@ class Celeba19Step(_StepBase):
         self.head = L.compile_plan(enc.head_modules())
         self.enc_plans = [e.plan() for e in model.attr_encoders]
         self.dec_plans = [d.plan() for d in model.attr_decoders]
+        # the 18 experts of each kind as ONE grouped launch per layer (MVAE_GROUPED=0: 18 launches)
+        self.grouped = os.environ.get('MVAE_GROUPED', '1') != '0'
+        if self.grouped:
+            self.enc_group = L.GroupedPlans(self.enc_plans)
+            self.dec_group = L.GroupedPlans(self.dec_plans)
         # device tables + pinned mirrors
         self.masks_host = torch.zeros(T, dtype=torch.int32)
         self.masks_dev = torch.zeros(T, dtype=torch.int32, device=dev)
@@ -568,9 +573,13 @@ class Celeba19Step(_StepBase):
         #      on the side stream: ~110 small launches that hide behind the image encoder
         heads_attr, c['tape_enc'] = [], []
         with self._branch():
-            for i in range(N_ATTRS):
-                ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
-                heads_attr.append(ha); c['tape_enc'].append(tp)
+            if self.grouped:
+                heads_all, c['tape_enc'] = L.forward_tape_grouped(self.enc_group, attrs)
+                heads_attr = [heads_all[i] for i in range(N_ATTRS)]
+            else:
+                for i in range(N_ATTRS):
+                    ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
+                    heads_attr.append(ha); c['tape_enc'].append(tp)
         # ---- image encoder: trunk once, n_img Dropout draws, head on n_img*B rows
         h, c['tape_trunk'] = L.forward_tape(self.trunk, image, bn_updates=self.n_img_present,
                                             bn_updates_dev=self.nimg_dev)
@@ -594,18 +603,25 @@ class Celeba19Step(_StepBase):
             K.block_gather(z, self.term_of_slot, zcat, B * D)
             logits_attr = torch.empty(N_ATTRS * S, B, dtype=torch.float32, device=dev)
             tape_dec = []
-            for i in range(N_ATTRS):
-                _, tp = L.forward_tape(self.dec_plans[i], zcat[i], final_out=logits_attr[i * S:(i + 1) * S])
-                tape_dec.append(tp)
+            if self.grouped:
+                _, tape_dec = L.forward_tape_grouped(self.dec_group, zcat, final_out=logits_attr)
+            else:
+                for i in range(N_ATTRS):
+                    _, tp = L.forward_tape(self.dec_plans[i], zcat[i], final_out=logits_attr[i * S:(i + 1) * S])
+                    tape_dec.append(tp)
             rows_attr = torch.empty(N_ATTRS * S, dtype=torch.float32, device=dev)
             dlog_attr = torch.empty_like(logits_attr)
             # logits row (i, s) holds B columns; its targets are column i of attrs[B, 18]
             K.bce_rowsum_fwd(logits_attr, attrs, rows_attr, drow=self.coef_attr, dlogits=dlog_attr,
                              rows_per_group=1, target_rows=N_ATTRS, target_div=S, target_strides=(1, N_ATTRS))
             dzcat = torch.empty_like(zcat)
-            for i in range(N_ATTRS):
-                L.backward_tape(self.dec_plans[i], tape_dec[i], dlog_attr[i * S:(i + 1) * S].reshape(S * B, 1),
-                                need_input_grad=True, input_grad_out=dzcat[i], input_grad_accumulate=False)
+            if self.grouped:
+                L.backward_tape_grouped(self.dec_group, tape_dec, dlog_attr.reshape(N_ATTRS, S * B, 1),
+                                        need_input_grad=True, input_grad_out=dzcat)
+            else:
+                for i in range(N_ATTRS):
+                    L.backward_tape(self.dec_plans[i], tape_dec[i], dlog_attr[i * S:(i + 1) * S].reshape(S * B, 1),
+                                    need_input_grad=True, input_grad_out=dzcat[i], input_grad_accumulate=False)
         # ---- image decoder in term order: [0,1] kept, [2..19] statistics only, sampled kept
         dplan = m.image_decoder.plan()
         logit_a, tape_a = L.forward_tape(dplan, z[0:2].reshape(2 * B, D), groups=2)
@@ -650,17 +666,21 @@ class Celeba19Step(_StepBase):
         m, B, D, n_img = self.model, self.B, self.D, self.n_img
         c = self._carry
         g_img = torch.empty_like(c['heads_img'])
-        g_attr = [torch.empty_like(h) for h in c['heads_attr']]
+        g_attr_all = torch.empty(N_ATTRS, B, 2 * D, dtype=torch.float32, device=self.dev)
+        g_attr = [g_attr_all[i] for i in range(N_ATTRS)]
         g_list = [g_img[k * B:(k + 1) * B] for k in range(n_img)] + g_attr
         K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
                   self.coef[2], [g[:, :D] for g in g_list], [g[:, D:] for g in g_list], m.POE_VARIANT,
                   dkl_per_term=True)
         with self._branch():
-            for i in range(N_ATTRS):
-                L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
+            if self.grouped:
+                L.backward_tape_grouped(self.enc_group, c['tape_enc'], g_attr_all)
+            else:
+                for i in range(N_ATTRS):
+                    L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
         d_hd = L.backward_tape(self.head, c['tape_head'], g_img, need_input_grad=True)
         d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
         K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
         L.backward_tape(self.trunk, c['tape_trunk'], d_h)
         self._join()
-        c['keep_b'] = (g_img, g_attr)
+        c['keep_b'] = (g_img, g_attr_all)

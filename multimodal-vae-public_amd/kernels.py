@@ -91,6 +91,73 @@ def linear_wgrad(dy, x, dw, db=None, accumulate=False):
           'mvae_linear_wgrad')
 
 
+# ---------------------------------------------------------------------------- grouped Linear
+# G problems of one shape per launch: activations are [G, rows, width] tensors, parameters are
+# (tensor of group 0, stride in floats to the same tensor of the next group) -- the experts' slices
+# of the parameter arena.
+def _g3(t, name):
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) < t.shape[1] * t.stride(1):
+        raise RuntimeError('%s must be a [groups, rows, width] tensor with unit column stride' % name)
+    return t
+
+
+def linear_fwd_grouped(x, w0, w_gs, b0, b_gs, pre=None, act=None):
+    _need_gpu(x, w0, b0, pre, act)
+    G, M, K = _g3(x, 'x').shape
+    N = w0.shape[0]
+    out = _g3(pre if pre is not None else act, 'output')
+    if pre is not None and act is not None and (act.stride() != pre.stride()):
+        raise RuntimeError('pre and act must share a layout')
+    check(_lib.lib().mvae_linear_fwd_grouped(_ptr(x), x.stride(1), x.stride(0), _ptr(w0), w_gs, _ptr(b0), b_gs,
+                                             _ptr(pre), _ptr(act), out.stride(1), out.stride(0), G, M, N, K,
+                                             _stream()), 'mvae_linear_fwd_grouped')
+
+
+def linear_dgrad_grouped(dy, w0, w_gs, dx, pre_in=None, accumulate=False):
+    _need_gpu(dy, w0, dx, pre_in)
+    G, M, N = _g3(dy, 'dy').shape
+    K = w0.shape[1]
+    _g3(dx, 'dx')
+    if pre_in is not None and (not pre_in.is_contiguous() or pre_in.shape != (G, M, K)):
+        raise RuntimeError('pre_in must be a contiguous [G, M, K] tensor')
+    check(_lib.lib().mvae_linear_dgrad_grouped(_ptr(dy), dy.stride(1), dy.stride(0), _ptr(w0), w_gs, _ptr(dx),
+                                               dx.stride(1), dx.stride(0), _ptr(pre_in), M * K, G, M, N, K,
+                                               ACCUMULATE if accumulate else 0, _stream()),
+          'mvae_linear_dgrad_grouped')
+
+
+def linear_wgrad_grouped(dy, x, dw0, dw_gs, db0=None, db_gs=0, accumulate=False):
+    _need_gpu(dy, x, dw0, db0)
+    G, M, N = _g3(dy, 'dy').shape
+    K = _g3(x, 'x').shape[2]
+    check(_lib.lib().mvae_linear_wgrad_grouped(_ptr(dy), dy.stride(1), dy.stride(0), _ptr(x), x.stride(1),
+                                               x.stride(0), _ptr(dw0), dw_gs, _ptr(db0), db_gs, G, M, N, K,
+                                               ACCUMULATE if accumulate else 0, _stream()),
+          'mvae_linear_wgrad_grouped')
+
+
+def embedding_swish_fwd_grouped(idx, w0, w_gs, act):
+    """idx: float [R, G] ({0,1} columns, celeba19's attrs); act [G, R, width] contiguous."""
+    _need_gpu(idx, w0, act)
+    if idx.dtype != torch.float32 or idx.dim() != 2 or idx.stride(1) != 1 or not act.is_contiguous():
+        raise RuntimeError('grouped embedding wants a float [rows, groups] index and a contiguous output')
+    R, G = idx.shape
+    check(_lib.lib().mvae_embedding_swish_fwd_grouped(_ptr(idx), idx.stride(0), 1, _ptr(w0), w_gs, _ptr(act),
+                                                      act.stride(0), G, R, w0.shape[0], w0.shape[1], _stream()),
+          'mvae_embedding_swish_fwd_grouped')
+
+
+def embedding_swish_bwd_grouped(idx, w0, w_gs, dact, dw0, accumulate=False):
+    _need_gpu(idx, w0, dact, dw0)
+    if idx.dtype != torch.float32 or idx.dim() != 2 or idx.stride(1) != 1 or not dact.is_contiguous():
+        raise RuntimeError('grouped embedding wants a float [rows, groups] index and a contiguous gradient')
+    R, G = idx.shape
+    check(_lib.lib().mvae_embedding_swish_bwd_grouped(_ptr(idx), idx.stride(0), 1, _ptr(w0), w_gs, _ptr(dact),
+                                                      dact.stride(0), _ptr(dw0), G, R, w0.shape[0], w0.shape[1],
+                                                      ACCUMULATE if accumulate else 0, _stream()),
+          'mvae_embedding_swish_bwd_grouped')
+
+
 # ---------------------------------------------------------------------------- Conv 4x4
 def _conv_call(name, a, b, c, d, B, Cin, H, W, Cout, stride, pad, repack=False):
     if repack:      # dgrad-form launches repack the weights (Cout*Cin*16 floats) into scratch first

@@ -468,6 +468,123 @@ def _lin_wgrad(op, g, x):
         K.linear_wgrad(g, x, dw, db, accumulate=acc)
 
 
+# ----------------------------------------------------------------------------- grouped executor
+class GroupedPlans(object):
+    """G stacks of IDENTICAL structure -- Embedding / Linear / paired heads / Swish only -- executed
+    one grouped launch per layer (celeba19's 18 attribute encoders and decoders,
+    celeba19/model.py:29-30).  Works on the experts' slices of the parameter arena: layer j of
+    expert g must sit at a uniform stride from layer j of expert 0, which the arena's module
+    order guarantees for identical sub-modules laid out back to back."""
+
+    def __init__(self, plans):
+        self.plans = [list(pl) for pl in plans]
+        self.G = len(self.plans)
+        p0 = self.plans[0]
+        for pl in self.plans:
+            if len(pl) != len(p0):
+                raise RuntimeError('grouped stacks differ in depth')
+            for a, b in zip(pl, p0):
+                if a.kind != b.kind or a.act != b.act or a.drop != 0 or a.kind not in ('emb', 'lin', 'lin2'):
+                    raise RuntimeError('grouped stacks must be identical Embedding/Linear/Swish chains')
+        if p0[-1].act:
+            raise RuntimeError('grouped stacks must end in a plain Linear')
+
+    def _params(self, j):
+        """per expert: (weight, bias or None) tensors of layer j (joined views for paired heads)"""
+        out = []
+        for pl in self.plans:
+            op = pl[j]
+            out.append((op.mod.weight, None) if op.kind == 'emb' else _lin_weights(op))
+        return out
+
+    @staticmethod
+    def _stride(ts):
+        if ts[0] is None:
+            return 0
+        if len(ts) == 1:
+            return 0
+        d = (ts[1].data_ptr() - ts[0].data_ptr()) // 4
+        for g, t in enumerate(ts):
+            if t.shape != ts[0].shape or t.data_ptr() - ts[0].data_ptr() != 4 * d * g:
+                raise RuntimeError('grouped stacks need uniformly strided parameters (one arena, identical '
+                                   'experts laid out back to back)')
+        if d <= 0:
+            raise RuntimeError('grouped parameter stride must be positive')
+        return d
+
+    def layer(self, j):
+        """(w0, w_stride, b0, b_stride) of layer j -- data tensors"""
+        ps = self._params(j)
+        ws, bs = [w for w, _ in ps], [b for _, b in ps]
+        return ws[0].detach(), self._stride(ws), (None if bs[0] is None else bs[0].detach()), self._stride(bs)
+
+    def grads(self, j):
+        """Gradient destinations of layer j for all experts: (dw0, db0 or None, accumulate)."""
+        accs = set()
+        for pl in self.plans:
+            op = pl[j]
+            ps = list(op.mod.parameters()) if op.kind != 'lin2' else [q for h in op.mod.heads for q in h.parameters()]
+            for q in ps:
+                accs.add(grad_target(q)[1])
+        if len(accs) != 1:
+            raise RuntimeError('grouped gradients out of sync')
+        op = self.plans[0][j]
+        if op.kind == 'lin2':
+            a, b = op.mod.heads
+            arena = a.weight._arena
+            return arena.joined(a.weight, b.weight)[1], arena.joined(a.bias, b.bias)[1], accs.pop()
+        return op.mod.weight.grad, (op.mod.bias.grad if getattr(op.mod, 'bias', None) is not None else None), accs.pop()
+
+
+def forward_tape_grouped(gp, x, final_out=None):
+    """x: float [rows, G] index columns when the stacks start with an Embedding, else
+    [G, rows, width].  Returns (output [G, rows, N], tape)."""
+    tape, h = [], x
+    G = gp.G
+    last = len(gp.plans[0]) - 1
+    for j, op in enumerate(gp.plans[0]):
+        w0, w_gs, b0, b_gs = gp.layer(j)
+        if op.kind == 'emb':
+            act = torch.empty(G, h.shape[0], w0.shape[1], dtype=torch.float32, device=h.device)
+            K.embedding_swish_fwd_grouped(h, w0, w_gs, act)
+            tape.append((h, None))
+            h = act
+            continue
+        M, N = h.shape[1], w0.shape[0]
+        if j == last and final_out is not None:
+            pre = final_out.reshape(G, M, N)
+        else:
+            pre = torch.empty(G, M, N, dtype=torch.float32, device=h.device)
+        act = torch.empty(G, M, N, dtype=torch.float32, device=h.device) if op.act else None
+        K.linear_fwd_grouped(h, w0, w_gs, b0, b_gs, pre, act)
+        tape.append((h, pre if op.act else None))
+        h = act if op.act else pre
+    return h, tape
+
+
+def backward_tape_grouped(gp, tape, g, need_input_grad=False, input_grad_out=None):
+    """g: [G, rows, N] gradient of the stacks' outputs.  Parameter gradients go to the arena."""
+    plan = gp.plans[0]
+    for j in range(len(plan) - 1, -1, -1):
+        op = plan[j]
+        x, _ = tape[j]
+        w0, w_gs, _, b_gs = gp.layer(j)
+        dw0, db0, acc = gp.grads(j)
+        if op.kind == 'emb':
+            K.embedding_swish_bwd_grouped(x, w0, w_gs, g.contiguous(), dw0, accumulate=acc)
+            return None
+        K.linear_wgrad_grouped(g, x, dw0, w_gs, db0, b_gs, accumulate=acc)
+        if j > 0 or need_input_grad:
+            pre_in = tape[j - 1][1] if (j > 0 and plan[j - 1].kind != 'emb') else None
+            if j == 0 and input_grad_out is not None:
+                dx = input_grad_out
+            else:
+                dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            K.linear_dgrad_grouped(g, w0, w_gs, dx, pre_in)
+            g = dx
+    return g if need_input_grad else None
+
+
 # ----------------------------------------------------------------------------- autograd bridge
 class StackFn(torch.autograd.Function):
     """autograd wrapper used by the module surface.  Parameters are passed as inputs only so

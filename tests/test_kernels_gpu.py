@@ -110,6 +110,75 @@ CONV_CASES = [(4, 3, 64, 32, 2, 1), (3, 32, 32, 64, 2, 1), (2, 64, 16, 128, 2, 1
               (5, 1, 28, 64, 2, 1), (2, 64, 14, 128, 2, 1), (1, 5, 6, 7, 1, 0), (3, 2, 4, 3, 2, 1)]
 
 
+# ----------------------------------------------------------------------------- grouped Linear / Embedding
+GROUPED_SHAPES = [(18, 256, 512, 512), (18, 768, 1, 512), (18, 768, 512, 100), (18, 64, 200, 512),
+                  (3, 37, 10, 12), (5, 130, 7, 33)]
+
+
+def _arena_like(G, shape, pad, seed):
+    """G tensors of ``shape`` at a uniform stride inside one flat buffer (like the experts' slices
+    of the parameter arena); returns (flat device buffer, [views], stride in floats)."""
+    n = int(np.prod(shape))
+    stride = (n + pad + 3) // 4 * 4
+    flat = (g(G * stride, seed=seed) * 0.1).to(DEV)
+    views = [flat[i * stride:i * stride + n].view(*shape) for i in range(G)]
+    return flat, views, stride
+
+
+@pytest.mark.parametrize('G,M,N,Kd', GROUPED_SHAPES)
+def test_linear_grouped(G, M, N, Kd):
+    x = g(G, M, Kd, seed=1)
+    _, ws, w_gs = _arena_like(G, (N, Kd), 40, 2)
+    _, bs, b_gs = _arena_like(G, (N,), 8, 3)
+    w = torch.stack([t.cpu() for t in ws]); b = torch.stack([t.cpu() for t in bs])
+    pre_ref = torch.einsum('gmk,gnk->gmn', x, w) + b[:, None, :]
+    pre = torch.empty(G, M, N, device=DEV); act = torch.empty_like(pre)
+    K.linear_fwd_grouped(dev(x), ws[0], w_gs, bs[0], b_gs, pre, act)
+    assert_close(pre, pre_ref, 'grouped fwd pre')
+    assert_close(act, swish(pre_ref), 'grouped fwd act')
+    # dgrad with the producer's swish' fused
+    dy = g(G, M, N, seed=4); pre_in = g(G, M, Kd, seed=5)
+    dx = torch.empty(G, M, Kd, device=DEV)
+    K.linear_dgrad_grouped(dev(dy), ws[0], w_gs, dx, dev(pre_in))
+    assert_close(dx, torch.einsum('gmn,gnk->gmk', dy, w) * swish_grad(pre_in), 'grouped dgrad')
+    # wgrad + bias gradient, overwrite then accumulate
+    dwf, dws, dw_gs = _arena_like(G, (N, Kd), 40, 6)
+    dbf, dbs, db_gs = _arena_like(G, (N,), 8, 7)
+    dwf_before = dwf.clone()
+    K.linear_wgrad_grouped(dev(dy), dev(x), dws[0], dw_gs, dbs[0], db_gs)
+    dw_ref = torch.einsum('gmn,gmk->gnk', dy, x); db_ref = dy.sum(1)
+    assert_close(torch.stack([t for t in dws]), dw_ref, 'grouped wgrad')
+    assert_close(torch.stack([t for t in dbs]), db_ref, 'grouped bias grad')
+    n = N * Kd
+    for i in range(G):      # the padding between the experts' slices is untouched
+        assert torch.equal(dwf[i * dw_gs + n:(i + 1) * dw_gs], dwf_before[i * dw_gs + n:(i + 1) * dw_gs])
+    K.linear_wgrad_grouped(dev(dy), dev(x), dws[0], dw_gs, dbs[0], db_gs, accumulate=True)
+    assert_close(torch.stack([t for t in dws]), 2 * dw_ref, 'grouped wgrad accumulate')
+    assert_close(torch.stack([t for t in dbs]), 2 * db_ref, 'grouped bias grad accumulate')
+
+
+def test_embedding_grouped():
+    G, R, W = 18, 300, 512
+    idx = torch.randint(0, 2, (R, G), generator=torch.Generator().manual_seed(1)).float()
+    _, ws, w_gs = _arena_like(G, (2, W), 12, 2)
+    w = torch.stack([t.cpu() for t in ws])
+    act = torch.empty(G, R, W, device=DEV)
+    K.embedding_swish_fwd_grouped(dev(idx), ws[0], w_gs, act)
+    ref = torch.stack([swish(w[i][idx[:, i].long()]) for i in range(G)])
+    assert_close(act, ref, 'grouped embedding fwd')
+    dact = g(G, R, W, seed=3)
+    dwf, dws, dw_gs = _arena_like(G, (2, W), 12, 4)
+    assert dw_gs == w_gs
+    K.embedding_swish_bwd_grouped(dev(idx), ws[0], w_gs, dev(dact), dws[0])
+    dref = []
+    for i in range(G):
+        d = torch.zeros(2, W)
+        d.index_add_(0, idx[:, i].long(), dact[i])
+        dref.append(d * swish_grad(w[i]))
+    assert_close(torch.stack([t for t in dws]), torch.stack(dref), 'grouped embedding bwd')
+
+
+
 @pytest.mark.parametrize('B,Cin,H,Cout,s,p', CONV_CASES)
 def test_conv2d(B, Cin, H, Cout, s, p):
     x = g(B, Cin, H, H, seed=20).requires_grad_()
