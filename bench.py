@@ -204,8 +204,15 @@ def main():
     ap.add_argument('--workload', default='mnist', choices=sorted(DEFAULT_BATCH))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--force-tiling', default=None,
+                    help='tuning aid: wm,wn,splits,kwaves forwarded to mvae_debug_set_tiling / _kwaves')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline / cpu_baseline / also')
     args = ap.parse_args()
+    if args.force_tiling:
+        from mvae_amd import _lib
+        wm, wn, sp, kw = (int(v) for v in args.force_tiling.split(','))
+        _lib.lib().mvae_debug_set_tiling(wm, wn, sp)
+        _lib.lib().mvae_debug_set_kwaves(kw)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

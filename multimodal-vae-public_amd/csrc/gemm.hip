@@ -609,6 +609,25 @@ __global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int spl
     e.put(i, j, s);
 }
 
+// few splits, J % 4 == 0: one thread per 4 consecutive outputs, float4 partial loads
+template <class E>
+__global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int splits, E e) {
+    const int jq = sink.J >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)sink.I * jq) return;
+    const int i = (int)(idx / jq), j = (int)(idx - (size_t)i * jq) * 4;
+    const float *src = sink.ws + (size_t)i * sink.J + j;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)z * sink.stride);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (e.col(j)) e.put(i, j, s.x);
+    if (e.col(j + 1)) e.put(i, j + 1, s.y);
+    if (e.col(j + 2)) e.put(i, j + 2, s.z);
+    if (e.col(j + 3)) e.put(i, j + 3, s.w);
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_few_kernel(const float *ws, float *out, int n, int splits,
                                                                 size_t stride, int accumulate) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -737,6 +756,10 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
         if (pl.splits > 16) {
             dim3 grid((J + 31) / 32, I);
             hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        } else if (J % 4 == 0 && sink.stride % 4 == 0 && aligned16(sink.ws)) {
+            const size_t nvec = (size_t)I * (J / 4);
+            hipLaunchKernelGGL((finish_few_vec_kernel<E>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, sink,
+                               pl.splits, e);
         } else {
             dim3 grid((J + 255) / 256, I);
             hipLaunchKernelGGL((finish_few_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);

@@ -45,14 +45,15 @@ __global__ __launch_bounds__(256) void embedding_swish_fwd_kernel(const void *id
     }
 }
 
-// dw[c,j] (+)= swish'(w[c,j]) * sum_{r: idx[r]==c} dact[r,j].  Block = 64 columns x 4 row lanes of
-// class c; each lane sums its rows in order and the 4 partials are added in a fixed order:
+// dw[c,j] (+)= swish'(w[c,j]) * sum_{r: idx[r]==c} dact[r,j].  Block = 64 columns x 16 row lanes of
+// class c; each lane sums its rows in order and the 16 partials are added in a fixed order:
 // deterministic (the reference's index_add_ backward is not).
-__global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *idx, int is_float, const float *w,
+constexpr int EMB_LANES = 16;
+__global__ __launch_bounds__(64 * EMB_LANES) void embedding_swish_bwd_kernel(const void *idx, int is_float, const float *w,
                                                                   const float *dact, float *dw, int R,
                                                                   int n_classes, int width, int accumulate,
                                                                   size_t idx_gs, size_t w_gs, size_t dact_gs) {
-    __shared__ float part[4][64];
+    __shared__ float part[EMB_LANES][64];
     const int g = blockIdx.z;
     idx = is_float ? (const void *)((const float *)idx + g * idx_gs) : (const void *)((const int64_t *)idx + g * idx_gs);
     w += g * w_gs; dw += g * w_gs; dact += g * dact_gs;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *id
     const int j = blockIdx.x * 64 + tx, c = blockIdx.y;
     float s = 0.f;
     if (j < width) {
-        const int per = (R + 3) / 4, r0 = ty * per, r1 = min(R, r0 + per);
+        const int per = (R + EMB_LANES - 1) / EMB_LANES, r0 = ty * per, r1 = min(R, r0 + per);
         for (int r = r0; r < r1; ++r) {
             int cr = read_index(idx, is_float, r);
             cr = min(max(cr, 0), n_classes - 1);
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void embedding_swish_bwd_kernel(const void *id
     part[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && j < width) {
-        s = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < EMB_LANES; q += 4) s += (part[q][tx] + part[q + 1][tx]) + (part[q + 2][tx] + part[q + 3][tx]);
         const size_t o = (size_t)c * width + j;
         s *= swish_grad_(w[o]);
         dw[o] = accumulate ? dw[o] + s : s;
@@ -221,7 +224,7 @@ MVAE_EXPORT int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, cons
                                          float *dw, int R, int n_classes, int width, int flags,
                                          mvae_stream_t stream) {
     if (!idx || !w || !dact || !dw || R <= 0 || n_classes <= 0 || width <= 0) return MVAE_ERR_ARG;
-    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, 1), dim3(256), 0,
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, 1), dim3(64 * EMB_LANES), 0,
                        (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
                        (flags & MVAE_ACCUMULATE) ? 1 : 0, (size_t)0, (size_t)0, (size_t)0);
     return mvae_launch_status();
@@ -232,7 +235,7 @@ MVAE_EXPORT int mvae_embedding_swish_bwd_grouped(const void *idx, int idx_is_flo
                                                  int R, int n_classes, int width, int flags, mvae_stream_t stream) {
     if (!idx || !w || !dact || !dw || G <= 0 || G > 65535 || R <= 0 || n_classes <= 0 || width <= 0)
         return MVAE_ERR_ARG;
-    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, G), dim3(256), 0,
+    hipLaunchKernelGGL(embedding_swish_bwd_kernel, dim3((width + 63) / 64, n_classes, G), dim3(64 * EMB_LANES), 0,
                        (hipStream_t)stream, idx, idx_is_float, w, dact, dw, R, n_classes, width,
                        (flags & MVAE_ACCUMULATE) ? 1 : 0, idx_gs, w_gs, dact_gs);
     return mvae_launch_status();

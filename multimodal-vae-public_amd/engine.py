@@ -93,13 +93,16 @@ class _StepBase(object):
         # well under the 256 CUs, so the branches overlap instead of queueing
         n_streams = int(os.environ.get('MVAE_STREAMS', '2'))
         self.side = torch.cuda.Stream(device=self.dev) if n_streams >= 2 else None
-        # MVAE_STREAMS=4 also moves each branch's weight gradients to a further stream.  Measured
-        # SLOWER (MNIST B=512: 0.73 vs 0.55 ms/step): every fork is a cross-queue signal, and one
-        # per layer costs more than the overlap returns.  Coarse forks (3 per step) are the win.
-        self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else None
-        self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else None
+        # MVAE_STREAMS=3/4 (tuning aid, off by default): each branch queues its weight-gradient
+        # launches (layers.backward_tape ``deferred``) and runs them with ONE fork per backward
+        # chain on a further stream, so only the data-gradient chains stay serial.  Measured on
+        # MI355X: no gain (MNIST B=512 0.58-0.60 vs 0.56 ms/step, CelebA B=256 3.54-3.67 vs 3.58) --
+        # with two branches in flight the kernels already fill the CUs; a fork per LAYER was 30 %
+        # slower (every fork is a cross-queue signal).
+        self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 3 else None
+        self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else self.wg_main
+        self._wg_pending = []
         self._forked = False
-        self._held = []      # gradients the side branch's weight-gradient stream reads
 
     @contextlib.contextmanager
     def _branch(self):
@@ -113,15 +116,35 @@ class _StepBase(object):
         with torch.cuda.stream(self.side):
             yield
 
+    def _deferred(self):
+        """The list a backward chain queues its weight-gradient launches in (None: launch inline)."""
+        return [] if self.wg_main is not None else None
+
+    def _launch_deferred(self, fns, stream):
+        """Run the queued weight-gradient launches on ``stream``, ordered after everything the
+        CURRENT stream has launched.  Joined by ``_join_wgrad`` -- directly into the origin stream:
+        hipGraph capture (ROCm 7.0) crashes in EndCapture when a fork of a fork joins back into
+        its parent (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main')."""
+        if not fns:
+            return
+        stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(stream):
+            for fn in fns:
+                fn()
+        self._carry.setdefault('deferred', []).append(fns)     # the closures own the gradients
+        if stream not in self._wg_pending:
+            self._wg_pending.append(stream)
+
+    def _join_wgrad(self):
+        main = torch.cuda.current_stream(self.dev)
+        for s in self._wg_pending:
+            main.wait_stream(s)
+        self._wg_pending = []
+
     def _join(self):
         if self._forked:
             main = torch.cuda.current_stream(self.dev)
             main.wait_stream(self.side)
-            if self.wg_side is not None:
-                # forked from the side stream but joined HERE: hipGraph capture (ROCm 7.0) crashes
-                # in EndCapture when a stream joins back into a parent that is itself a fork
-                # (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main')
-                main.wait_stream(self.wg_side)
             self._forked = False
 
     # subclasses: _phase_a(image, label), _phase_b(), set_coefficients(beta), draw_noise()
@@ -291,7 +314,6 @@ class BimodalStep(_StepBase):
         if image.shape[0] != B:
             raise ValueError('engine was built for batch %d, got %d' % (B, image.shape[0]))
         c = self._carry = {}
-        self._held = c['held'] = []
         image = image.contiguous()
         n_up = 2  # each encoder is called twice per step in the reference
         # ---- encoders: label on the side stream, image on this one
@@ -332,9 +354,10 @@ class BimodalStep(_StepBase):
             else:
                 K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
                                  dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
+            wl = self._deferred()
             g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
-                                    defer_input_grad=True, wgrad_stream=self.wg_side,
-                                    wgrad_join=False, held=self._held)
+                                    defer_input_grad=True, deferred=wl)
+            self._launch_deferred(wl, self.wg_side)
         # ---- image branch (this stream)
         zi = z[i0:i0 + ni].reshape(ni * B, D)
         logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
@@ -348,8 +371,10 @@ class BimodalStep(_StepBase):
         dlog_img = torch.empty_like(li)
         K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
                          rows_per_group=B, target_rows=B)
+        wi = self._deferred()
         g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
-                                groups=ni, defer_input_grad=True, wgrad_stream=self.wg_main)
+                                groups=ni, defer_input_grad=True, deferred=wi)
+        self._launch_deferred(wi, self.wg_main)     # decoder weight gradients run behind phase B
         self._join()
         # ---- ELBO per term and total (mnist/train.py:57-58,214)
         elbo = self.elbo
@@ -365,6 +390,8 @@ class BimodalStep(_StepBase):
         c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_lbl=heads_lbl,
                  keep=(z, kl, logits_lbl, tape_dl, rows_lbl, dlog_lbl, g_lbl, logits_img, tape_di,
                        rows_img, dlog_img, g_img, lbl_in))
+        if self._comm is not None or self.on_bucket_ready is not None:
+            self._join_wgrad()      # data parallel: the decoder bucket is all-reduced after phase A
 
     def _phase_b(self):
         m, B, D = self.model, self.B, self.D
@@ -377,19 +404,28 @@ class BimodalStep(_StepBase):
         K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
                   self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
                   dkl_per_term=True)
-        # ---- encoders backward
+        # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
+        #      gradients spread over this stream and the two weight-gradient streams
+        wl, wi = self._deferred(), self._deferred()
         with self._branch():
-            L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, wgrad_stream=self.wg_side,
-                            wgrad_join=False, held=self._held)
+            L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
         if self.has_dropout:
-            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True,
-                                   wgrad_stream=self.wg_main)
+            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True, deferred=wi)
             d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
             K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
-            L.backward_tape(self.trunk, c['tape_trunk'], d_h, wgrad_stream=self.wg_main)
+            L.backward_tape(self.trunk, c['tape_trunk'], d_h, deferred=wi)
         else:
-            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, wgrad_stream=self.wg_main)
+            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, deferred=wi)
         self._join()
+        if wi is not None:
+            fns = wi + wl
+            n = len(fns)
+            self._launch_deferred(fns[:n // 3], self.wg_main)
+            self._launch_deferred(fns[n // 3:2 * n // 3], self.wg_side)
+            for fn in fns[2 * n // 3:]:
+                fn()
+            c.setdefault('deferred', []).append(fns)
+        self._join_wgrad()
         c['keep_b'] = (g_heads_img, g_heads_lbl)
 
 

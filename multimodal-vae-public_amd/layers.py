@@ -322,8 +322,7 @@ def _producer(plan, tape, i):
 
 
 def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out=None,
-                  input_grad_accumulate=False, defer_input_grad=False, wgrad_stream=None,
-                  wgrad_join=True, held=None):
+                  input_grad_accumulate=False, defer_input_grad=False, deferred=None):
     """Backward through the plan.  ``g`` = gradient w.r.t. the stack output.  Parameter
     gradients go to ``p.grad`` (the arena); returns the input gradient or None.
     ``input_grad_out`` (stacks that start with a Linear): write -- or with
@@ -331,26 +330,14 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
     decoders) instead of allocating one.  ``defer_input_grad`` (same stacks): skip the first
     Linear's input gradient and return the gradient w.r.t. its OUTPUT; the caller finishes with
     ``first_linear_dgrad`` -- used when two stacks run on different streams but share dz.
-    ``wgrad_stream``: launch the weight-gradient kernels there, so only the data-gradient
-    chain is serial; joined before returning unless ``wgrad_join`` is False -- then the caller
-    joins it and keeps ``held`` (a list that receives every gradient tensor the weight-gradient
-    kernels read) alive until it has."""
-    cur = torch.cuda.current_stream(g.device) if wgrad_stream is not None else None
-    if held is None:
-        held = []       # every gradient a wgrad reads stays allocated until the join
-
+    ``deferred``: a list that receives the weight-gradient launches as closures instead of
+    running them here, so only the data-gradient chain is serial; the caller runs them (in order)
+    on another stream and keeps the list alive until that stream is joined."""
     def side(fn):
-        if wgrad_stream is None:
+        if deferred is None:
             fn()
-            return
-        wgrad_stream.wait_stream(cur)
-        with torch.cuda.stream(wgrad_stream):
-            fn()
-
-    def finish(out):
-        if wgrad_stream is not None and wgrad_join:
-            cur.wait_stream(wgrad_stream)
-        return out
+        else:
+            deferred.append(fn)
 
     last = len(plan) - 1
     while last >= 0 and plan[last].kind == 'view':
@@ -376,10 +363,9 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             g = g.reshape(x.shape[0], -1)
             if g.stride(1) != 1:
                 g = g.contiguous()
-            held.append(g)
             side(lambda op=op, g=g, x=x: _lin_wgrad(op, g, x))
             if defer_input_grad and i == first:
-                return finish(g)
+                return g
             if want_dx:
                 w, _ = _lin_weights(op)
                 acc = False
@@ -396,10 +382,10 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             s, p = m.stride[0], m.padding[0]
             out_shape = _conv_out_shape(op, x)
             g = g.reshape(out_shape).contiguous()
-            dw, acc = grad_target(m.weight)
-            held.append(g)
-            side(lambda op=op, g=g, x=x, dw=dw, acc=acc, s=s, p=p:
-                 (K.conv2d_wgrad if op.kind == 'conv' else K.convT2d_wgrad)(g, x, dw, s, p, accumulate=acc))
+            def conv_wgrad(op=op, m=m, g=g, x=x, s=s, p=p):
+                dw, acc = grad_target(m.weight)
+                (K.conv2d_wgrad if op.kind == 'conv' else K.convT2d_wgrad)(g, x, dw, s, p, accumulate=acc)
+            side(conv_wgrad)
             if want_dx:
                 dx = torch.empty_like(x)
                 (K.conv2d_dgrad if op.kind == 'conv' else K.convT2d_dgrad)(
@@ -420,11 +406,12 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
                 raise RuntimeError('BatchNorm input must come from a non-activated layer')
             g = dx
         elif op.kind == 'emb':
-            m = op.mod
-            dw, acc = grad_target(m.weight)
-            K.embedding_swish_bwd(saved[0], m.weight.detach(), g.contiguous(), dw, accumulate=acc)
+            def emb_wgrad(m=op.mod, idx=saved[0], g=g.contiguous()):
+                dw, acc = grad_target(m.weight)
+                K.embedding_swish_bwd(idx, m.weight.detach(), g, dw, accumulate=acc)
+            side(emb_wgrad)
             g = None
-    return finish(g if need_input_grad else None)
+    return g if need_input_grad else None
 
 
 def first_linear_dgrad(plan, g, out, accumulate):

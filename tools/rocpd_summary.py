@@ -32,7 +32,36 @@ def main(path):
                                                                  100.0 * tot / total, name))
 
 
-if __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == '--pmc'):
+def timeline(path, tail=0.5):
+    """Busy / idle analysis of the last ``tail`` fraction of the trace (the timed, graph-replayed
+    steps): span, union of kernel intervals (GPU busy), sum of durations (> union when streams
+    overlap), and the idle gaps between kernels."""
+    c = sqlite3.connect(path)
+    rows = sorted(c.execute('select start, end, name from kernels').fetchall())
+    rows = rows[int(len(rows) * (1.0 - tail)):]
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    busy, cur_s, cur_e, gaps = 0, rows[0][0], rows[0][1], []
+    for s, e, _ in rows[1:]:
+        if s > cur_e:
+            busy += cur_e - cur_s
+            gaps.append(s - cur_e)
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    tot = sum(e - s for s, e, _ in rows)
+    gaps.sort()
+    print('# timeline of the last %d kernels of %s' % (len(rows), path))
+    print('span_us %.1f  busy_us %.1f (%.1f%%)  sum_of_durations_us %.1f (overlap x%.2f)  kernels %d' % (
+        (t1 - t0) / 1e3, busy / 1e3, 100.0 * busy / (t1 - t0), tot / 1e3, tot / max(busy, 1), len(rows)))
+    if gaps:
+        print('idle gaps: n %d  total_us %.1f  median_us %.2f  p90_us %.2f  max_us %.1f' % (
+            len(gaps), sum(gaps) / 1e3, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, gaps[-1] / 1e3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == '--timeline':
+    timeline(sys.argv[1])
+elif __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == '--pmc'):
     main(sys.argv[1])
 
 
