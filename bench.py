@@ -109,31 +109,50 @@ def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True):
 
 
 def roofline_from_profile(eng, opt, batches, n_steps=3):
-    """Eager steps with every launch bracketed by HIP events on the launch stream."""
+    """Which launches make up a step, and how fast each runs.
+
+    Pass 1 (eager, ONE stream): every launcher of kernels.py is bracketed by HIP events and tagged
+    with its algorithmic work -- gives the call list (name, shape, calls per step).  Pass 2: each
+    distinct GEMM-shaped call, and the busiest HBM-bound one, is re-issued 20x inside a hipGraph and
+    timed with HIP events on the launch stream (KernelProfile.steady_state_ms): the average launch
+    duration with the queue kept full, free of host enqueue gaps.  achieved = algorithmic flops of
+    the call / that duration."""
     from mvae_amd.profiler import GEMM_COSTS, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, KernelProfile
-    for i in range(2):
-        eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
-    with KernelProfile() as prof:
-        for i in range(n_steps):
-            eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
-            opt.step()
-    rows = prof.summary()
-    for r in rows:
-        r['ms_per_step'] = r['ms_total'] / n_steps
-    gemm = [r for r in rows if r['name'] in GEMM_COSTS]
+    streams = (eng.side, eng.wg_main, eng.wg_side)
+    eng.side = eng.wg_main = eng.wg_side = None          # single stream for the call census
+    try:
+        for i in range(2):
+            eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
+        with KernelProfile() as prof:
+            for i in range(n_steps):
+                eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
+                opt.step()
+        rows = prof.summary()
+        gemm = [r for r in rows if r['name'] in GEMM_COSTS]
+        for r in gemm:
+            r['ms_avg'] = prof.steady_state_ms(r['name'], r['key'])
+            r['ms_total'] = r['ms_avg'] * r['calls']
+            r['tflops'] = r['flops'] / (r['ms_avg'] * 1e-3) / 1e12
+        hbm = [r for r in rows if r['name'] not in GEMM_COSTS and r['bytes'] > 0]
+        if hbm:
+            top = max(hbm, key=lambda r: r['ms_total'])
+            top['ms_avg'] = prof.steady_state_ms(top['name'], top['key'])
+            top['gbs'] = top['bytes'] / (top['ms_avg'] * 1e-3) / 1e9
+    finally:
+        eng.side, eng.wg_main, eng.wg_side = streams
+    gemm.sort(key=lambda r: -r['ms_total'])
     dom = gemm[0]
     flops_step = sum(r['flops'] * r['calls'] for r in gemm) / n_steps
     ms_gemm = sum(r['ms_total'] for r in gemm) / n_steps
-    ms_all = sum(r['ms_total'] for r in rows) / n_steps
     roof = {
         'bound': 'mfma', 'kernel': 'igemm_kernel<%s %s>' % (dom['name'], dom['key']),
         'achieved': round(dom['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+        'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic_for(dom['name'], dom['key']),
         'avg_launch_ms': round(dom['ms_avg'], 5), 'algorithmic_flops_per_launch': dom['flops'],
+        'timing': 'HIP events around 5 replays of a hipGraph of 20 launches, on the launch stream',
         'all_gemm_kernels': {'tflops': round(flops_step / (ms_gemm * 1e-3) / 1e12, 3),
                              'frac': round(flops_step / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                              'ms_per_step': round(ms_gemm, 4), 'gflop_per_step': round(flops_step / 1e9, 3)},
-        'kernel_ms_per_step_eager': round(ms_all, 4),
     }
     conv = [r for r in gemm if r['name'].startswith('conv')]
     if conv:
@@ -142,15 +161,28 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
         roof['conv_kernels'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 3),
                                 'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 'ms_per_step': round(ms, 4), 'gflop_per_step': round(fl / 1e9, 3)}
-    hbm = [r for r in rows if r['name'] not in GEMM_COSTS and r['bytes'] > 0]
     if hbm:
-        top = max(hbm, key=lambda r: r['ms_total'])
         roof['top_hbm_kernel'] = {'kernel': top['name'], 'gbs': round(top['gbs'], 1),
                                   'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5)}
-    top5 = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_per_step'], 4),
-             'calls_per_step': r['calls'] / n_steps, 'tflops': round(r['tflops'], 2)} for r in rows[:6]]
-    roof['top_kernels'] = top5
+    roof['top_kernels'] = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_total'] / n_steps, 4),
+                            'calls_per_step': r['calls'] / n_steps, 'tflops': round(r['tflops'], 2)} for r in gemm[:6]]
     return roof
+
+
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+
+
+def traffic_for(name, key):
+    """HBM bytes per launch of the call from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
+    tools/traffic_probe.py + tools/rocpd_summary.py --pmc).  None when that call was not probed."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            table = json.load(f)
+    except (IOError, ValueError):
+        return None
+    ent = table.get('%s %s' % (name, key))
+    return None if ent is None else ent['hbm_bytes_per_launch']
 
 
 def cpu_baseline(kind, batch, budget_s=15.0):

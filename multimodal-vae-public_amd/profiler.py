@@ -68,7 +68,21 @@ def _conv_cost(kind):
     return cost
 
 
+def _lin_grouped_cost(which):
+    def cost(*a, **kw):
+        if which == 'fwd':            # (x[G,M,K], w0[N,K], ...)
+            (G, M, Kd), N = a[0].shape, a[1].shape[0]
+        elif which == 'dgrad':        # (dy[G,M,N], w0[N,K], ...)
+            (G, M, N), Kd = a[0].shape, a[1].shape[1]
+        else:                         # (dy[G,M,N], x[G,M,K], ...)
+            (G, M, N), Kd = a[0].shape, a[1].shape[2]
+        return 2.0 * G * M * N * Kd, 'G%d M%d N%d K%d' % (G, M, N, Kd)
+    return cost
+
+
 GEMM_COSTS = {
+    'linear_fwd_grouped': _lin_grouped_cost('fwd'), 'linear_dgrad_grouped': _lin_grouped_cost('dgrad'),
+    'linear_wgrad_grouped': _lin_grouped_cost('wgrad'),
     'linear_fwd': _lin_cost('fwd'), 'linear_dgrad': _lin_cost('dgrad'), 'linear_wgrad': _lin_cost('wgrad'),
     'conv2d_fwd': _conv_cost('conv2d_fwd'), 'conv2d_dgrad': _conv_cost('conv2d_dgrad'),
     'conv2d_wgrad': _conv_cost('conv2d_wgrad'), 'convT2d_fwd': _conv_cost('convT2d_fwd'),
@@ -77,12 +91,14 @@ GEMM_COSTS = {
 HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bwd', 'embedding_swish_fwd',
            'embedding_swish_bwd', 'poe_fwd', 'poe_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'bce_rowsum_fwd',
            'bce_rowsum_bwd', 'ce_fwd', 'ce_bwd', 'group_sums', 'randn_', 'bernoulli_', 'adam_step', 'fill_',
-           'dropout_fanout_fwd', 'dropout_fanin_bwd', 'bce_elem_fwd', 'bce_elem_bwd']
+           'dropout_fanout_fwd', 'dropout_fanin_bwd', 'bce_elem_fwd', 'bce_elem_bwd', 'embedding_swish_fwd_grouped',
+           'embedding_swish_bwd_grouped', 'block_gather', 'block_scatter_add']
 
 
 class KernelProfile(object):
     def __init__(self):
         self.records = []
+        self.last_call = {}      # (name, key) -> (launcher, args, kwargs) of the most recent call
         self._saved = {}
 
     def _wrap(self, name, fn, cost):
@@ -98,6 +114,7 @@ class KernelProfile(object):
             else:
                 flops, key, nbytes = 0.0, '', _numel_bytes(a, kw)
             self.records.append((name, key, flops, nbytes, e0, e1))
+            self.last_call[(name, key)] = (fn, a, kw)
             return out
         return wrapped
 
@@ -113,6 +130,32 @@ class KernelProfile(object):
             setattr(K, name, fn)
         self._saved = {}
         return False
+
+    def steady_state_ms(self, name, key, launches=20, replays=5):
+        """Average duration of ONE launch of the recorded call (name, key) with the GPU queue kept
+        full: ``launches`` copies captured into a hipGraph on a private stream, replayed
+        ``replays`` times between two HIP events on that stream.  The per-call event pairs of the
+        eager pass include host enqueue gaps (python is slower than a 10 us kernel); this does not."""
+        fn, a, kw = self.last_call[(name, key)]
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn(*a, **kw)                     # scratch of this stream exists before capture
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(launches):
+                fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            g.replay()
+            e0.record()
+            for _ in range(replays):
+                g.replay()
+            e1.record()
+        st.synchronize()
+        torch.cuda.current_stream().wait_stream(st)
+        return e0.elapsed_time(e1) / (launches * replays)
 
     def summary(self):
         """[{name, key, calls, ms_total, ms_avg, flops, bytes, tflops, gbs}] sorted by total time."""
