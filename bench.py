@@ -66,11 +66,11 @@ def annealing(step, total=2000):
     return min(1.0, float(step + 1) / total)
 
 
-def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True):
+def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, force_dp=False):
     import torch.distributed as dist
     model, eng, opt = build(kind, batch, device, world)
     dp = None
-    if world > 1:
+    if world > 1 or force_dp:
         from mvae_amd.parallel import DataParallel
         dp = DataParallel(model, eng)
     batches = [synthetic(kind, batch, 1234 + rank * 100 + i, device) for i in range(4)]
@@ -239,6 +239,8 @@ def main():
     ap.add_argument('--force-tiling', default=None,
                     help='tuning aid: wm,wn,splits,kwaves forwarded to mvae_debug_set_tiling / _kwaves')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline / cpu_baseline / also')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='tuning aid: run the data-parallel launch path (3 graphs + RCCL) even at world size 1')
     args = ap.parse_args()
     if args.force_tiling:
         from mvae_amd import _lib
@@ -253,15 +255,18 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29531')
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
     kind = args.workload
     batch = args.batch or DEFAULT_BATCH[kind]
 
     dt, loss, state = timed_run(kind, batch, args.steps, args.warmup, device, world, rank,
-                                use_graph=not args.no_graph)
+                                use_graph=not args.no_graph, force_dp=args.force_dp)
     out = {
         'metric': 'images/sec (MVAE train step)', 'value': round(world * batch * args.steps / dt, 1),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -286,7 +291,7 @@ def main():
                             'cpu_baseline': cpu_baseline('celeba', 256, budget_s=12.0)}]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

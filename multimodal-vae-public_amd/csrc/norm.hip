@@ -7,8 +7,8 @@
 // Work split: block (s, c, g) owns a slice of batch rows of channel c in group g and sweeps each
 // row's HW contiguous floats with float4 loads (lanes along the spatial axis; rows in parallel when
 // HW/4 < 256), no integer division in the loop.  Statistics are (count, mean, M2) per slice
-// with a two-pass sum inside the slice (the slice is L2-resident for the second pass) merged with
-// Chan's formula -- no E[x^2]-E[x]^2 cancellation.  All cross-block reductions go through the
+// from ONE sweep of the slice (sums of x - p and (x - p)^2 around a pivot p = the slice's first
+// element, so there is no E[x^2]-E[x]^2 cancellation), merged with Chan's formula.  All cross-block reductions go through the
 // caller's workspace in a fixed order: deterministic, no atomics.
 #include "common.h"
 
