@@ -189,20 +189,28 @@ def cpu_baseline(kind, batch, budget_s=15.0):
     """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
     host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s."""
     from oracle import models as OM, steps as OS
-    if kind == 'celeba19':
-        return None
+    import numpy as np
     cores = os.cpu_count() or 1
     cls, d = OM.MODELS[kind]
     torch.manual_seed(0)
     model = cls(d).train()
     opt = torch.optim.Adam(model.parameters(), lr=LR[kind])
     image, label = OS.synthetic_batch(kind, batch, 1234)
+    rng = np.random.RandomState(7)
 
     def one_step():
-        noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+        if kind == 'celeba19':      # 20 + 1 terms, a fresh random subset per step (approx-m 1)
+            from mvae_amd.engine import sample_subsets
+            terms = OS.celeba19_terms(sample_subsets(rng, 19, 1))
+            noise = OS.draw_celeba19_noise(batch, d, terms)
+        else:
+            noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
         t0 = time.perf_counter()
         opt.zero_grad()
-        total, _, _ = OS.bimodal_step(model, kind, image, label, noise, 1.0, LAMBDA_LABEL[kind], 0.5)
+        if kind == 'celeba19':
+            total, _, _ = OS.celeba19_step(model, image, label, terms, noise, 1.0, LAMBDA_LABEL[kind], 0.5)
+        else:
+            total, _, _ = OS.bimodal_step(model, kind, image, label, noise, 1.0, LAMBDA_LABEL[kind], 0.5)
         total.backward()
         opt.step()
         return time.perf_counter() - t0
@@ -210,7 +218,8 @@ def cpu_baseline(kind, batch, budget_s=15.0):
     # torch's CPU kernels do not scale to every core of a big host (oversubscribed small ops get
     # slower): probe a few intra-op thread counts and time the sample at the fastest one
     best = None
-    for th in [t for t in (8, 16, 32, 64) if t <= cores] or [cores]:
+    probe = (16, 32) if kind == 'celeba19' else (8, 16, 32, 64)      # a celeba19 step is ~20 model() calls
+    for th in [t for t in probe if t <= cores] or [cores]:
         torch.set_num_threads(th)
         one_step()                                   # warm this thread count
         dt = one_step()

@@ -133,6 +133,8 @@ int mvae_convT2d_k4_wgrad(const float *dy, const float *x, float *dw,
  *     Running statistics are updated sequentially for g = 0..G-1, each `n_updates` times
  *     (unbiased variance for the running estimate, biased for normalisation).
  *     save_mean / save_invstd are [G, C].  ws: mvae_bn_ws_bytes(G, C, B*HW).
+ *     y == NULL: statistics only (saved + running), for decoder passes the reference runs but
+ *     whose output it never reads (celeba19/train.py:277-283 -- SURVEY Appendix B-4).
  *     eval: y = swish?((x - running_mean) / sqrt(running_var + eps) * gamma + beta).
  * ---------------------------------------------------------------------------------- */
 size_t mvae_bn_ws_bytes(int G, int C, int n_per_group);

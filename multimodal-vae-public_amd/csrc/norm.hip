@@ -124,6 +124,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x
             running_var[c] = rv;
         }
     }
+    if (!y) return;                                        // statistics-only call
     const float ga = gamma[c], be = beta[c];
     auto one = [&](float v) {
         const float h = ga * ((v - mean) * invstd) + be;   // same expression as the backward's
@@ -243,14 +244,16 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
                                   int n_updates, const int *n_updates_dev, int flags, void *ws,
                                   size_t ws_bytes, mvae_stream_t stream) {
     BnShape sh;
-    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, x, y, nullptr, &sh))
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, x, y, nullptr, &sh))
         return MVAE_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
     if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(sh.S, C, G);
     hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(BN_THREADS), 0, st, x, (float *)ws, sh);
-    hipLaunchKernelGGL(bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
+    // y == NULL: only the (s = 0) block of each (channel, group) has work -- saved + running statistics
+    const dim3 agrid(y ? sh.S : 1, C, G);
+    hipLaunchKernelGGL(bn_fwd_apply_kernel, agrid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
                        save_mean, save_invstd, running_mean, running_var, sh, eps, momentum, n_updates,
                        n_updates_dev, (flags & MVAE_ACT_SWISH) ? 1 : 0);
     return mvae_launch_status();

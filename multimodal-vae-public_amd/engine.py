@@ -364,7 +364,8 @@ class BimodalStep(_StepBase):
         if self.has_bn and ni < T:
             # the reference also decodes the image for the label-only call: no loss, but its
             # BatchNorm running statistics advance (celeba/train.py:195)
-            L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni)
+            L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni,
+                           stats_only=True)
         P = logits_img[0].numel()
         li = logits_img.reshape(ni * B, P)
         rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
@@ -662,7 +663,7 @@ class Celeba19Step(_StepBase):
         dplan = m.image_decoder.plan()
         logit_a, tape_a = L.forward_tape(dplan, z[0:2].reshape(2 * B, D), groups=2)
         if self.faithful:
-            L.forward_tape(dplan, z[2:t_s].reshape(N_ATTRS * B, D), groups=N_ATTRS)
+            L.forward_tape(dplan, z[2:t_s].reshape(N_ATTRS * B, D), groups=N_ATTRS, stats_only=True)
         if M > 0:
             logit_c, tape_c = L.forward_tape(dplan, z[t_s:T].reshape(M * B, D), groups=M)
         P = logit_a[0].numel()

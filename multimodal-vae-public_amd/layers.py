@@ -227,16 +227,22 @@ def _lin_weights(op):
 
 
 def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, final_out=None,
-                 bn_updates_dev=None):
+                 bn_updates_dev=None, stats_only=False):
     """Run the plan.  Returns (output, tape); tape is None when not training.
     ``final_out``: preallocated [rows, N] destination for a stack that ends in a plain Linear
     (celeba19 collects its 18 attribute decoders' logits in one buffer).  ``bn_updates_dev``:
-    device int32[1] overriding ``bn_updates`` (number of running-statistics updates)."""
+    device int32[1] overriding ``bn_updates`` (number of running-statistics updates).
+    ``stats_only``: the pass exists only for its BatchNorm running-statistics side effect -- stop at
+    the last BatchNorm, which computes its statistics without writing an output; returns
+    (None, None)."""
     masks = list(masks) if masks is not None else []
     tape = [] if training else None
     h = x
     last_op = plan[-1]
-    for op in plan:
+    last_bn = max([i for i, op in enumerate(plan) if op.kind == 'bn'] or [-1]) if stats_only else -1
+    if stats_only and (last_bn < 0 or not training):
+        raise RuntimeError('stats_only needs a training-mode stack with a BatchNorm')
+    for op_index, op in enumerate(plan):
         saved = None
         if op.kind in ('lin', 'lin2'):
             if h.dim() != 2 or h.stride(1) != 1:
@@ -283,7 +289,7 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
         elif op.kind == 'bn':
             m = op.mod
             h = h.contiguous()
-            y = torch.empty_like(h)
+            y = None if (stats_only and op_index == last_bn) else torch.empty_like(h)
             if training:
                 C = h.shape[1]
                 sm = torch.empty(groups, C, dtype=torch.float32, device=h.device)
@@ -292,6 +298,8 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
                                m.running_var, groups, eps=m.eps, momentum=m.momentum,
                                n_updates=bn_updates, swish=op.act, n_updates_dev=bn_updates_dev)
                 m._nbt_pending += groups * bn_updates
+                if y is None:
+                    return None, None
                 saved = (h, sm, si)
             else:
                 K.bn_eval_fwd(h, m.weight.detach(), m.bias.detach(), y, m.running_mean, m.running_var,
