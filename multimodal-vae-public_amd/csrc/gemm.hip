@@ -405,7 +405,17 @@ struct SplitSink {
     float *rowsum; size_t rowsum_stride; int rowsum_accumulate;   // (split, i) at rowsum[split*rowsum_stride + i]
     int ncls;                                 // parity classes (transposed conv) / groups (grouped Linear) folded into gridDim.x
     size_t rowsum_cls_stride;                 // grouped Linear wgrad: per-group offset of the bias gradient
+    float *rowsum_final; int rowsum_final_accumulate;   // split launches: where the finish kernel puts the summed row sums
 };
+
+// the bias gradient of a split Linear wgrad: sum the per-split row sums in split order
+__device__ __forceinline__ void finish_rowsum(const SplitSink &sink, int splits, int i) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sink.rowsum[(size_t)z * sink.rowsum_stride + i];
+    float *dst = sink.rowsum_final + i;
+    if (sink.rowsum_final_accumulate) s += *dst;
+    *dst = s;
+}
 
 // ------------------------------------------------------------------------------------------
 // the kernel
@@ -504,17 +514,24 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
     if (mover && nsteps > 1) { p.load(kbeg + BK, kend, t, pr1); q.load(kbeg + BK, kend, t, qr1); }
     if (mover && nsteps > 0) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
     __syncthreads();
-    for (int s = 0; s < nsteps; s += 2) {
+    // two k-steps per trip (the register sets alternate); a lone last step is peeled off below so the
+    // loop has ONE exit -- with a break in the middle hipcc ping-ponged the accumulator between two
+    // register sets (16 v_mov + 17 wait states per k-step)
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
         // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
         if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BK, kend, t, pr0); q.load(kbeg + (s + 2) * BK, kend, t, qr0); }
         compute(0);
-        if (mover && s + 1 < nsteps) { p.store(Ps[1], t, pr1); q.store(Qs[1], t, qr1); }
+        if (mover) { p.store(Ps[1], t, pr1); q.store(Qs[1], t, qr1); }
         __syncthreads();
-        if (s + 1 >= nsteps) break;
         // odd step
         if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BK, kend, t, pr1); q.load(kbeg + (s + 3) * BK, kend, t, qr1); }
         compute(1);
         if (mover && s + 2 < nsteps) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+        __syncthreads();
+    }
+    if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
+        compute(0);
         __syncthreads();
     }
     if (KW > 1) {
@@ -597,12 +614,29 @@ __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits,
             ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]));
         e.put(i, j, s);
     }
+    if (sink.rowsum_final && blockIdx.x == 0) {      // block-uniform: the bias gradient of row i, 8 split groups
+        __syncthreads();
+        if (o == 0) {
+            float r = 0.f;
+            for (int z = grp; z < splits; z += 8) r += sink.rowsum[(size_t)z * sink.rowsum_stride + i];
+            part[grp][0] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float r = ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0])) +
+                      ((part[4][0] + part[5][0]) + (part[6][0] + part[7][0]));
+            float *dst = sink.rowsum_final + i;
+            if (sink.rowsum_final_accumulate) r += *dst;
+            *dst = r;
+        }
+    }
 }
 
 // few splits: one thread per output, the chain is short
 template <class E>
 __global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int splits, E e) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (sink.rowsum_final && j == 0) finish_rowsum(sink, splits, i);
     if (j >= sink.J || !e.col(j)) return;
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
@@ -614,7 +648,11 @@ template <class E>
 __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int splits, E e) {
     const int jq = sink.J >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)sink.I * jq) return;
+    const size_t nvec = (size_t)sink.I * jq;
+    if (idx >= nvec) {          // the launch carries I extra threads for the bias gradient
+        if (sink.rowsum_final && idx < nvec + sink.I) finish_rowsum(sink, splits, (int)(idx - nvec));
+        return;
+    }
     const int i = (int)(idx / jq), j = (int)(idx - (size_t)i * jq) * 4;
     const float *src = sink.ws + (size_t)i * sink.J + j;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -626,35 +664,6 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
     if (e.col(j + 1)) e.put(i, j + 1, s.y);
     if (e.col(j + 2)) e.put(i, j + 2, s.z);
     if (e.col(j + 3)) e.put(i, j + 3, s.w);
-}
-
-__global__ __launch_bounds__(256) void splitk_reduce_few_kernel(const float *ws, float *out, int n, int splits,
-                                                                size_t stride, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * stride + idx];
-    if (accumulate) s += out[idx];
-    out[idx] = s;
-}
-
-// out[idx] (+)= sum_s ws[s * stride + idx]   (bias-gradient partials), same scheme as finish_kernel
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, float *out, int n,
-                                                            int splits, size_t stride, int accumulate) {
-    __shared__ float part[8][32];
-    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + o;
-    float s = 0.f;
-    if (idx < n)
-        for (int z = grp; z < splits; z += 8) s += ws[(size_t)z * stride + idx];
-    part[grp][o] = s;
-    __syncthreads();
-    if (grp == 0 && idx < n) {
-        s = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) +
-            ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]));
-        if (accumulate) s += out[idx];
-        out[idx] = s;
-    }
 }
 
 // wr[cls][(co,a,b)][ci] = w[co][ci][kh0 + s*a][kw0 + s*b]: the weights of one output parity class of
@@ -757,7 +766,7 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
             dim3 grid((J + 31) / 32, I);
             hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
         } else if (J % 4 == 0 && sink.stride % 4 == 0 && aligned16(sink.ws)) {
-            const size_t nvec = (size_t)I * (J / 4);
+            const size_t nvec = (size_t)I * (J / 4) + (sink.rowsum_final ? I : 0);
             hipLaunchKernelGGL((finish_few_vec_kernel<E>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, sink,
                                pl.splits, e);
         } else {
@@ -773,6 +782,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     s.ws = (float *)ws; s.I = I; s.J = J;
     s.stride = (size_t)I * J + (rowsum ? I : 0);
     s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
+    s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0;
     return s;
 }
 
@@ -1164,19 +1174,11 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
             sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc; sink.rowsum_cls_stride = gr.c;
         } else {
             sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
+            sink.rowsum_final = db; sink.rowsum_final_accumulate = acc;     // summed by the finish launch
         }
         rc = vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st)
                  : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
         if (rc) return rc;
-        if (pl.splits > 1) {
-            if (pl.splits > 16)
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st,
-                                   (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
-            else
-                hipLaunchKernelGGL(splitk_reduce_few_kernel, dim3((N + 255) / 256), dim3(256), 0, st,
-                                   (const float *)ws + (size_t)N * K, db, N, pl.splits, sink.stride, acc);
-            return mvae_launch_status();
-        }
         return MVAE_OK;
     }
     return vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st)
