@@ -726,7 +726,8 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
         if (want > maxs) want = maxs;
         if (want < 1) want = 1;
         if (want > (tiles <= 4 ? 512 : 64)) want = (tiles <= 4 ? 512 : 64);   // tiny outputs may split deeper
-        if (g_force_splits) want = g_force_splits;
+        if (g_force_splits > 0) want = g_force_splits;
+        if (g_force_splits < 0 && kind == PLAN_FWD) want = 1;      // tuning: forward / dgrad forms never split
     }
     p.klen = (int)(((K + want - 1) / want + BK - 1) / BK * BK);
     p.splits = (K + p.klen - 1) / p.klen;
@@ -1102,7 +1103,7 @@ MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len
     if (rows_out <= 0 || cols_out <= 0 || reduce_len <= 0) return 0;
     size_t n = split_ws_floats(rows_out, cols_out, reduce_len);
     const size_t repack = (size_t)rows_out * cols_out;      // dgrad-form weight repack: Cin x (Cout*16)
-    if (g_force_splits) n = (size_t)g_force_splits * ((size_t)rows_out * cols_out + rows_out);
+    if (g_force_splits > 0) n = (size_t)g_force_splits * ((size_t)rows_out * cols_out + rows_out);
     return (n > repack ? n : repack) * sizeof(float);
 }
 
