@@ -57,8 +57,8 @@ def _test_total(model, image, attrs, args):
     return elbo_loss([recon_image] + recon_attrs, [image] + cols, mu, logvar)
 
 
-def _make_engine(model, args, rank):
-    return Celeba19Step(model, args.batch_size, args.lambda_image, args.lambda_attrs,
+def _make_engine(model, args, rank, batch_size):
+    return Celeba19Step(model, batch_size, args.lambda_image, args.lambda_attrs,
                         approx_m=args.approx_m, seed=1 + rank)
 
 

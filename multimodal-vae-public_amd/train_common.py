@@ -59,6 +59,8 @@ def add_extra_flags(parser):
                         help='random-pixel / random-label batches instead of the dataset')
     parser.add_argument('--steps-per-epoch', type=int, default=100,
                         help='mini-batches per epoch with --synthetic [default: 100]')
+    parser.add_argument('--synthetic-last-batch', type=int, default=0,
+                        help='with --synthetic: make the last mini-batch of an epoch this short (dataset tail)')
     parser.add_argument('--no-graph', action='store_true', default=False,
                         help='launch kernels eagerly instead of replaying the captured hipGraph')
     parser.add_argument('--out-dir', type=str, default='./trained_models')
@@ -66,22 +68,24 @@ def add_extra_flags(parser):
 
 class SyntheticLoader(object):
     """len()/iteration surface of the DataLoader the reference builds (mnist/train.py:159-165)."""
-    def __init__(self, kind, batch_size, n_batches, seed, device):
+    def __init__(self, kind, batch_size, n_batches, seed, device, last_batch=0):
         self.kind, self.batch_size, self.n, self.seed, self.device = kind, batch_size, n_batches, seed, device
-        self.dataset = range(batch_size * n_batches)
+        self.last_batch = int(last_batch)       # > 0: the final batch is this short (a dataset tail)
+        self.dataset = range(batch_size * n_batches - (batch_size - self.last_batch if self.last_batch else 0))
 
     def __len__(self):
         return self.n
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)
-        for _ in range(self.n):
+        for i in range(self.n):
+            bs = self.last_batch if (self.last_batch and i == self.n - 1) else self.batch_size
             if self.kind in ('mnist', 'fashionmnist'):
-                image = torch.rand(self.batch_size, 1, 28, 28, generator=g)
-                label = torch.randint(0, 10, (self.batch_size,), generator=g)
+                image = torch.rand(bs, 1, 28, 28, generator=g)
+                label = torch.randint(0, 10, (bs,), generator=g)
             else:
-                image = torch.rand(self.batch_size, 3, 64, 64, generator=g)
-                label = torch.randint(0, 2, (self.batch_size, 18), generator=g).float()
+                image = torch.rand(bs, 3, 64, 64, generator=g)
+                label = torch.randint(0, 2, (bs, 18), generator=g).float()
             yield image.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
 
 
@@ -96,14 +100,14 @@ def _real_loaders(kind, batch_size):
         raise SystemExit('only the MNIST torchvision loader is wired up; use --synthetic')
     mk = lambda train: torch.utils.data.DataLoader(  # noqa: E731
         MNIST('./data', train=train, download=True, transform=transforms.ToTensor()),
-        batch_size=batch_size, shuffle=train, drop_last=True)
+        batch_size=batch_size, shuffle=train)
     return mk(True), mk(False)
 
 
 def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0, make_engine=None):
     """The reference's main loop.  ``annealing_epoch_offset``: 0 for mnist/celeba
     ((epoch - 1) * N, mnist/train.py:182), 1 for fashionmnist (epoch * N, fashionmnist/train.py:182).
-    ``make_engine(model, args, rank)``: the fused step to use instead of ``BimodalStep`` (celeba19)."""
+    ``make_engine(model, args, rank, batch_size)``: the fused step to use instead of ``BimodalStep`` (celeba19)."""
     import torch.distributed as dist
     from .engine import BimodalStep
     from .optim import FusedAdam
@@ -123,7 +127,8 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
         os.makedirs(args.out_dir)
 
     if args.synthetic:
-        train_loader = SyntheticLoader(kind, args.batch_size, args.steps_per_epoch, 1234 + rank, device)
+        train_loader = SyntheticLoader(kind, args.batch_size, args.steps_per_epoch, 1234 + rank, device,
+                                       last_batch=args.synthetic_last_batch)
         test_loader = SyntheticLoader(kind, args.batch_size, max(1, args.steps_per_epoch // 10), 4321, device)
     else:
         train_loader, test_loader = _real_loaders(kind, args.batch_size)
@@ -132,12 +137,15 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
     model = mvae_cls(args.n_latents)
     model.cuda(device)
     optimizer = FusedAdam(model.parameters(), lr=args.lr, grad_scale=1.0 / world)
-    if make_engine is not None:
-        engine = make_engine(model, args, rank)
-    else:
-        engine = BimodalStep(model, args.batch_size, args.lambda_image, lambda_label, seed=1 + rank)
+    def build_engine(batch_size):
+        if make_engine is not None:
+            return make_engine(model, args, rank, batch_size)
+        return BimodalStep(model, batch_size, args.lambda_image, lambda_label, seed=1 + rank)
+
+    engine = build_engine(args.batch_size)
     dp = DataParallel(model, engine) if world > 1 else None
     captured = [False]
+    ragged = {}           # the reference trains on the loader's short last batch too: eager engine per size
 
     def train(epoch):
         model.train()
@@ -150,7 +158,17 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
             else:
                 annealing_factor = 1.0
             image, label = image.to(device), label.to(device)
-            if not args.no_graph:
+            if len(image) != args.batch_size:
+                eng = ragged.get(len(image))
+                if eng is None:
+                    eng = ragged[len(image)] = build_engine(len(image))
+                    if dp is not None:
+                        eng.on_bucket_ready = dp.buckets.launch
+                elbo = eng.step(image, label, annealing_factor)
+                if dp is not None:
+                    dp.wait()
+                optimizer.step()
+            elif not args.no_graph:
                 if not captured[0]:
                     engine.capture(optimizer, image.shape[1:], label, comm=dp)
                     captured[0] = True

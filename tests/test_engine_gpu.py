@@ -95,7 +95,11 @@ def test_fused_step_matches_reference_goldens(golden_dir, kind, batch):
     check_bn_vs(model, {k[3:]: v for k, v in fx.items() if k.startswith('bn/')})
 
 
-@pytest.mark.parametrize('kind,batch', [('mnist', 96), ('fashionmnist', 40), ('celeba', 12)])
+# ragged sizes too: odd batches leave partial tiles / partial float4 groups in every kernel.  (CelebA
+# at batch 2 is left out: BatchNorm1d over two samples maps every input to +-1, the gradient behind it is
+# exactly zero in exact arithmetic, and what either implementation returns there is round-off.)
+@pytest.mark.parametrize('kind,batch', [('mnist', 96), ('fashionmnist', 40), ('celeba', 12), ('mnist', 1),
+                                        ('mnist', 67), ('fashionmnist', 13), ('celeba', 5), ('celeba', 7)])
 def test_fused_step_matches_live_oracle(kind, batch):
     oracle, model, d = build_pair(kind, weight_seed=11)
     image, label = OS.synthetic_batch(kind, batch, seed=77)

@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [
-    ('mnist', ['--n-latents', '16', '--lambda-text', '50']),
+    ('mnist', ['--n-latents', '16', '--lambda-text', '50', '--synthetic-last-batch', '5']),    # + a short dataset tail
     ('fashionmnist', ['--n-latents', '16', '--lambda-text', '50']),
-    ('celeba', ['--n-latents', '20', '--lambda-attrs', '10']),
+    ('celeba', ['--n-latents', '20', '--lambda-attrs', '10', '--synthetic-last-batch', '3']),
     ('celeba19', ['--n-latents', '20', '--lambda-attrs', '10', '--approx-m', '2']),
 ]
 
