@@ -46,3 +46,18 @@ for M, N in ((1024, 512), (4096, 2048)):
             row.append('K%d: %.1fus' % (Kd, us))
         print('M%d N%d kw%d  ' % (M, N, kw) + '  '.join(row))
 lib.mvae_debug_set_tiling(0, 0, 0); lib.mvae_debug_set_kwaves(0)
+
+# fixed cost of a launch: one tile, one k-step; then the epilogue variants
+print('--- floor')
+for M, N, Kd, two in ((64, 64, 32, True), (64, 64, 32, False), (1024, 512, 32, True), (1024, 512, 32, False),
+                      (1024, 512, 128, True), (1024, 512, 128, False)):
+    lib.mvae_debug_set_tiling(1, 1, 1); lib.mvae_debug_set_kwaves(1)
+    x, w, b = torch.randn(M, Kd, device='cuda'), torch.randn(N, Kd, device='cuda'), torch.randn(N, device='cuda')
+    pre, act = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    us = graph_time(lambda: K.linear_fwd(x, w, b, pre, act if two else None))
+    print('M%d N%d K%d %s: %.2f us' % (M, N, Kd, 'pre+act' if two else 'pre only', us))
+lib.mvae_debug_set_tiling(0, 0, 0); lib.mvae_debug_set_kwaves(0)
+z = torch.zeros(1 << 20, device='cuda')
+print('fill 4 MB: %.2f us' % graph_time(lambda: K.fill_(z, 1.0)))
+z2 = torch.zeros(256, device='cuda')
+print('fill 1 KB: %.2f us' % graph_time(lambda: K.fill_(z2, 1.0)))
