@@ -21,6 +21,8 @@
 // 6400 inputs or outputs) are split across blockIdx.z into a caller-provided workspace and
 // finished by `finish_kernel`, which sums the splits in a fixed order and applies the same
 // epilogue functor: deterministic, no atomics.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -720,7 +722,15 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
     if (g_force_kw) p.kw = (p.wm == 1 && p.wn == 1) ? g_force_kw : 1;
     long want = 1;
     if (allow_split) {
-        const long target_blocks = 1024 / p.kw;
+        // blocks to aim for (profiles/r01_split_sweep.txt): the Linear forward / dgrad forms want every
+        // CU busy and then as FEW splits as possible (each block keeps >= 8 k-steps, the finish reads
+        // less); the 128-wide conv weight-gradient tiles run two blocks per CU; everything else (Linear
+        // weight gradients, small conv outputs) is fastest with ~4 blocks per CU
+        static const long target_env = getenv("MVAE_SPLIT_TARGET") ? atol(getenv("MVAE_SPLIT_TARGET")) : 0;   // tuning
+        long target_blocks = 1024 / p.kw;
+        if (kind == PLAN_FWD) target_blocks = (p.kw == 1) ? 512 : 256;
+        if (kind == PLAN_CONV_WGRAD && p.wm * p.wn >= 2) target_blocks = 512;
+        if (target_env > 0) target_blocks = target_env / p.kw;
         want = (target_blocks + tiles - 1) / tiles;
         const long maxs = (K + 2 * BK - 1) / (2 * BK);
         if (want > maxs) want = maxs;
