@@ -731,10 +731,20 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
         if (kind == PLAN_FWD) target_blocks = (p.kw == 1) ? 512 : 256;
         if (kind == PLAN_CONV_WGRAD && p.wm * p.wn >= 2) target_blocks = 512;
         if (target_env > 0) target_blocks = target_env / p.kw;
-        want = (target_blocks + tiles - 1) / tiles;
+        want = (target_blocks + tiles / 2) / tiles;         // nearest: 800 tiles against 1024 is one round, not two
         const long maxs = (K + 2 * BK - 1) / (2 * BK);
         if (want > maxs) want = maxs;
         if (want < 1) want = 1;
+        if (kind == PLAN_LIN_WGRAD && !g_force_kw && !target_env) {
+            // Linear weight gradients: plain 4-wave blocks, ~2 per CU, >= 8 k-steps each beat k-wave
+            // groups and deeper splits (512x512 over M = 1024: 36 vs 33 TFLOP/s; 784x512: 40 vs 32) --
+            // unless the reduction is too short to make enough blocks that way
+            const long maxs8 = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
+            long w1 = (512 + tiles / 2) / tiles;
+            if (w1 > maxs8) w1 = maxs8;
+            if (w1 < 1) w1 = 1;
+            if (tiles * w1 >= 128) { p.kw = 1; want = w1; }
+        }
         if (want > (tiles <= 4 ? 512 : 64)) want = (tiles <= 4 ? 512 : 64);   // tiny outputs may split deeper
         if (g_force_splits > 0) want = g_force_splits;
         if (g_force_splits < 0 && kind == PLAN_FWD) want = 1;      // tuning: forward / dgrad forms never split
