@@ -297,6 +297,27 @@ int mvae_bce_elem_fwd(const float *logits, const float *target, float *out, size
 int mvae_bce_elem_bwd(const float *logits, const float *target, const float *g,
                       float *dlogits, float *dtarget, size_t n, mvae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Input pipeline: what the reference's DataLoader workers do per image on
+ * the CPU, on a batch of raw uint8 images resident in HBM.
+ *   mvae_u8_to_f32            : ToTensor (mnist/train.py:160,164): dst = (float)src / 255
+ *   mvae_resize_crop_u8_to_f32: Compose([Resize(S), CenterCrop(S), ToTensor()]) (celeba/train.py:
+ *       146-148, celeba19/train.py:200-202) on src[B,H,W,3] -> dst[B,3,S,S].  Resize is Pillow's
+ *       8-bit separable BILINEAR resample (torchvision delegates to it), byte-exact: the caller
+ *       builds the fixed-point coefficient tables of both axes once per image size with the HOST
+ *       function mvae_resample_coeffs (kk[out, ksize], bounds[out, 2] = first tap, taps; ksize =
+ *       mvae_resample_ksize) and uploads them; out_h/out_w = the resized size, (crop_top,
+ *       crop_left) the crop origin in it, [y0, y1) the source rows the cropped rows depend on
+ *       (min/max over their bounds).  One block per image, (y1-y0)*S*3 bytes of LDS <= 150 KiB.
+ * ---------------------------------------------------------------------------------- */
+int mvae_resample_ksize(int in_size, int out_size);
+int mvae_resample_coeffs(int in_size, int out_size, int *kk_host, int *bounds_host);
+int mvae_resize_crop_u8_to_f32(const uint8_t *src, float *dst, int B, int H, int W, int out_h,
+                               int out_w, int S, int crop_top, int crop_left, const int *kx_dev,
+                               const int *bx_dev, int ksx, const int *ky_dev, const int *by_dev,
+                               int ksy, int y0, int y1, mvae_stream_t stream);
+int mvae_u8_to_f32(const uint8_t *src, float *dst, size_t n, mvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

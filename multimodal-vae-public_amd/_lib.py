@@ -64,6 +64,10 @@ _SIGNATURES = {
                                                  c_int, P]),
     'mvae_embedding_swish_bwd_grouped': (c_int, [P, c_int, c_size_t, P, c_size_t, P, c_size_t, P, c_int, c_int,
                                                  c_int, c_int, c_int, P]),
+    'mvae_resample_ksize': (c_int, [c_int, c_int]),
+    'mvae_resample_coeffs': (c_int, [c_int, c_int, P, P]),
+    'mvae_resize_crop_u8_to_f32': (c_int, [P, P] + [c_int] * 8 + [P, P, c_int, P, P, c_int, c_int, c_int, P]),
+    'mvae_u8_to_f32': (c_int, [P, P, c_size_t, P]),
     'mvae_poe_fwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P,
                              c_int, c_int, c_int, P]),
     'mvae_poe_bwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P, P, P, c_int,
