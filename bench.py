@@ -185,6 +185,50 @@ def traffic_for(name, key):
     return None if ent is None else ent['hbm_bytes_per_launch']
 
 
+def elbo_delta(kind, batch=32):
+    """BASELINE.json's metric is 'images/sec ...; ELBO delta vs CPU ref': one step of the HIP engine and
+    of the CPU oracle at identical weights, inputs and noise; relative difference of the summed ELBO and
+    the worst relative gradient error (part of the cpu_baseline leg: the oracle is the checker)."""
+    import numpy as np
+    import mvae_amd
+    from oracle import models as OM, steps as OS
+    cls, d = OM.MODELS[kind]
+    oracle = OM.fill_parameters(cls(d), 17).train()
+    model = getattr(mvae_amd, kind).model.MVAE(d)
+    model.load_state_dict(oracle.state_dict())
+    model.cuda().train()
+    image, label = OS.synthetic_batch(kind, batch, seed=18)
+    torch.manual_seed(19)
+    lam = LAMBDA_LABEL[kind]
+    if kind == 'celeba19':
+        from mvae_amd.engine import Celeba19Step, sample_subsets
+        combos = sample_subsets(np.random.RandomState(3), 19, 1)
+        terms = OS.celeba19_terms(combos)
+        noise = OS.draw_celeba19_noise(batch, d, terms)
+        total, _, _ = OS.celeba19_step(oracle, image, label, terms, noise, 1.0, lam, 0.5)
+        eng = Celeba19Step(model, batch, 1.0, lam, approx_m=1)
+        got = eng.step(image.cuda(), label.cuda(), 0.5, noise=noise, combos=combos)[-1].item()
+    else:
+        from mvae_amd.engine import BimodalStep
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+        total, _, _ = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, lam, 0.5)
+        eng = BimodalStep(model, batch, 1.0, lam)
+        got = eng.step(image.cuda(), label.cuda(), 0.5, noise=noise)[-1].item()
+    total.backward()
+    og = dict(oracle.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in og.values())
+    worst = 0.0
+    for name, p in model.named_parameters():
+        ref = og[name].grad
+        # gradients that are zero in exact arithmetic (a bias feeding BatchNorm) are judged on the
+        # scale of the largest gradient, as in tests/test_engine_gpu.py
+        scale = max(ref.abs().max().item(), 1e-2 * gmax)
+        worst = max(worst, (p.grad.cpu() - ref).abs().max().item() / scale)
+    ref = total.item()
+    return {'hip': round(got, 4), 'cpu': round(ref, 4), 'rel': float('%.3e' % (abs(got - ref) / abs(ref))),
+            'worst_gradient_rel': float('%.3e' % worst), 'batch': batch, 'tolerance': 1e-4}
+
+
 def cpu_baseline(kind, batch, budget_s=15.0):
     """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
     host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s."""
@@ -234,7 +278,8 @@ def cpu_baseline(kind, batch, budget_s=15.0):
             break
     return {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '
-                      '%d threads' % (n, kind, batch, torch.__version__, threads)}
+                      '%d threads' % (n, kind, batch, torch.__version__, threads),
+            'elbo_delta': elbo_delta(kind, 8 if kind == 'celeba19' else 32)}
 
 
 def main():
