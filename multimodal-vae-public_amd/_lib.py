@@ -7,7 +7,7 @@ wrapper in ``ops.py`` raises when it is handed a non-GPU tensor.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_double, c_float, c_int, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmvae_hip.so')

@@ -14,7 +14,6 @@ import torch.nn as nn
 from .. import layers as L
 from ..base import MVAEBase, Stack
 from ..celeba.model import ImageDecoder, ImageEncoder, N_ATTRS  # noqa: F401  (identical stacks)
-from ..functional import PoEFn
 
 
 class AttributeEncoder(Stack):

@@ -18,7 +18,6 @@ for.  Design for MI355X rather than a per-parameter DDP hook storm:
 ``GradBuckets`` is backend-agnostic (it only needs a flat tensor), which is how the gloo CPU
 tests exercise the N > 1 logic without GPUs.
 """
-import torch
 import torch.distributed as dist
 
 

@@ -9,7 +9,6 @@ Dropout -- then the reparameterisation eps; SURVEY.md section 7 "identical seeds
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import functional as OF
 

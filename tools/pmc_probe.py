@@ -17,7 +17,6 @@ sys.path.insert(0, ROOT)
 def run():
     import torch
     import mvae_amd  # noqa: F401
-    from mvae_amd import kernels as K
     from gemm_bench import conv_cases, convT_cases
     B = 256
     cases = (conv_cases(B, 32, 32, 64, 2, 1, 'enc2') + conv_cases(B, 64, 16, 128, 2, 1, 'enc3')
