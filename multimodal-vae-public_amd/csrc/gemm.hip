@@ -1090,17 +1090,202 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     return launch_igemm<LdRowsMNS, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
+// ---- weight gradient of the <= 4-input-channel convs (Conv2d(3,32) / ConvTranspose2d(32,3) of CelebA,
+//      Conv2d(1,64) / ConvTranspose2d(64,1) of FashionMNIST; stride 2, pad 1).  The output is 32..64 x
+//      16..48 values over a reduction of B*OH*OW ~ 10^5..10^6: as an implicit GEMM that is ONE
+//      under-filled tile split 512 ways, a third of whose gathered columns are padding (62 / 107 us on
+//      CelebA B = 256).  It is an HBM-bound op (46 / 92 MB): here every wave streams whole output rows --
+//      unit (b, oh): the CO x OW slab of dy and the CI x 4 input rows it touches, both staged through
+//      the wave's own LDS with coalesced float4 loads -- and multiplies them with MFMAs (k = ow);
+//      per-block partials go to scratch and the ordinary split finish sums them in a fixed order. ----
+constexpr int SC_MAXW = 64;                 // input row length limit
+constexpr int SC_XW = SC_MAXW + 8;          // staged input row: 4 zero floats, the row, 4 zero floats
+constexpr int SC_DW = 33;                   // staged dy row (OW <= 32, odd pitch: conflict-free fragment reads)
+
+constexpr int SC_WAVES = 8;                 // waves per block, each streaming its own units
+
+template <int MT, int NT>
+__global__ __launch_bounds__(64 * SC_WAVES) void wgrad_smallcin_kernel(const float *dy, const float *x, float *ws, ConvGeom g,
+                                                             int units) {
+    extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+    constexpr int CO = 32 * MT;
+    constexpr int WAVE_FLOATS = CO * SC_DW + 16 * SC_XW;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float *dys = sc_lds + wave * WAVE_FLOATS;          // [CO][SC_DW]
+    float *xs = dys + CO * SC_DW;                      // [CI*4][SC_XW]
+    const int J = g.Cin * 16, OW = g.OW, W = g.W;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // zero the halos of the input rows once (the row bodies are rewritten per unit)
+    for (int i = lane; i < g.Cin * 4 * 8; i += 64) {
+        const int row = i >> 3, c = i & 7;
+        xs[row * SC_XW + (c < 4 ? c : W + c)] = 0.f;
+    }
+    const int lr = lane & 31, lk = lane >> 5;
+    // per-lane column j = (ci, kh, kw) of each column tile
+    int xoff[NT]; float xmask[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int j = b * 32 + lr;
+        const bool ok = j < J;
+        const int jj = ok ? j : 0;
+        xoff[b] = ((jj >> 4) * 4 + ((jj >> 2) & 3)) * SC_XW + 4 - 1 + (jj & 3);      // + 2*k at use
+        xmask[b] = ok ? 1.f : 0.f;
+    }
+    // registers of the NEXT unit: its global loads are in flight while this unit is multiplied
+    constexpr int NDY = 8 * MT;                 // float2 per lane for CO x OW <= 32*MT x 32
+    constexpr int NX = 4;                       // float4 per lane for <= 16 rows x 64
+    float2 dyr[NDY]; float4 xr[NX];
+    const int v2 = OW >> 1, v4 = W >> 2;
+    auto fetch = [&](int u) {
+        const int b = u / g.OH, oh = u - b * g.OH;
+        const float *dyb = dy + ((size_t)b * CO * g.OH + oh) * OW;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = lane + 64 * i;
+            const int co = min(e / v2, CO - 1), c2 = e % v2;       // clamped: always a legal address
+            dyr[i] = *reinterpret_cast<const float2 *>(dyb + (size_t)co * g.OH * OW + c2 * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = lane + 64 * i;
+            const int row = min(e / v4, g.Cin * 4 - 1), c4 = e % v4;
+            const int ci = row >> 2, ih = 2 * oh - 1 + (row & 3);
+            const int ihc = min(max(ih, 0), g.H - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)b * g.Cin + ci) * g.H + ihc) * W + c4 * 4);
+            const float m = (ih >= 0 && ih < g.H) ? 1.f : 0.f;      // rows outside the image are zero padding
+            xr[i] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = lane + 64 * i;
+            if (e < CO * v2) {
+                const int co = e / v2, c2 = e % v2;
+                dys[co * SC_DW + c2 * 2] = dyr[i].x; dys[co * SC_DW + c2 * 2 + 1] = dyr[i].y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < g.Cin * 4 * v4) {
+                const int row = e / v4, c4 = e % v4;
+                *reinterpret_cast<float4 *>(xs + row * SC_XW + 4 + c4 * 4) = xr[i];
+            }
+        }
+    };
+    const int nwaves = gridDim.x * SC_WAVES;
+    int u = blockIdx.x * SC_WAVES + wave;
+    if (u < units) fetch(u);
+    for (; u < units; u += nwaves) {
+        stage();
+        __builtin_amdgcn_wave_barrier();
+        if (u + nwaves < units) fetch(u + nwaves);
+        // ---- k = ow in pairs
+        for (int q = 0; q < (OW >> 1); ++q) {
+            const int k = 2 * q + lk;
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = dys[(a * 32 + lr) * SC_DW + k];
+#pragma unroll
+            for (int b2 = 0; b2 < NT; ++b2) bf[b2] = xs[xoff[b2] + 2 * k] * xmask[b2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < NT; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b2], acc[a][b2], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- sum the waves' partials in a fixed order, write this block's [CO][J] partial
+    __syncthreads();
+    float *red = sc_lds;                               // (SC_WAVES - 1) x MT*NT tiles of 1024 floats
+    if (wave > 0) {
+        float *dst = red + (wave - 1) * MT * NT * 1024 + lane;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * NT + b) * 16 + r) * 64] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float *out = ws + (size_t)blockIdx.x * CO * J;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r];
+#pragma unroll
+                for (int w2 = 0; w2 < SC_WAVES - 1; ++w2) v += red[w2 * MT * NT * 1024 + ((a * NT + b) * 16 + r) * 64 + lane];
+                const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, j = b * 32 + lr;
+                if (j < J) out[(size_t)co * J + j] = v;
+            }
+}
+
+inline bool wgrad_smallcin_ok(const ConvGeom &g) {
+    return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && (g.Cout == 32 || g.Cout == 64) && g.OW <= 32 &&
+           (g.OW & 1) == 0 && g.W <= SC_MAXW && (g.W & 3) == 0;
+}
+inline int wgrad_smallcin_blocks(const ConvGeom &g) {
+    const int units = g.B * g.OH;
+    int blocks = (units + SC_WAVES - 1) / SC_WAVES;
+    return blocks > 256 ? 256 : blocks;      // one 8-wave block per CU; more partials only slow the finish
+}
+
 // ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----
 int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int flags, void *ws,
                     size_t ws_bytes, hipStream_t st) {
     const int I = g.Cout, J = g.Cin * 16, K = g.B * g.OH * g.OW;
-    Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
-    SplitSink sink = make_sink(ws, I, J, false);
-    if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = dw; e.act = nullptr; e.ld = J; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
     e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = I; e.J = J;
     e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+    if (wgrad_smallcin_ok(g) && !g_force_wm && !g_force_splits && ws) {
+        const int blocks = wgrad_smallcin_blocks(g);
+        if (ws_bytes >= (size_t)blocks * I * J * sizeof(float)) {
+            const int mt = I / 32, nt = (J + 31) / 32;
+            const size_t wave_b = ((size_t)I * SC_DW + 16 * SC_XW) * sizeof(float);
+            const size_t red_b = (size_t)(SC_WAVES - 1) * mt * nt * 1024 * sizeof(float);
+            const size_t lds = SC_WAVES * wave_b > red_b ? SC_WAVES * wave_b : red_b;
+#define MVAE_SC(MT_, NT_)                                                                                   \
+    {                                                                                                       \
+        auto kern = wgrad_smallcin_kernel<MT_, NT_>;                                                        \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);              \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SC_WAVES), lds, st, dy, x, (float *)ws, g, g.B * g.OH); \
+    }
+            if (mt == 1 && nt == 1) MVAE_SC(1, 1)
+            else if (mt == 1) MVAE_SC(1, 2)
+            else if (nt == 1) MVAE_SC(2, 1)
+            else MVAE_SC(2, 2)
+#undef MVAE_SC
+            SplitSink fs = make_sink(ws, I, J, false);
+            if (blocks > 16) {
+                hipLaunchKernelGGL((finish_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(256), 0, st, fs, blocks, e);
+            } else {
+                hipLaunchKernelGGL((finish_few_kernel<EpRowMajor>), dim3((J + 255) / 256, I), dim3(256), 0, st, fs,
+                                   blocks, e);
+            }
+            return mvae_launch_status();
+        }
+    }
+    Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
+    SplitSink sink = make_sink(ws, I, J, false);
+    if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
     auto mp = [&](auto &p) { p.dy = dy; p.g = g; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.J = J; };
     return launch_igemm<LdWgradDy, LdWgradX, EpRowMajor, false>(pl, mp, mq, e, I, J, K, sink, st);
@@ -1124,6 +1309,8 @@ MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len
     size_t n = split_ws_floats(rows_out, cols_out, reduce_len);
     const size_t repack = (size_t)rows_out * cols_out;      // dgrad-form weight repack: Cin x (Cout*16)
     if (g_force_splits > 0) n = (size_t)g_force_splits * ((size_t)rows_out * cols_out + rows_out);
+    const size_t smallcin = (size_t)512 * rows_out * cols_out;      // per-block partials of wgrad_smallcin_kernel
+    if (rows_out <= 64 && cols_out <= 64 && smallcin > n) n = smallcin;
     return (n > repack ? n : repack) * sizeof(float);
 }
 

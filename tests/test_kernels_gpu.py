@@ -107,7 +107,8 @@ def test_linear_strided_views():
 
 # ----------------------------------------------------------------------------- Conv / ConvT
 CONV_CASES = [(4, 3, 64, 32, 2, 1), (3, 32, 32, 64, 2, 1), (2, 64, 16, 128, 2, 1), (2, 128, 8, 256, 1, 0),
-              (5, 1, 28, 64, 2, 1), (2, 64, 14, 128, 2, 1), (1, 5, 6, 7, 1, 0), (3, 2, 4, 3, 2, 1)]
+              (5, 1, 28, 64, 2, 1), (2, 64, 14, 128, 2, 1), (1, 5, 6, 7, 1, 0), (3, 2, 4, 3, 2, 1),
+              (130, 3, 64, 32, 2, 1), (37, 1, 28, 64, 2, 1)]      # more (image, row) units than waves of the small-Cin wgrad
 
 
 # ----------------------------------------------------------------------------- grouped Linear / Embedding
