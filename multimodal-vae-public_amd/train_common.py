@@ -64,6 +64,8 @@ def add_extra_flags(parser):
     parser.add_argument('--no-graph', action='store_true', default=False,
                         help='launch kernels eagerly instead of replaying the captured hipGraph')
     parser.add_argument('--out-dir', type=str, default='./trained_models')
+    parser.add_argument('--data-dir', type=str, default='./data',
+                        help='where the MNIST / FashionMNIST IDX files live (without --synthetic)')
 
 
 class SyntheticLoader(object):
@@ -89,19 +91,77 @@ class SyntheticLoader(object):
             yield image.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True)
 
 
-def _real_loaders(kind, batch_size):
-    try:
-        from torchvision import transforms
-        from torchvision.datasets import MNIST
-    except ImportError:
-        raise SystemExit('torchvision is not installed: run with --synthetic (the reference reads '
-                         '%s through torchvision, mnist/train.py:159-165)' % kind)
-    if kind != 'mnist':
-        raise SystemExit('only the MNIST torchvision loader is wired up; use --synthetic')
-    mk = lambda train: torch.utils.data.DataLoader(  # noqa: E731
-        MNIST('./data', train=train, download=True, transform=transforms.ToTensor()),
-        batch_size=batch_size, shuffle=train)
-    return mk(True), mk(False)
+def read_idx(path):
+    """Parse an IDX file (the raw MNIST / FashionMNIST distribution format, optionally .gz):
+    magic 0x0000 <dtype 0x08 = uint8> <ndim>, big-endian uint32 dims, then the bytes."""
+    import gzip
+    import struct
+    import numpy as np
+    op = gzip.open if path.endswith('.gz') else open
+    with op(path, 'rb') as f:
+        raw = f.read()
+    zero, dtype, ndim = struct.unpack('>HBB', raw[:4])
+    if zero != 0 or dtype != 0x08:
+        raise ValueError('%s is not a uint8 IDX file' % path)
+    dims = struct.unpack('>' + 'I' * ndim, raw[4:4 + 4 * ndim])
+    data = np.frombuffer(raw, dtype=np.uint8, offset=4 + 4 * ndim)
+    if data.size != int(np.prod(dims)):
+        raise ValueError('%s: %d bytes for dims %s' % (path, data.size, dims))
+    return data.reshape(dims)
+
+
+class IdxLoader(object):
+    """MNIST / FashionMNIST from the raw IDX files, without torchvision: the whole split sits in HBM as
+    uint8 (47 MB), a batch is an index gather + ``preprocess.to_tensor`` on the device -- the
+    DataLoader + ``transforms.ToTensor()`` of mnist/train.py:159-165 with no host work per batch.
+    Same iteration surface (len(), .dataset, (image float [B,1,28,28], label int64 [B]) batches, the
+    short last batch kept, reshuffled every epoch when ``shuffle``)."""
+
+    def __init__(self, images_path, labels_path, batch_size, shuffle, device, seed=0):
+        from . import preprocess
+        self._to_tensor = preprocess.to_tensor
+        images, labels = read_idx(images_path), read_idx(labels_path)
+        if images.ndim != 3 or labels.ndim != 1 or images.shape[0] != labels.shape[0]:
+            raise ValueError('unexpected IDX shapes %s / %s' % (images.shape, labels.shape))
+        self.images = torch.from_numpy(images.copy()).to(device)
+        self.labels = torch.from_numpy(labels.astype('int64')).to(device)
+        self.batch_size, self.shuffle, self.device = int(batch_size), bool(shuffle), device
+        self.dataset = range(images.shape[0])
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = (torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)).to(self.device)
+        for i in range(0, n, self.batch_size):
+            idx = order[i:i + self.batch_size]
+            yield self._to_tensor(self.images[idx]), self.labels[idx]
+
+
+def _find_idx(root, stem):
+    for name in (stem, stem + '.gz', stem.replace('-idx', '.idx'), stem.replace('-idx', '.idx') + '.gz'):
+        for sub in ('', 'raw', 'MNIST/raw', 'FashionMNIST/raw'):
+            p = os.path.join(root, sub, name)
+            if os.path.exists(p):
+                return p
+    return None
+
+
+def _real_loaders(kind, batch_size, device, rank=0, data_dir='./data'):
+    """The loaders of mnist/train.py:159-165 / fashionmnist/train.py:159-165 from the IDX files under
+    ``data_dir`` (where torchvision's ``download=True`` puts them); this box has no network, so they
+    must already be there.  CelebA's image folder + attribute file parsing is out of scope
+    (celeba/datasets.py): use --synthetic."""
+    if kind not in ('mnist', 'fashionmnist'):
+        raise SystemExit('the CelebA dataset loader is out of scope here: run with --synthetic')
+    paths = [_find_idx(data_dir, stem) for stem in ('train-images-idx3-ubyte', 'train-labels-idx1-ubyte',
+                                                    't10k-images-idx3-ubyte', 't10k-labels-idx1-ubyte')]
+    if any(p is None for p in paths):
+        raise SystemExit('no %s IDX files under %s (no network to download them): run with --synthetic' % (kind, data_dir))
+    return (IdxLoader(paths[0], paths[1], batch_size, True, device, seed=1234 + rank),
+            IdxLoader(paths[2], paths[3], batch_size, False, device))
 
 
 def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0, make_engine=None):
@@ -131,7 +191,7 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
                                        last_batch=args.synthetic_last_batch)
         test_loader = SyntheticLoader(kind, args.batch_size, max(1, args.steps_per_epoch // 10), 4321, device)
     else:
-        train_loader, test_loader = _real_loaders(kind, args.batch_size)
+        train_loader, test_loader = _real_loaders(kind, args.batch_size, device, rank, args.data_dir)
     N_mini_batches = len(train_loader)
 
     model = mvae_cls(args.n_latents)

@@ -34,3 +34,22 @@ def test_train_cli(kind, extra, tmp_path):
     assert os.path.exists(ckpt) and os.path.exists(os.path.join(str(tmp_path), 'model_best.pth.tar'))
     state = torch.load(ckpt, map_location='cpu', weights_only=False)
     assert set(state) == {'state_dict', 'best_loss', 'n_latents', 'optimizer'}
+
+
+def test_mnist_cli_on_idx_files(tmp_path):
+    """Without --synthetic: the loaders read raw IDX files (no torchvision), keep the split in HBM as
+    uint8 and apply ToTensor on the device; the 37-image split leaves a short last batch."""
+    import numpy as np
+    from test_loader_cpu import write_idx
+    rng = np.random.RandomState(1)
+    data = tmp_path / 'data'
+    data.mkdir()
+    for stem, n in (('train', 37), ('t10k', 11)):
+        write_idx(str(data / ('%s-images-idx3-ubyte' % stem)), rng.randint(0, 256, (n, 28, 28)))
+        write_idx(str(data / ('%s-labels-idx1-ubyte' % stem)), rng.randint(0, 10, (n,)))
+    script = os.path.join(ROOT, 'multimodal-vae-public_amd', 'mnist', 'train.py')
+    cmd = [sys.executable, script, '--cuda', '--epochs', '2', '--batch-size', '8', '--n-latents', '16',
+           '--annealing-epochs', '2', '--log-interval', '2', '--data-dir', str(data), '--out-dir', str(tmp_path / 'out')]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'Train Epoch: 2 [16/37' in out.stdout and '====> Test Loss:' in out.stdout
