@@ -83,16 +83,21 @@ int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
  * identical attribute encoders / decoders (celeba19/model.py:29-30, 173-196) and the reference runs
  * them one after another (celeba19/model.py:78-81, 53-54); here operand g of every array is at
  * base + g * <name>_gs floats (the expert's slice of the parameter arena / of a [G, rows, width]
- * activation buffer).  No dropout mask, no split scratch.  Same maths as the single forms. */
+ * activation buffer; any two same-shaped problems qualify: the stride is the pointer difference,
+ * modulo 2^64).  No dropout mask.  ws (NULL = never split): G * mvae_gemm_ws_bytes of the single
+ * problem is always enough.  Same maths as the single forms. */
 int mvae_linear_fwd_grouped(const float *x, int ldx, size_t x_gs, const float *w, size_t w_gs,
                             const float *bias, size_t bias_gs, float *pre, float *act, int ldy,
-                            size_t y_gs, int G, int M, int N, int K, mvae_stream_t stream);
+                            size_t y_gs, int G, int M, int N, int K, void *ws, size_t ws_bytes,
+                            mvae_stream_t stream);
 int mvae_linear_dgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *w, size_t w_gs,
                               float *dx, int lddx, size_t dx_gs, const float *pre_in, size_t pre_gs,
-                              int G, int M, int N, int K, int flags, mvae_stream_t stream);
+                              int G, int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                              mvae_stream_t stream);
 int mvae_linear_wgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *x, int ldx,
                               size_t x_gs, float *dw, size_t dw_gs, float *db, size_t db_gs, int G,
-                              int M, int N, int K, int flags, mvae_stream_t stream);
+                              int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                              mvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K2  Conv2d 4x4, bias=False, (stride,pad) in {(2,1),(1,0)}: fashionmnist/model.py:79,81;

@@ -41,11 +41,11 @@ _SIGNATURES = {
     'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_wgrad': (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_fwd_grouped': (c_int, [P, c_int, c_size_t, P, c_size_t, P, c_size_t, P, P, c_int, c_size_t,
-                                        c_int, c_int, c_int, c_int, P]),
+                                        c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_dgrad_grouped': (c_int, [P, c_int, c_size_t, P, c_size_t, P, c_int, c_size_t, P, c_size_t,
-                                          c_int, c_int, c_int, c_int, c_int, P]),
+                                          c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_wgrad_grouped': (c_int, [P, c_int, c_size_t, P, c_int, c_size_t, P, c_size_t, P, c_size_t,
-                                          c_int, c_int, c_int, c_int, c_int, P]),
+                                          c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_conv2d_k4_fwd': (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
     'mvae_conv2d_k4_dgrad': (c_int, [P, P, P, P] + [c_int] * 7 + [P, c_size_t, P]),
     'mvae_conv2d_k4_wgrad': (c_int, [P, P, P] + [c_int] * 8 + [P, c_size_t, P]),

@@ -408,7 +408,16 @@ struct SplitSink {
     int ncls;                                 // parity classes (transposed conv) / groups (grouped Linear) folded into gridDim.x
     size_t rowsum_cls_stride;                 // grouped Linear wgrad: per-group offset of the bias gradient
     float *rowsum_final; int rowsum_final_accumulate;   // split launches: where the finish kernel puts the summed row sums
+    size_t cls_region;                        // grouped + split: class c keeps its partials at ws + c * cls_region
+    size_t rowsum_final_cls_stride;           //                  and its bias gradient at rowsum_final + c * this
 };
+
+// finish kernels of a grouped launch: one grid slice per class
+__device__ __forceinline__ void sink_select_class(SplitSink &sink, int cls) {
+    sink.ws += (size_t)cls * sink.cls_region;
+    if (sink.rowsum) sink.rowsum += (size_t)cls * sink.cls_region;
+    if (sink.rowsum_final) sink.rowsum_final += (size_t)cls * sink.rowsum_final_cls_stride;
+}
 
 // the bias gradient of a split Linear wgrad: sum the per-split row sums in split order
 __device__ __forceinline__ void finish_rowsum(const SplitSink &sink, int splits, int i) {
@@ -580,7 +589,8 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
             for (int r = 0; r < 16; ++r) {
                 const int i = ib + (r & 3) + 8 * (r >> 2);
                 if (partial) {
-                    if (i < sink.I) sink.ws[(size_t)split * sink.stride + (size_t)i * sink.J + j] = acc[x][y][r];
+                    if (i < sink.I)
+                        sink.ws[(size_t)cls * sink.cls_region + (size_t)split * sink.stride + (size_t)i * sink.J + j] = acc[x][y][r];
                 } else {
                     e.put(i, j, acc[x][y][r]);
                 }
@@ -602,6 +612,7 @@ __global__ __launch_bounds__(NTHREADS * KW, (KW == 1 ? 2 : 1)) void igemm_kernel
 template <class E>
 __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits, E e) {
     __shared__ float part[8][32];
+    sink_select_class(sink, blockIdx.z); e.set_class(blockIdx.z);
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + o, i = blockIdx.y;
     float s = 0.f;
@@ -637,6 +648,7 @@ __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits,
 // few splits: one thread per output, the chain is short
 template <class E>
 __global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int splits, E e) {
+    sink_select_class(sink, blockIdx.z); e.set_class(blockIdx.z);
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (sink.rowsum_final && j == 0) finish_rowsum(sink, splits, i);
     if (j >= sink.J || !e.col(j)) return;
@@ -648,6 +660,7 @@ __global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int spl
 // few splits, J % 4 == 0: one thread per 4 consecutive outputs, float4 partial loads
 template <class E>
 __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int splits, E e) {
+    sink_select_class(sink, blockIdx.y); e.set_class(blockIdx.y);
     const int jq = sink.J >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t nvec = (size_t)sink.I * jq;
@@ -784,14 +797,14 @@ int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitS
 #undef MVAE_LAUNCH
     if (pl.splits > 1) {
         if (pl.splits > 16) {
-            dim3 grid((J + 31) / 32, I);
+            dim3 grid((J + 31) / 32, I, sink.ncls);
             hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
         } else if (J % 4 == 0 && sink.stride % 4 == 0 && aligned16(sink.ws)) {
             const size_t nvec = (size_t)I * (J / 4) + (sink.rowsum_final ? I : 0);
-            hipLaunchKernelGGL((finish_few_vec_kernel<E>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, sink,
+            hipLaunchKernelGGL((finish_few_vec_kernel<E>), dim3((unsigned)((nvec + 255) / 256), sink.ncls), dim3(256), 0, st, sink,
                                pl.splits, e);
         } else {
-            dim3 grid((J + 255) / 256, I);
+            dim3 grid((J + 255) / 256, I, sink.ncls);
             hipLaunchKernelGGL((finish_few_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
         }
     }
@@ -803,7 +816,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     s.ws = (float *)ws; s.I = I; s.J = J;
     s.stride = (size_t)I * J + (rowsum ? I : 0);
     s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
-    s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0;
+    s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0; s.cls_region = 0; s.rowsum_final_cls_stride = 0;
     return s;
 }
 
@@ -1317,17 +1330,18 @@ MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len
 // Linear layers.  G > 1: G independent problems of one shape in ONE launch (celeba19's 18 attribute
 // experts, celeba19/model.py:173-196) -- operand g lives at base + g * group stride; the group index
 // rides on the class slot of the grid, so a layer of all 18 experts is 18x the blocks instead of 18
-// under-filled launches.  Grouped launches never split the reduction.
+// under-filled launches.  With scratch a grouped launch may split the reduction like a single one:
+// class c keeps its partials in its own region of the scratch, the finish launch has one grid slice per class.
 struct LinGroups { int G; size_t a, b, c, d; };     // meaning of a..d per entry point below
 
 static int linear_fwd_impl(const float *x, int ldx, const float *w, const float *bias, float *pre, float *act,
                            int ldy, const float *mask, float mask_scale, int M, int N, int K, void *ws,
                            size_t ws_bytes, LinGroups gr, hipStream_t st) {
     // gr: a = x stride, b = w stride, c = bias stride, d = pre/act stride
-    Plan pl = make_plan(M, N, K, ws != nullptr && gr.G == 1, PLAN_FWD, gr.G);
+    Plan pl = make_plan(M, N, K, ws != nullptr, PLAN_FWD, gr.G);
     SplitSink sink = make_sink(ws, M, N, false);
-    sink.ncls = gr.G;
-    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = pre; e.act = act; e.ld = ldy; e.bias = bias; e.dpre = nullptr; e.ldp = 0;
     e.mask = mask; e.ldm = N; e.mask_scale = mask_scale; e.I = M; e.J = N; e.accumulate = 0;
@@ -1343,10 +1357,10 @@ static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *d
                              const float *mask, float mask_scale, int M, int N, int K, int flags, void *ws,
                              size_t ws_bytes, LinGroups gr, hipStream_t st) {
     // D[i = m][j = k] = sum_n dy[m][n] * w[n][k];  gr: a = dy stride, b = w stride, c = pre_in stride, d = dx stride
-    Plan pl = make_plan(M, K, N, ws != nullptr && gr.G == 1, PLAN_FWD, gr.G);
+    Plan pl = make_plan(M, K, N, ws != nullptr, PLAN_FWD, gr.G);
     SplitSink sink = make_sink(ws, M, K, false);
-    sink.ncls = gr.G;
-    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
     EpRowMajor e;
     e.out = dx; e.act = nullptr; e.ld = lddx; e.bias = nullptr; e.dpre = pre_in; e.ldp = K;
     e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
@@ -1362,10 +1376,10 @@ static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *d
 static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db, int M, int N,
                              int K, int flags, void *ws, size_t ws_bytes, LinGroups gr, hipStream_t st) {
     // D[i = n][j = k] = sum_m dy[m][n] * x[m][k];  gr: a = dy stride, b = x stride, c = db stride, d = dw stride
-    Plan pl = make_plan(N, K, M, ws != nullptr && gr.G == 1, PLAN_LIN_WGRAD, gr.G);
+    Plan pl = make_plan(N, K, M, ws != nullptr, PLAN_LIN_WGRAD, gr.G);
     SplitSink sink = make_sink(ws, N, K, db != nullptr);
-    sink.ncls = gr.G;
-    if (pl.splits > 1 && ws_bytes < pl.splits * sink.stride * sizeof(float)) return MVAE_ERR_WS;
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
     const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
     EpRowMajor e;
     e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
@@ -1382,7 +1396,9 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
             sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc; sink.rowsum_cls_stride = gr.c;
         } else {
             sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
+            sink.rowsum_cls_stride = sink.cls_region;
             sink.rowsum_final = db; sink.rowsum_final_accumulate = acc;     // summed by the finish launch
+            sink.rowsum_final_cls_stride = gr.c;
         }
         rc = vec ? launch_igemm<LdRowsMN, LdRowsMN, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st)
                  : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
@@ -1423,28 +1439,31 @@ static inline bool groups_ok(int G) { return G >= 1 && G <= 4096; }
 
 MVAE_EXPORT int mvae_linear_fwd_grouped(const float *x, int ldx, size_t x_gs, const float *w, size_t w_gs,
                                         const float *bias, size_t bias_gs, float *pre, float *act, int ldy,
-                                        size_t y_gs, int G, int M, int N, int K, mvae_stream_t stream) {
+                                        size_t y_gs, int G, int M, int N, int K, void *ws, size_t ws_bytes,
+                                        mvae_stream_t stream) {
     if (!x || !w || (!pre && !act) || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N)
         return MVAE_ERR_ARG;
     const LinGroups gr = {G, x_gs, w_gs, bias_gs, y_gs};
-    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, nullptr, 1.f, M, N, K, nullptr, 0, gr, (hipStream_t)stream);
+    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, nullptr, 1.f, M, N, K, ws, ws_bytes, gr, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_linear_dgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *w, size_t w_gs,
                                           float *dx, int lddx, size_t dx_gs, const float *pre_in, size_t pre_gs,
-                                          int G, int M, int N, int K, int flags, mvae_stream_t stream) {
+                                          int G, int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                          mvae_stream_t stream) {
     if (!dy || !w || !dx || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
     const LinGroups gr = {G, dy_gs, w_gs, pre_gs, dx_gs};
-    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, nullptr, 1.f, M, N, K, flags, nullptr, 0, gr,
+    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, nullptr, 1.f, M, N, K, flags, ws, ws_bytes, gr,
                              (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_linear_wgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *x, int ldx,
                                           size_t x_gs, float *dw, size_t dw_gs, float *db, size_t db_gs, int G,
-                                          int M, int N, int K, int flags, mvae_stream_t stream) {
+                                          int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                          mvae_stream_t stream) {
     if (!dy || !x || !dw || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
     const LinGroups gr = {G, dy_gs, x_gs, db_gs, dw_gs};
-    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, nullptr, 0, gr, (hipStream_t)stream);
+    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, ws, ws_bytes, gr, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,

@@ -108,9 +108,10 @@ def linear_fwd_grouped(x, w0, w_gs, b0, b_gs, pre=None, act=None):
     out = _g3(pre if pre is not None else act, 'output')
     if pre is not None and act is not None and (act.stride() != pre.stride()):
         raise RuntimeError('pre and act must share a layout')
+    ws, wsb = _ws_args(G * _lib.lib().mvae_gemm_ws_bytes(M, N, K), x.device)
     check(_lib.lib().mvae_linear_fwd_grouped(_ptr(x), x.stride(1), x.stride(0), _ptr(w0), w_gs, _ptr(b0), b_gs,
                                              _ptr(pre), _ptr(act), out.stride(1), out.stride(0), G, M, N, K,
-                                             _stream()), 'mvae_linear_fwd_grouped')
+                                             ws, wsb, _stream()), 'mvae_linear_fwd_grouped')
 
 
 def linear_dgrad_grouped(dy, w0, w_gs, dx, pre_in=None, accumulate=False):
@@ -120,9 +121,10 @@ def linear_dgrad_grouped(dy, w0, w_gs, dx, pre_in=None, accumulate=False):
     _g3(dx, 'dx')
     if pre_in is not None and (not pre_in.is_contiguous() or pre_in.shape != (G, M, K)):
         raise RuntimeError('pre_in must be a contiguous [G, M, K] tensor')
+    ws, wsb = _ws_args(G * _lib.lib().mvae_gemm_ws_bytes(M, K, N), dy.device)
     check(_lib.lib().mvae_linear_dgrad_grouped(_ptr(dy), dy.stride(1), dy.stride(0), _ptr(w0), w_gs, _ptr(dx),
                                                dx.stride(1), dx.stride(0), _ptr(pre_in), M * K, G, M, N, K,
-                                               ACCUMULATE if accumulate else 0, _stream()),
+                                               ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
           'mvae_linear_dgrad_grouped')
 
 
@@ -130,9 +132,80 @@ def linear_wgrad_grouped(dy, x, dw0, dw_gs, db0=None, db_gs=0, accumulate=False)
     _need_gpu(dy, x, dw0, db0)
     G, M, N = _g3(dy, 'dy').shape
     K = _g3(x, 'x').shape[2]
+    ws, wsb = _ws_args(G * _lib.lib().mvae_gemm_ws_bytes(N, K, M), dy.device)
     check(_lib.lib().mvae_linear_wgrad_grouped(_ptr(dy), dy.stride(1), dy.stride(0), _ptr(x), x.stride(1),
                                                x.stride(0), _ptr(dw0), dw_gs, _ptr(db0), db_gs, G, M, N, K,
-                                               ACCUMULATE if accumulate else 0, _stream()),
+                                               ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
+          'mvae_linear_wgrad_grouped')
+
+
+# ---- pairs: two same-shaped Linear problems anywhere in memory as ONE grouped launch (G = 2); the group
+#      stride is the pointer difference modulo 2^64.  MNIST's image and text decoders share their first
+#      three layer shapes (mnist/model.py:96-104,137-145): pairing them halves those launches.
+_U64 = (1 << 64) - 1
+
+
+def _pair_stride(a, what):
+    a0, a1 = a
+    if (a0 is None) != (a1 is None):
+        raise RuntimeError('%s: both or neither of a pair' % what)
+    if a0 is None:
+        return 0
+    if a0.shape != a1.shape or a0.stride() != a1.stride() or a0.dtype != torch.float32 or a1.dtype != torch.float32:
+        raise RuntimeError('%s: the two problems of a pair must share shape, strides and dtype' % what)
+    d = a1.data_ptr() - a0.data_ptr()
+    if d % 4:
+        raise RuntimeError('%s: misaligned pair' % what)
+    return (d // 4) & _U64
+
+
+def _rows2d(t, what):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError('%s must be [rows, width] with unit column stride' % what)
+    return t
+
+
+def linear_fwd_pair(x, w, b, pre, act):
+    """(x0, x1), (w0, w1), (b0, b1), (pre0, pre1), (act0, act1): pre_g = x_g.w_g^T + b_g, act = swish."""
+    _need_gpu(*x, *w, *b, *pre, *act)
+    M, K = _rows2d(x[0], 'x').shape
+    N = w[0].shape[0]
+    out = pre if pre[0] is not None else act
+    if pre[0] is not None and act[0] is not None and pre[0].stride() != act[0].stride():
+        raise RuntimeError('pre and act must share a layout')
+    if _pair_stride(pre, 'pre') != _pair_stride(act, 'act') and pre[0] is not None and act[0] is not None:
+        raise RuntimeError('pre and act pairs must be laid out alike')
+    ws, wsb = _ws_args(2 * _lib.lib().mvae_gemm_ws_bytes(M, N, K), x[0].device)
+    check(_lib.lib().mvae_linear_fwd_grouped(_ptr(x[0]), x[0].stride(0), _pair_stride(x, 'x'), _ptr(w[0]),
+                                             _pair_stride(w, 'w'), _ptr(b[0]), _pair_stride(b, 'bias'),
+                                             _ptr(pre[0]), _ptr(act[0]), _rows2d(out[0], 'out').stride(0),
+                                             _pair_stride(out, 'out'), 2, M, N, K, ws, wsb, _stream()),
+          'mvae_linear_fwd_grouped')
+
+
+def linear_dgrad_pair(dy, w, dx, pre_in=(None, None), accumulate=False):
+    _need_gpu(*dy, *w, *dx, *pre_in)
+    M, N = _rows2d(dy[0], 'dy').shape
+    K = w[0].shape[1]
+    if pre_in[0] is not None and not (pre_in[0].is_contiguous() and pre_in[0].shape == (M, K)):
+        raise RuntimeError('pre_in must be contiguous [M, K]')
+    ws, wsb = _ws_args(2 * _lib.lib().mvae_gemm_ws_bytes(M, K, N), dy[0].device)
+    check(_lib.lib().mvae_linear_dgrad_grouped(_ptr(dy[0]), dy[0].stride(0), _pair_stride(dy, 'dy'), _ptr(w[0]),
+                                               _pair_stride(w, 'w'), _ptr(dx[0]), _rows2d(dx[0], 'dx').stride(0),
+                                               _pair_stride(dx, 'dx'), _ptr(pre_in[0]), _pair_stride(pre_in, 'pre_in'),
+                                               2, M, N, K, ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
+          'mvae_linear_dgrad_grouped')
+
+
+def linear_wgrad_pair(dy, x, dw, db=(None, None), accumulate=False):
+    _need_gpu(*dy, *x, *dw, *db)
+    M, N = _rows2d(dy[0], 'dy').shape
+    K = _rows2d(x[0], 'x').shape[1]
+    ws, wsb = _ws_args(2 * _lib.lib().mvae_gemm_ws_bytes(N, K, M), dy[0].device)
+    check(_lib.lib().mvae_linear_wgrad_grouped(_ptr(dy[0]), dy[0].stride(0), _pair_stride(dy, 'dy'), _ptr(x[0]),
+                                               x[0].stride(0), _pair_stride(x, 'x'), _ptr(dw[0]),
+                                               _pair_stride(dw, 'dw'), _ptr(db[0]), _pair_stride(db, 'db'), 2, M, N, K,
+                                               ACCUMULATE if accumulate else 0, ws, wsb, _stream()),
           'mvae_linear_wgrad_grouped')
 
 

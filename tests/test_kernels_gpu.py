@@ -158,6 +158,40 @@ def test_linear_grouped(G, M, N, Kd):
     assert_close(torch.stack([t for t in dbs]), 2 * db_ref, 'grouped bias grad accumulate')
 
 
+@pytest.mark.parametrize('M,N,Kd', [(1024, 512, 512), (1024, 512, 64), (96, 512, 512), (37, 10, 24)])
+def test_linear_pair(M, N, Kd):
+    """Two same-shaped problems at unrelated addresses (second one allocated FIRST: negative pointer
+    difference) as one grouped launch, including the shapes whose reduction gets split."""
+    second = [dev(g(M, Kd, seed=2)), dev(g(N, Kd, seed=4) * 0.1), dev(g(N, seed=6))]
+    first = [dev(g(M, Kd, seed=1)), dev(g(N, Kd, seed=3) * 0.1), dev(g(N, seed=5))]
+    x, w, b = (first[0], second[0]), (first[1], second[1]), (first[2], second[2])
+    pre = (torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV))
+    act = (torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV))
+    if (pre[1].data_ptr() - pre[0].data_ptr()) != (act[1].data_ptr() - act[0].data_ptr()):
+        buf = torch.empty(4, M, N, device=DEV)          # same spacing for pre and act
+        pre, act = (buf[0], buf[2]), (buf[1], buf[3])
+    K.linear_fwd_pair(x, w, b, pre, act)
+    for i in range(2):
+        ref = x[i].cpu() @ w[i].cpu().t() + b[i].cpu()
+        assert_close(pre[i], ref, 'pair fwd pre %d' % i)
+        assert_close(act[i], swish(ref), 'pair fwd act %d' % i)
+    dy = (dev(g(M, N, seed=7)), dev(g(M, N, seed=8)))
+    pin = torch.stack([g(M, Kd, seed=9), g(M, Kd, seed=10)]).to(DEV)
+    dx = torch.empty(2, M, Kd, device=DEV)
+    K.linear_dgrad_pair(dy, w, (dx[0], dx[1]), (pin[0], pin[1]))
+    for i in range(2):
+        assert_close(dx[i], (dy[i].cpu() @ w[i].cpu()) * swish_grad(pin[i].cpu()), 'pair dgrad %d' % i)
+    dw = (torch.empty(N, Kd, device=DEV), torch.empty(N, Kd, device=DEV))
+    db = (torch.empty(N, device=DEV), torch.empty(N, device=DEV))
+    if (dw[1].data_ptr() - dw[0].data_ptr()) % 16:
+        pytest.skip('allocator gave a 4-byte-granular spacing')
+    K.linear_wgrad_pair(dy, x, dw, db)
+    K.linear_wgrad_pair(dy, x, dw, db, accumulate=True)
+    for i in range(2):
+        assert_close(dw[i], 2 * (dy[i].cpu().t() @ x[i].cpu()), 'pair wgrad %d' % i)
+        assert_close(db[i], 2 * dy[i].cpu().sum(0), 'pair bias grad %d' % i)
+
+
 def test_embedding_grouped():
     G, R, W = 18, 300, 512
     idx = torch.randint(0, 2, (R, G), generator=torch.Generator().manual_seed(1)).float()
