@@ -117,6 +117,23 @@ def test_fused_step_matches_live_oracle(kind, batch):
     print('%s B=%d worst gradient rel err %.2e' % (kind, batch, worst))
 
 
+@pytest.mark.parametrize('kind,batch', [('mnist', 24), ('fashionmnist', 9)])
+def test_paired_decoder_launches_match_live_oracle(kind, batch, monkeypatch):
+    """MVAE_PAIR=1: the decoders' shared leading Linear layers as one launch for both (opt-in path)."""
+    monkeypatch.setenv('MVAE_PAIR', '1')
+    oracle, model, d = build_pair(kind, weight_seed=13)
+    image, label = OS.synthetic_batch(kind, batch, seed=78)
+    torch.manual_seed(6)
+    noise = OS.draw_bimodal_noise(batch, d, has_dropout=False)
+    total, terms, _ = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, 50.0, 0.41)
+    total.backward()
+    eng = BimodalStep(model, batch, 1.0, 50.0)
+    assert eng.pair_dec == (3 if kind == 'mnist' else 1)
+    elbo = eng.terms_in_reference_order(eng.step(image.to(DEV), label.to(DEV), 0.41, noise=noise)).cpu()
+    assert_close(elbo[:3], torch.stack(terms).detach(), 'ELBO terms')
+    check_grads_vs_oracle(model, oracle)
+
+
 @pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6)])
 def test_module_surface_matches_live_oracle(kind, batch):
     """The reference's own call pattern: three model() calls, three elbo_loss calls, backward
