@@ -1,0 +1,81 @@
+"""CPU: host-side logic of the drop-in that needs no kernel -- subset sampling of the 19-modality
+objective (celeba19/train.py:87-142), the grouped-launch stride check over the parameter arena, the
+train.py helper mirrors, the input pipeline's size rules."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mvae_amd
+from mvae_amd import layers as L
+from mvae_amd import preprocess as PP
+from mvae_amd.engine import sample_subsets
+from mvae_amd.train_common import AverageMeter
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                'multimodal-vae-public_amd'))
+
+
+def test_sample_subsets_shape_sizes_order_and_determinism():
+    a = sample_subsets(np.random.RandomState(3), 19, 6)
+    b = sample_subsets(np.random.RandomState(3), 19, 6)
+    assert a.shape == (6, 19) and a.dtype == bool and np.array_equal(a, b)
+    sizes = a.sum(axis=1)
+    assert (sizes >= 2).all() and (sizes <= 18).all()            # never a single modality, never all 19
+    assert list(sizes) == sorted(sizes)                           # grouped by size like the reference
+    assert len({tuple(r) for r in a}) == 6                        # distinct
+    assert sample_subsets(np.random.RandomState(0), 19, 0).shape == (0, 19)
+
+
+def test_sample_subsets_size_is_uniform_over_2_to_18():
+    rng = np.random.RandomState(11)
+    sizes = np.concatenate([sample_subsets(rng, 19, 1).sum(axis=1) for _ in range(3400)])
+    counts = np.bincount(sizes, minlength=19)[2:19]
+    assert counts.min() > 130 and counts.max() < 270              # 200 expected per size
+
+
+def test_celeba19_train_helpers():
+    from mvae_amd.celeba19 import train as T
+    pool = T.enumerate_combinations(5)
+    assert pool.shape == (sum(math.comb(5, k) for k in range(2, 5)), 5)
+    assert list(pool.sum(axis=1)) == sorted(pool.sum(axis=1))
+    cols = T.tensor_2d_to_list(torch.arange(12.).reshape(4, 3))
+    assert len(cols) == 3 and torch.equal(cols[1], torch.tensor([1., 4., 7., 10.]))
+    s = T.sample_combinations(T.enumerate_combinations(19)[:10], size=3)
+    assert s.shape == (3, 19)
+
+
+def test_grouped_plans_need_uniformly_strided_experts():
+    from mvae_amd.arena import ParamArena
+    model = mvae_amd.celeba19.model.MVAE(20)
+    ParamArena(model, order=model.arena_order(), adjacent=model.arena_adjacent())     # device-agnostic bookkeeping
+    enc = L.GroupedPlans([e.plan() for e in model.attr_encoders])
+    dec = L.GroupedPlans([d.plan() for d in model.attr_decoders])
+    for gp in (enc, dec):
+        for j in range(len(gp.plans[0])):
+            w0, w_gs, b0, b_gs = gp.layer(j)
+            assert w_gs > 0 and w_gs % 4 == 0                     # float4 loads stay aligned in every expert
+            first, second = gp.plans[0][j], gp.plans[1][j]
+            w1 = second.mod.weight if second.kind == 'emb' else L._lin_weights(second)[0]
+            assert w1.data_ptr() - w0.data_ptr() == 4 * w_gs
+    # experts of two different models do not sit at a uniform stride
+    other = mvae_amd.celeba19.model.MVAE(20)
+    ParamArena(other, order=other.arena_order(), adjacent=other.arena_adjacent())
+    mixed = L.GroupedPlans([model.attr_decoders[0].plan(), model.attr_decoders[1].plan(),
+                            other.attr_decoders[0].plan()])
+    with pytest.raises(RuntimeError):
+        mixed.layer(0)
+    # different structures cannot be grouped at all
+    with pytest.raises(RuntimeError):
+        L.GroupedPlans([model.attr_encoders[0].plan(), model.attr_decoders[0].plan()])
+
+
+def test_average_meter_and_size_rules():
+    m = AverageMeter()
+    m.update(2.0, 10); m.update(4.0, 30)
+    assert m.val == 4.0 and m.count == 40 and abs(m.avg - 3.5) < 1e-12
+    assert PP.resized_size(218, 178, 64) == (78, 64) and PP.center_crop_origin(78, 64, 64) == (7, 0)
+    assert PP.resized_size(100, 160, 64) == (64, 102)
