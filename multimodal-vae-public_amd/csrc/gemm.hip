@@ -20,7 +20,12 @@
 // Long reductions with a small output (weight gradients over the batch; Linear layers with
 // 6400 inputs or outputs) are split across blockIdx.z into a caller-provided workspace and
 // finished by `finish_kernel`, which sums the splits in a fixed order and applies the same
-// epilogue functor: deterministic, no atomics.
+// epilogue functor: deterministic, no atomics.  Grouped launches (G same-shaped problems, the group
+// index on the grid's class slot) keep one partial region per class.
+//
+// Three shapes do not fit the template and have their own kernels below: the stride-1 transposed conv
+// (convT_s1_kernel: dense GEMM + col2im), the <= 4-output-channel transposed conv (convT_small_kernel)
+// and the weight gradient of the <= 4-input-channel conv (wgrad_smallcin_kernel).
 #include <cstdlib>
 
 #include "common.h"
