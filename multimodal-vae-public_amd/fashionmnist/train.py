@@ -14,7 +14,7 @@ if __package__ in (None, ''):      # executed as a script, like the reference (`
 
 from ..functional import binary_cross_entropy_with_logits, cross_entropy  # noqa: E402,F401
 from ..functional import elbo_loss_label as elbo_loss  # noqa: E402
-from ..train_common import AverageMeter, add_extra_flags, make_load_checkpoint, run, save_checkpoint  # noqa: E402,F401
+from ..train_common import AverageMeter, make_load_checkpoint, reference_parser, run, save_checkpoint  # noqa: E402,F401
 from .model import MVAE  # noqa: E402
 
 load_checkpoint = make_load_checkpoint(MVAE)
@@ -31,26 +31,5 @@ def _test_total(model, image, text, args):
 
 
 if __name__ == "__main__":
-    import argparse
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--n-latents', type=int, default=64,
-                        help='size of the latent embedding [default: 64]')
-    parser.add_argument('--batch-size', type=int, default=100, metavar='N',
-                        help='input batch size for training [default: 100]')
-    parser.add_argument('--epochs', type=int, default=500, metavar='N',
-                        help='number of epochs to train [default: 500]')
-    parser.add_argument('--annealing-epochs', type=int, default=200, metavar='N',
-                        help='number of epochs to anneal KL for [default: 200]')
-    parser.add_argument('--lr', type=float, default=1e-3, metavar='LR',
-                        help='learning rate [default: 1e-3]')
-    parser.add_argument('--log-interval', type=int, default=10, metavar='N',
-                        help='how many batches to wait before logging training status [default: 10]')
-    parser.add_argument('--lambda-image', type=float, default=1.,
-                        help='multipler for image reconstruction [default: 1]')
-    parser.add_argument('--lambda-text', type=float, default=10.,
-                        help='multipler for text reconstruction [default: 10]')
-    parser.add_argument('--cuda', action='store_true', default=False,
-                        help='enables CUDA training [default: False]')
-    add_extra_flags(parser)
-    args = parser.parse_args()
+    args = reference_parser('fashionmnist').parse_args()
     run('fashionmnist', MVAE, _test_total, args, args.lambda_text, annealing_epoch_offset=1)

@@ -54,6 +54,48 @@ def make_load_checkpoint(mvae_cls):
     return load_checkpoint
 
 
+# The reference's command lines as data: (flag, type, default, how the default is printed, metavar, text).
+# mnist/train.py:133-154 (fashionmnist: same), celeba/train.py:119-140, celeba19/train.py:181-204.
+_SMALL = dict(n_latents=(64, '64'), epochs=(500, '500'), annealing=(200, '200'), lr=(1e-3, '1e-3'))
+_CELEBA = dict(n_latents=(100, '100'), epochs=(100, '100'), annealing=(20, '20'), lr=(1e-4, '1e-4'))
+
+
+def _reference_flags(kind):
+    d = _SMALL if kind in ('mnist', 'fashionmnist') else _CELEBA
+    label = 'text' if kind in ('mnist', 'fashionmnist') else 'attrs'
+    label_words = 'text' if label == 'text' else 'attributes'
+    flags = [
+        ('--n-latents', int, d['n_latents'], None, 'size of the latent embedding'),
+        ('--batch-size', int, (100, '100'), 'N', 'input batch size for training'),
+        ('--epochs', int, d['epochs'], 'N', 'number of epochs to train'),
+        ('--annealing-epochs', int, d['annealing'], 'N', 'number of epochs to anneal KL for'),
+        ('--lr', float, d['lr'], 'LR', 'learning rate'),
+        ('--log-interval', int, (10, '10'), 'N', 'how many batches to wait before logging training status'),
+    ]
+    if kind == 'celeba19':
+        flags.append(('--approx-m', int, (1, '1'), None, 'number of ELBO terms to approx. the full MVAE objective'))
+    flags += [
+        ('--lambda-image', float, (1., '1'), None, 'multipler for image reconstruction'),
+        ('--lambda-%s' % label, float, (10., '10'), None, 'multipler for %s reconstruction' % label_words),
+    ]
+    return flags
+
+
+def reference_parser(kind):
+    """argparse parser with exactly the reference's flags, defaults and help texts for ``kind``'s
+    train.py, plus the opt-in extras of ``add_extra_flags``."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    for flag, typ, (default, shown), metavar, text in _reference_flags(kind):
+        kw = dict(type=typ, default=default, help='%s [default: %s]' % (text, shown))
+        if metavar:
+            kw['metavar'] = metavar
+        parser.add_argument(flag, **kw)
+    parser.add_argument('--cuda', action='store_true', default=False, help='enables CUDA training [default: False]')
+    add_extra_flags(parser)
+    return parser
+
+
 def add_extra_flags(parser):
     parser.add_argument('--synthetic', action='store_true', default=False,
                         help='random-pixel / random-label batches instead of the dataset')

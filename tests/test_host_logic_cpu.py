@@ -79,3 +79,32 @@ def test_average_meter_and_size_rules():
     assert m.val == 4.0 and m.count == 40 and abs(m.avg - 3.5) < 1e-12
     assert PP.resized_size(218, 178, 64) == (78, 64) and PP.center_crop_origin(78, 64, 64) == (7, 0)
     assert PP.resized_size(100, 160, 64) == (64, 102)
+
+
+REF_DEFAULTS = {        # mnist/train.py:133-154, celeba/train.py:119-140, celeba19/train.py:181-204
+    'mnist': dict(n_latents=64, batch_size=100, epochs=500, annealing_epochs=200, lr=1e-3, log_interval=10,
+                  lambda_image=1.0, lambda_text=10.0, cuda=False),
+    'fashionmnist': dict(n_latents=64, batch_size=100, epochs=500, annealing_epochs=200, lr=1e-3, log_interval=10,
+                         lambda_image=1.0, lambda_text=10.0, cuda=False),
+    'celeba': dict(n_latents=100, batch_size=100, epochs=100, annealing_epochs=20, lr=1e-4, log_interval=10,
+                   lambda_image=1.0, lambda_attrs=10.0, cuda=False),
+    'celeba19': dict(n_latents=100, batch_size=100, epochs=100, annealing_epochs=20, lr=1e-4, log_interval=10,
+                     approx_m=1, lambda_image=1.0, lambda_attrs=10.0, cuda=False),
+}
+
+
+@pytest.mark.parametrize('kind', sorted(REF_DEFAULTS))
+def test_train_cli_has_the_reference_flags_and_defaults(kind):
+    from mvae_amd.train_common import reference_parser
+    parser = reference_parser(kind)
+    ns = vars(parser.parse_args([]))
+    for k, v in REF_DEFAULTS[kind].items():
+        assert ns[k] == v and type(ns[k]) is type(v), (kind, k, ns[k])
+    # the README's recommended invocations parse (README.md:47,83)
+    lam = '--lambda-text' if 'lambda_text' in REF_DEFAULTS[kind] else '--lambda-attrs'
+    ns = vars(parser.parse_args([lam, '50.', '--cuda', '--batch-size', '32']))
+    assert ns[lam[2:].replace('-', '_')] == 50.0 and ns['cuda'] is True and ns['batch_size'] == 32
+    text = parser.format_help()
+    assert 'size of the latent embedding [default: %d]' % REF_DEFAULTS[kind]['n_latents'] in text
+    assert ('learning rate [default: %s]' % ('1e-3' if kind in ('mnist', 'fashionmnist') else '1e-4')) in text
+    assert ('--approx-m' in text) == (kind == 'celeba19')
