@@ -217,12 +217,15 @@ def elbo_delta(kind, batch=32):
     total.backward()
     og = dict(oracle.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values())
+    # gradients that are zero in exact arithmetic -- the bias of a Linear that feeds a training-mode
+    # BatchNorm (celeba/model.py:148-151,175-181) -- are judged on the scale of the largest gradient;
+    # every other parameter on its own magnitude (same rule as tests/util.py:ZERO_GRAD_PARAMS)
+    zero_grad = ('attrs_encoder.net.0.bias', 'attrs_encoder.net.3.bias', 'attrs_decoder.net.0.bias',
+                 'attrs_decoder.net.3.bias', 'attrs_decoder.net.6.bias') if kind == 'celeba' else ()
     worst = 0.0
     for name, p in model.named_parameters():
         ref = og[name].grad
-        # gradients that are zero in exact arithmetic (a bias feeding BatchNorm) are judged on the
-        # scale of the largest gradient, as in tests/test_engine_gpu.py
-        scale = max(ref.abs().max().item(), 1e-2 * gmax)
+        scale = max(ref.abs().max().item(), 1e-2 * gmax if name in zero_grad else 0.0, 1e-30)
         worst = max(worst, (p.grad.cpu() - ref).abs().max().item() / scale)
     ref = total.item()
     return {'hip': round(got, 4), 'cpu': round(ref, 4), 'rel': float('%.3e' % (abs(got - ref) / abs(ref))),

@@ -29,8 +29,8 @@ def tensor_2d_to_list(x):
 
 def enumerate_combinations(n):
     """All subsets of n modalities with 2 .. n-1 members as an [n_subsets, n] boolean matrix ordered by size
-    (celeba19/train.py:87-108).  The fused step never materialises this pool -- it draws the
-    members directly (``engine.sample_subsets``) -- the function is kept for callers that
+    (celeba19/train.py:87-108).  The fused step never materialises this pool -- ``engine.sample_subsets`` makes the
+    same generator calls and un-ranks the drawn row numbers -- the function is kept for callers that
     index into it."""
     from itertools import combinations
     rows = []
@@ -44,10 +44,22 @@ def enumerate_combinations(n):
 
 
 def sample_combinations(pool, size=1):
-    """``size`` rows of the pool: a subset size uniformly, then a row of that size without
-    replacement (celeba19/train.py:111-142)."""
+    """``size`` rows of ``pool`` exactly as celeba19/train.py:111-142 picks them from the global
+    ``np.random`` state: a subset size per sample (uniform over the sizes present in the pool, with
+    replacement), then for each drawn size, in increasing order, that many distinct rows of the size's
+    block.  The fused step draws the same rows without a pool (``engine.sample_subsets``: identical
+    generator calls, row number -> members by un-ranking)."""
+    pool = np.asarray(pool)
     n = pool.shape[1]
-    return sample_subsets(np.random, n, size)
+    row_size = pool.sum(axis=1)
+    present = np.flatnonzero(np.bincount(row_size))
+    drawn = np.bincount(np.random.choice(present, size, replace=True), minlength=n)
+    picked = []
+    for k in range(n):
+        if drawn[k] > 0:
+            block = np.flatnonzero(row_size == k)
+            picked.append(block[np.random.choice(block.size, size=int(drawn[k]), replace=False)])
+    return pool[np.concatenate(picked)]
 
 
 def _test_total(model, image, attrs, args):
@@ -58,8 +70,14 @@ def _test_total(model, image, attrs, args):
 
 
 def _make_engine(model, args, rank, batch_size):
+    # subsets come from the global numpy generator, as in the reference (celeba19/train.py:286): the same
+    # np.random.seed gives the same subsets.  Data parallel: every rank seeds it identically once, so all
+    # ranks draw the same subsets each step and do equal work.
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not getattr(_make_engine, 'seeded', False):
+        np.random.seed(681307)
+        _make_engine.seeded = True
     return Celeba19Step(model, batch_size, args.lambda_image, args.lambda_attrs,
-                        approx_m=args.approx_m, seed=1 + rank)
+                        approx_m=args.approx_m, seed=1 + rank, rng=np.random)
 
 
 if __name__ == "__main__":

@@ -102,15 +102,19 @@ __global__ __launch_bounds__(256) void ce_kernel(const float *logits, const int6
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
     const float *x = logits + (size_t)r * K;
-    const int y = (int)label[r % label_rows];
+    const int64_t yraw = label[r % label_rows];
+    // a label outside 0..K-1 (the reference fails in scatter_, mnist/train.py:86-88) must not index the
+    // logits row: its loss row and gradient row become NaN, which the step's ELBO then shows
+    const bool bad = yraw < 0 || yraw >= K;
+    const int y = bad ? 0 : (int)yraw;
     float mx = -INFINITY;
     for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k] + 1e-6f);
     float se = 0.f;
     for (int k = 0; k < K; ++k) se += expf(x[k] + 1e-6f - mx);
     const float lse = logf(se) + mx;
-    if (row) row[r] = -((x[y] + 1e-6f) - lse);
+    if (row) row[r] = bad ? NAN : -((x[y] + 1e-6f) - lse);
     if (dlogits) {
-        const float dr = drow[r / rows_per_group];
+        const float dr = bad ? NAN : drow[r / rows_per_group];
         for (int k = 0; k < K; ++k) {
             const float p = expf(x[k] + 1e-6f - lse);
             dlogits[(size_t)r * K + k] = dr * (p - (k == y ? 1.f : 0.f));

@@ -66,9 +66,50 @@ def _restore(model, optimizer, counter, snap):
             optimizer._host_step = opt[3]
 
 
-def _pinned(*shape):
-    t = torch.zeros(*shape, dtype=torch.float32)
-    return t.pin_memory() if torch.cuda.is_available() else t
+class StepTables(object):
+    """The per-step device tables of a fused step (loss coefficients, PoE masks, BatchNorm update
+    count) as ONE int32 block in HBM refreshed by ONE async copy from pinned host memory.
+
+    The host may run several steps ahead of the GPU (graph replays are enqueue-only), so a pinned
+    buffer must not be rewritten while an earlier step's copy may still be reading it: the host side is a
+    ring of ``slots`` pinned blocks, each guarded by an event recorded right after its copy was queued;
+    ``begin()`` waits on the slot's previous event (``slots`` steps back) before handing it out."""
+
+    def __init__(self, n_words, device, slots=4):
+        import numpy as np
+        self.dev = torch.zeros(n_words, dtype=torch.int32, device=device)
+        self._host, self._np, self._events = [], [], []
+        for _ in range(slots):
+            h = torch.zeros(n_words, dtype=torch.int32)
+            if torch.cuda.is_available():
+                h = h.pin_memory()
+            self._host.append(h)
+            self._np.append(h.numpy())
+            self._events.append(None)
+        self._i = 0
+        self._np_float = [a.view(np.float32) for a in self._np]
+
+    def ints(self, lo, n):
+        return self.dev[lo:lo + n]
+
+    def floats(self, lo, n):
+        return self.dev[lo:lo + n].view(torch.float32)
+
+    def begin(self):
+        """(int32 view, float32 view) of the next pinned slot, safe to overwrite."""
+        k = self._i % len(self._host)
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        return self._np[k], self._np_float[k]
+
+    def commit(self):
+        k = self._i % len(self._host)
+        self.dev.copy_(self._host[k], non_blocking=True)
+        if torch.cuda.is_available():
+            if self._events[k] is None:
+                self._events[k] = torch.cuda.Event()
+            self._events[k].record()
+        self._i += 1
 
 
 class _StepBase(object):
@@ -278,8 +319,8 @@ class BimodalStep(_StepBase):
         self.pair_dec = self._pairable_decoder_layers() if os.environ.get('MVAE_PAIR', '0') == '1' else 0
         # per-term loss coefficients lambda/B, beta/B: pinned host mirror -> device, so a captured
         # graph sees new annealing factors without re-capture
-        self.coef_host = _pinned(3, self.T)
-        self.coef = torch.zeros(3, self.T, dtype=torch.float32, device=dev)
+        self.tables = StepTables(3 * self.T, dev)
+        self.coef = self.tables.floats(0, 3 * self.T).reshape(3, self.T)
         self.noise = torch.empty(self.T, B, self.D, dtype=torch.float32, device=dev)
         self.drop_masks = torch.empty(2, B, 512, dtype=torch.float32, device=dev) if self.has_dropout else None
         self.elbo = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
@@ -376,11 +417,13 @@ class BimodalStep(_StepBase):
     # ------------------------------------------------------------------ host-side setup per step
     def set_coefficients(self, annealing_factor):
         B = float(self.B)
+        _, c = self.tables.begin()
+        c = c.reshape(3, self.T)
         for t in range(self.T):
-            self.coef_host[0, t] = self.lambda_image / B if self.img_has_loss[t] else 0.0
-            self.coef_host[1, t] = self.lambda_label / B if self.lbl_has_loss[t] else 0.0
-            self.coef_host[2, t] = float(annealing_factor) / B
-        self.coef.copy_(self.coef_host, non_blocking=True)
+            c[0, t] = self.lambda_image / B if self.img_has_loss[t] else 0.0
+            c[1, t] = self.lambda_label / B if self.lbl_has_loss[t] else 0.0
+            c[2, t] = float(annealing_factor) / B
+        self.tables.commit()
 
     def set_noise(self, noise):
         """Parity mode: ``noise`` = {'eps': [3 x [B,D]], 'mask': [3 x [B,512] or None]} in the
@@ -532,25 +575,51 @@ class BimodalStep(_StepBase):
 N_ATTRS = 18
 
 
+def unrank_combination(n, k, index):
+    """Members of the ``index``-th k-subset of range(n) in the order ``itertools.combinations`` yields
+    them (lexicographic) -- the row order of the reference's pool within one subset size
+    (celeba19/train.py:99-101)."""
+    from math import comb
+    if not 0 <= index < comb(n, k):
+        raise IndexError('combination index %d out of range for C(%d,%d)' % (index, n, k))
+    members, first = [], 0
+    for slot in range(k, 0, -1):
+        # the block of subsets whose next member is ``first`` has C(n-first-1, slot-1) rows
+        while True:
+            block = comb(n - first - 1, slot - 1)
+            if index < block:
+                break
+            index -= block
+            first += 1
+        members.append(first)
+        first += 1
+    return members
+
+
 def sample_subsets(rng, n_modalities=19, size=1):
-    """``size`` random modality subsets like celeba19/train.py:111-142: a subset SIZE is drawn
-    uniformly from {2 .. n-1}, then a uniform subset of that size (distinct within a size).
-    The reference materialises all 524,267 subsets (:87-108) to index into; drawing the
-    members directly is the same distribution without the 10 MB pool."""
+    """``size`` modality subsets, draw for draw what ``sample_combinations(enumerate_combinations(n),
+    size)`` of celeba19/train.py:111-142 returns under the same generator state -- without the
+    524,267 x 19 pool (:87-108).  The reference makes exactly these generator calls:
+      1. ``choice(pool_space, size, replace=True)`` -- a subset SIZE per sample, pool_space = 2..n-1;
+      2. for each size k that was drawn c > 0 times, in increasing k:
+         ``choice(range(C(n,k)), size=c, replace=False)`` -- c distinct row numbers of the size-k block,
+    and a row number is the lexicographic rank of the subset (``unrank_combination``).  ``rng`` is
+    ``numpy.random`` (the reference's global generator) or a ``RandomState``.  Rows come back grouped by
+    size, in draw order within a size, like the reference's ``np.concatenate``."""
     import numpy as np
+    from math import comb
+    n = int(n_modalities)
     if size <= 0:
-        return np.zeros((0, n_modalities), dtype=bool)
-    out, seen = [], set()
-    while len(out) < size:
-        k = int(rng.randint(2, n_modalities))
-        members = tuple(sorted(rng.choice(n_modalities, k, replace=False).tolist()))
-        if members in seen:
-            continue
-        seen.add(members)
-        row = np.zeros(n_modalities, dtype=bool)
-        row[list(members)] = True
-        out.append(row)
-    out.sort(key=lambda r: int(r.sum()))       # the reference returns them grouped by size
+        return np.zeros((0, n), dtype=bool)
+    sizes = rng.choice(np.arange(2, n), size, replace=True)
+    counts = np.bincount(sizes, minlength=n)
+    out = []
+    for k in range(n):
+        if counts[k] > 0:
+            for r in rng.choice(comb(n, k), size=int(counts[k]), replace=False):
+                row = np.zeros(n, dtype=bool)
+                row[unrank_combination(n, k, int(r))] = True
+                out.append(row)
     return np.stack(out)
 
 
@@ -572,7 +641,7 @@ class Celeba19Step(_StepBase):
     """
 
     def __init__(self, model, batch_size, lambda_image=1.0, lambda_attrs=1.0, approx_m=1, seed=0,
-                 combo_seed=681307, faithful_bn_stats=True):
+                 combo_seed=681307, faithful_bn_stats=True, rng=None):
         import numpy as np
         self._init_common(model, batch_size, seed)
         self.lambda_image, self.lambda_attrs = float(lambda_image), float(lambda_attrs)
@@ -580,10 +649,13 @@ class Celeba19Step(_StepBase):
         self.T = 2 + N_ATTRS + self.M
         self.n_img = 2 + self.M
         self.S = self.M + 2                       # decoder slots: complete, sampled..., single
-        if self.n_img + N_ATTRS > 32 or self.T > 40:
-            raise ValueError('approx_m too large for the PoE kernel limits (experts <= 32, terms <= 40)')
+        if self.n_img + N_ATTRS >= 32 or self.T > 40:      # expert bits live in a signed 32-bit mask word
+            raise ValueError('approx_m too large for the PoE kernel limits (experts <= 31, terms <= 40): approx_m <= 11')
         self.faithful = bool(faithful_bn_stats)
-        self.rng = np.random.RandomState(combo_seed)      # same seed on every rank: same subsets
+        # subsets come from ``rng`` (``numpy.random`` = the reference's global generator: the same
+        # ``np.random.seed`` then gives the reference's subsets draw for draw) or a private
+        # RandomState(combo_seed) -- the same seed on every rank: same subsets, equal work
+        self.rng = rng if rng is not None else np.random.RandomState(combo_seed)
         B, D, dev, T, S = self.B, self.D, self.dev, self.T, self.S
         enc = model.image_encoder
         self.trunk = L.compile_plan(enc.trunk_modules())
@@ -595,18 +667,14 @@ class Celeba19Step(_StepBase):
         if self.grouped:
             self.enc_group = L.GroupedPlans(self.enc_plans)
             self.dec_group = L.GroupedPlans(self.dec_plans)
-        # device tables + pinned mirrors
-        self.masks_host = torch.zeros(T, dtype=torch.int32)
-        self.masks_dev = torch.zeros(T, dtype=torch.int32, device=dev)
-        self.coef_host = _pinned(3, T)            # rows: image, (unused), kl
-        self.coef = torch.zeros(3, T, dtype=torch.float32, device=dev)
-        self.coef_attr_host = _pinned(N_ATTRS * S)
-        self.coef_attr = torch.zeros(N_ATTRS * S, dtype=torch.float32, device=dev)
-        self.nimg_host = torch.zeros(1, dtype=torch.int32)
-        self.nimg_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        if torch.cuda.is_available():
-            self.masks_host = self.masks_host.pin_memory()
-            self.nimg_host = self.nimg_host.pin_memory()
+        # device tables: [masks int32 T | n_img int32 1 | coef f32 3*T (rows: image, unused, kl) | coef_attr f32 18*S]
+        self.tables = tb = StepTables(T + 1 + 3 * T + N_ATTRS * S, dev)
+        self._off = (0, T, T + 1, T + 1 + 3 * T)
+        self.masks_dev = tb.ints(0, T)
+        self.nimg_dev = tb.ints(T, 1)
+        self.coef = tb.floats(T + 1, 3 * T).reshape(3, T)
+        self.coef_attr = tb.floats(T + 1 + 3 * T, N_ATTRS * S)
+        self._beta = 1.0
         term_of = torch.zeros(N_ATTRS, S, dtype=torch.int32)
         for i in range(N_ATTRS):
             term_of[i, 0] = 0
@@ -621,45 +689,41 @@ class Celeba19Step(_StepBase):
         self.set_terms(sample_subsets(self.rng, 1 + N_ATTRS, self.M))
 
     # ------------------------------------------------------------------ host-side tables
-    def set_terms(self, combos):
-        """``combos``: bool [M, 19] (column 0 = image) -- the step's sampled subsets."""
+    def set_terms(self, combos, commit=True):
+        """``combos``: bool [M, 19] (column 0 = image) -- the step's sampled subsets.  ``commit=False``:
+        only remember them; the tables go to the device with the next ``set_coefficients``."""
         import numpy as np
-        combos = np.asarray(combos, dtype=bool).reshape(self.M, 1 + N_ATTRS)
-        self.combos = combos
-        n_img = self.n_img
-        m = self.masks_host
-        m[0] = 1 | (((1 << N_ATTRS) - 1) << n_img)            # complete: image draw 0 + all attributes
-        m[1] = 1 << 1                                         # image only: image draw 1
-        for i in range(N_ATTRS):
-            m[2 + i] = 1 << (n_img + i)
-        for j in range(self.M):
-            bits = (1 << (2 + j)) if combos[j, 0] else 0
-            for i in range(N_ATTRS):
-                if combos[j, 1 + i]:
-                    bits |= 1 << (n_img + i)
-            m[2 + N_ATTRS + j] = bits
-        self.masks_dev.copy_(m, non_blocking=True)
-        self.n_img_present = 2 + int(combos[:, 0].sum())
-        self.nimg_host[0] = self.n_img_present
-        self.nimg_dev.copy_(self.nimg_host, non_blocking=True)
+        self.combos = np.asarray(combos, dtype=bool).reshape(self.M, 1 + N_ATTRS)
+        self.n_img_present = 2 + int(self.combos[:, 0].sum())
+        if commit:
+            self.set_coefficients(self._beta)
 
     def set_coefficients(self, annealing_factor):
-        B, T, S, M = float(self.B), self.T, self.S, self.M
-        c = self.coef_host
-        c.zero_()
-        c[0, 0] = self.lambda_image / B
-        c[0, 1] = self.lambda_image / B
-        for j in range(M):                         # sampled terms omit the lambdas -> 1.0 (:294-300)
-            c[0, 2 + N_ATTRS + j] = (1.0 / B) if self.combos[j, 0] else 0.0
-        c[2, :] = float(annealing_factor) / B
-        self.coef.copy_(c, non_blocking=True)
-        ca = self.coef_attr_host
-        for i in range(N_ATTRS):
-            ca[i * S + 0] = self.lambda_attrs / B              # complete term uses lambda_attrs (:265-267)
-            for j in range(M):
-                ca[i * S + 1 + j] = (1.0 / B) if self.combos[j, 1 + i] else 0.0
-            ca[i * S + S - 1] = 1.0 / B                        # single-attribute terms omit it (:281-282)
-        self.coef_attr.copy_(ca, non_blocking=True)
+        """Fill one pinned slot with every per-step table and queue its copy (one DMA per step)."""
+        import numpy as np
+        B, T, S, M, n_img = float(self.B), self.T, self.S, self.M, self.n_img
+        combos = self.combos
+        self._beta = float(annealing_factor)
+        wi, wf = self.tables.begin()
+        o_mask, o_nimg, o_coef, o_attr = self._off
+        attr_bits = (combos[:, 1:].astype(np.int64) << (n_img + np.arange(N_ATTRS))).sum(axis=1)
+        m = np.zeros(T, dtype=np.int64)
+        m[0] = 1 | (((1 << N_ATTRS) - 1) << n_img)            # complete: image draw 0 + all attributes
+        m[1] = 1 << 1                                         # image only: image draw 1
+        m[2:2 + N_ATTRS] = 1 << (n_img + np.arange(N_ATTRS))
+        m[2 + N_ATTRS:] = attr_bits + np.where(combos[:, 0], 1 << (2 + np.arange(M)), 0)
+        wi[o_mask:o_mask + T] = m.astype(np.int32)
+        wi[o_nimg] = self.n_img_present
+        c = wf[o_coef:o_coef + 3 * T].reshape(3, T)
+        c[:] = 0.0
+        c[0, 0] = c[0, 1] = self.lambda_image / B
+        c[0, 2 + N_ATTRS:] = np.where(combos[:, 0], 1.0 / B, 0.0)   # sampled terms omit the lambdas -> 1.0 (:294-300)
+        c[2, :] = self._beta / B
+        ca = wf[o_attr:o_attr + N_ATTRS * S].reshape(N_ATTRS, S)
+        ca[:, 0] = self.lambda_attrs / B                      # complete term uses lambda_attrs (:265-267)
+        ca[:, 1:1 + M] = np.where(combos[:, 1:].T, 1.0 / B, 0.0)
+        ca[:, S - 1] = 1.0 / B                                # single-attribute terms omit it (:281-282)
+        self.tables.commit()
 
     def set_noise(self, noise):
         """``noise`` in the reference's term order (oracle.steps.draw_celeba19_noise)."""
@@ -678,11 +742,11 @@ class Celeba19Step(_StepBase):
         K.bernoulli_(self.drop_masks, KEEP, self.seed ^ 0x9E3779B97F4A7C15, self.counter)
 
     def step(self, image, attrs, annealing_factor, noise=None, combos=None):
-        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M), commit=False)
         return _StepBase.step(self, image, attrs, annealing_factor, noise=noise)
 
     def replay(self, image, attrs, annealing_factor, combos=None):
-        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+        self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M), commit=False)
         return _StepBase.replay(self, image, attrs, annealing_factor)
 
     def terms_in_reference_order(self, elbo):

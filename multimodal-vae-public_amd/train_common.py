@@ -159,24 +159,34 @@ class IdxLoader(object):
     Same iteration surface (len(), .dataset, (image float [B,1,28,28], label int64 [B]) batches, the
     short last batch kept, reshuffled every epoch when ``shuffle``)."""
 
-    def __init__(self, images_path, labels_path, batch_size, shuffle, device, seed=0):
+    def __init__(self, images_path, labels_path, batch_size, shuffle, device, seed=0, rank=0, world=1,
+                 n_classes=10):
         from . import preprocess
         self._to_tensor = preprocess.to_tensor
         images, labels = read_idx(images_path), read_idx(labels_path)
         if images.ndim != 3 or labels.ndim != 1 or images.shape[0] != labels.shape[0]:
             raise ValueError('unexpected IDX shapes %s / %s' % (images.shape, labels.shape))
+        if labels.size and int(labels.max()) >= n_classes:
+            # the loss kernel indexes the logits row with the label: refuse a corrupt file here, loudly
+            raise ValueError('%s: label %d outside 0..%d' % (labels_path, int(labels.max()), n_classes - 1))
         self.images = torch.from_numpy(images.copy()).to(device)
         self.labels = torch.from_numpy(labels.astype('int64')).to(device)
         self.batch_size, self.shuffle, self.device = int(batch_size), bool(shuffle), device
-        self.dataset = range(images.shape[0])
+        self.rank, self.world = int(rank), int(world)
+        # data parallel: every rank draws the SAME permutation (shared seed) and keeps order[rank::world],
+        # so one epoch is one pass over the data across all ranks (what a DistributedSampler does)
+        self.dataset = range(rank, images.shape[0], world)
+        self._n_total = images.shape[0]
         self._gen = torch.Generator().manual_seed(seed)
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        n = len(self.dataset)
-        order = (torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)).to(self.device)
+        n_total = self._n_total
+        order = torch.randperm(n_total, generator=self._gen) if self.shuffle else torch.arange(n_total)
+        order = order[self.rank::self.world].to(self.device)
+        n = order.numel()
         for i in range(0, n, self.batch_size):
             idx = order[i:i + self.batch_size]
             yield self._to_tensor(self.images[idx]), self.labels[idx]
@@ -191,7 +201,7 @@ def _find_idx(root, stem):
     return None
 
 
-def _real_loaders(kind, batch_size, device, rank=0, data_dir='./data'):
+def _real_loaders(kind, batch_size, device, rank=0, data_dir='./data', world=1):
     """The loaders of mnist/train.py:159-165 / fashionmnist/train.py:159-165 from the IDX files under
     ``data_dir`` (where torchvision's ``download=True`` puts them); this box has no network, so they
     must already be there.  CelebA's image folder + attribute file parsing is out of scope
@@ -202,7 +212,7 @@ def _real_loaders(kind, batch_size, device, rank=0, data_dir='./data'):
                                                     't10k-images-idx3-ubyte', 't10k-labels-idx1-ubyte')]
     if any(p is None for p in paths):
         raise SystemExit('no %s IDX files under %s (no network to download them): run with --synthetic' % (kind, data_dir))
-    return (IdxLoader(paths[0], paths[1], batch_size, True, device, seed=1234 + rank),
+    return (IdxLoader(paths[0], paths[1], batch_size, True, device, seed=1234, rank=rank, world=world),
             IdxLoader(paths[2], paths[3], batch_size, False, device))
 
 
@@ -233,7 +243,7 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
                                        last_batch=args.synthetic_last_batch)
         test_loader = SyntheticLoader(kind, args.batch_size, max(1, args.steps_per_epoch // 10), 4321, device)
     else:
-        train_loader, test_loader = _real_loaders(kind, args.batch_size, device, rank, args.data_dir)
+        train_loader, test_loader = _real_loaders(kind, args.batch_size, device, rank, args.data_dir, world)
     N_mini_batches = len(train_loader)
 
     model = mvae_cls(args.n_latents)
@@ -264,6 +274,7 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
                 eng = ragged.get(len(image))
                 if eng is None:
                     eng = ragged[len(image)] = build_engine(len(image))
+                    eng.counter = engine.counter      # one Philox stream: never replay the main engine's draws
                     if dp is not None:
                         eng.on_bucket_ready = dp.buckets.launch
                 elbo = eng.step(image, label, annealing_factor)
@@ -280,18 +291,19 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
                 if dp is not None:
                     dp.wait()
                 optimizer.step()
-            pending.append(elbo[-1].clone())
+            pending.append((elbo[-1].clone(), len(image)))
             if batch_idx % args.log_interval == 0:
-                for v in torch.stack(pending).tolist():      # ONE device->host sync per log line
-                    train_loss_meter.update(v, len(image))
+                # ONE device->host sync per log line
+                for v, n in zip(torch.stack([q[0] for q in pending]).tolist(), [q[1] for q in pending]):
+                    train_loss_meter.update(v, n)
                 pending = []
                 if rank == 0:
                     print('Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {:.6f}\tAnnealing-Factor: {:.3f}'.format(
                         epoch, batch_idx * len(image), len(train_loader.dataset),
                         100. * batch_idx / len(train_loader), train_loss_meter.avg, annealing_factor))
         if pending:
-            for v in torch.stack(pending).tolist():
-                train_loss_meter.update(v, args.batch_size)
+            for v, n in zip(torch.stack([q[0] for q in pending]).tolist(), [q[1] for q in pending]):
+                train_loss_meter.update(v, n)
         if rank == 0:
             print('====> Epoch: {}\tLoss: {:.4f}'.format(epoch, train_loss_meter.avg))
 
@@ -301,7 +313,9 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
         with torch.no_grad():
             for batch_idx, (image, label) in enumerate(test_loader):
                 image, label = image.to(device), label.to(device)
-                test_loss_meter.update(test_total(model, image, label, args).item(), len(image))
+                # celeba19/train.py:338 divides the sum of batch means by len(test_loader); the others weight by B
+                test_loss_meter.update(test_total(model, image, label, args).item(),
+                                       1 if kind == 'celeba19' else len(image))
         if rank == 0:
             print('====> Test Loss: {:.4f}'.format(test_loss_meter.avg))
         return test_loss_meter.avg

@@ -60,6 +60,66 @@ def test_fused_step_matches_live_oracle(approx_m, batch, with_image):
     print('celeba19 M=%d worst gradient rel err %.2e' % (approx_m, worst))
 
 
+def test_fused_step_matches_live_oracle_at_baseline_batch():
+    """BASELINE.json configs[4]: batch 256 per GPU, approx-m 1, lambda_attrs 10; subsets drawn the way
+    the reference's train loop draws them (same generator calls), 1e-4 on terms and every gradient,
+    1e-5 on the BatchNorm running statistics after the 21 image-decoder / 2-3 trunk updates."""
+    batch, approx_m = 256, 1
+    oracle, model, d = build_pair('celeba19', weight_seed=41)
+    image, attrs = OS.synthetic_batch('celeba19', batch, seed=93)
+    combos = sample_subsets(np.random.RandomState(2024), 19, approx_m)
+    terms = OS.celeba19_terms(combos)
+    torch.manual_seed(11)
+    noise = OS.draw_celeba19_noise(batch, d, terms)
+    total, elbos, lat = OS.celeba19_step(oracle, image, attrs, terms, noise, 1.0, 10.0, 0.5)
+    total.backward()
+    eng = Celeba19Step(model, batch, 1.0, 10.0, approx_m=approx_m)
+    elbo = eng.step(image.to(DEV), attrs.to(DEV), 0.5, noise=noise, combos=combos).cpu()
+    T = len(terms)
+    assert_close(elbo[:T], torch.stack(elbos).detach(), 'ELBO terms')
+    assert_close(elbo[T], total.detach(), 'total')
+    worst = check_grads_vs_oracle(model, oracle)
+    check_bn_vs(model, oracle.state_dict())
+    print('celeba19 B=256 M=1 (BASELINE size) worst gradient rel err %.2e' % worst)
+
+
+def test_step_tables_match_a_plain_loop():
+    """The per-step device tables (PoE masks, loss coefficients, BatchNorm update count) are filled
+    vectorised into one pinned block; check them against the obvious per-entry loop
+    (celeba19/train.py:265-302: which lambda each term uses)."""
+    _, model, d = build_pair('celeba19', weight_seed=43)
+    B, M = 4, 3
+    eng = Celeba19Step(model, B, 2.0, 7.0, approx_m=M)
+    combos = sample_subsets(np.random.RandomState(8), 19, M)
+    combos[1, 0] = True; combos[2, 0] = False
+    eng.set_terms(combos, commit=False)
+    eng.set_coefficients(0.25)
+    torch.cuda.synchronize()
+    n_img, S, T = eng.n_img, eng.S, eng.T
+    masks = [1 | (((1 << 18) - 1) << n_img), 1 << 1] + [1 << (n_img + i) for i in range(18)]
+    coef_img = [2.0 / B, 2.0 / B] + [0.0] * 18
+    for j in range(M):
+        bits = (1 << (2 + j)) if combos[j, 0] else 0
+        for i in range(18):
+            if combos[j, 1 + i]:
+                bits |= 1 << (n_img + i)
+        masks.append(bits)
+        coef_img.append(1.0 / B if combos[j, 0] else 0.0)
+    assert eng.masks_dev.cpu().tolist() == masks
+    assert eng.nimg_dev.item() == 2 + int(combos[:, 0].sum())
+    np.testing.assert_allclose(eng.coef[0].cpu().numpy(), np.array(coef_img, dtype=np.float32))
+    np.testing.assert_allclose(eng.coef[2].cpu().numpy(), np.full(T, 0.25 / B, dtype=np.float32))
+    ca = eng.coef_attr.cpu().numpy().reshape(18, S)
+    for i in range(18):
+        expect = [7.0 / B] + [1.0 / B if combos[j, 1 + i] else 0.0 for j in range(M)] + [1.0 / B]
+        np.testing.assert_allclose(ca[i], np.array(expect, dtype=np.float32))
+    # the ring: many refreshes without a sync leave the LAST values on the device
+    for k in range(9):
+        eng.set_coefficients(0.1 * k)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(eng.coef[2].cpu().numpy(), np.full(T, 0.8 / B, dtype=np.float32), rtol=1e-6)
+
+
 def test_module_surface_two_terms():
     """model(image, attrs) + elbo_loss on lists, as celeba19/train.py:264-283 calls them."""
     import mvae_amd.functional as MF
@@ -95,7 +155,7 @@ def test_module_surface_two_terms():
         if ref is None:
             assert p.grad is None or p.grad.abs().max().item() == 0, name
             continue
-        scale = max(ref.abs().max().item(), 1e-2 * gmax)
+        scale = max(ref.abs().max().item(), 1e-30)      # celeba19 has no mathematically-zero gradients: own magnitude
         err = (p.grad.cpu() - ref).abs().max().item() / scale
         assert err <= 1e-4, 'grad %s: %.3e' % (name, err)
 

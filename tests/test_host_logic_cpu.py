@@ -19,22 +19,75 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
                                 'multimodal-vae-public_amd'))
 
 
-def test_sample_subsets_shape_sizes_order_and_determinism():
+@pytest.fixture(scope='module')
+def full_pool():
+    from oracle import steps as OS
+    return OS.enumerate_combinations(19)          # 524,267 x 19, pinned to the reference's by make_golden.py
+
+
+def test_sample_subsets_equals_the_reference_draw_for_draw(full_pool, golden_dir):
+    """celeba19/train.py:111-142 under the same generator state: the poolless sampler of the fused step
+    returns the rows the reference's (= the oracle's, bit-checked against the reference when the goldens
+    were made) ``sample_combinations`` returns, and leaves the generator in the same state."""
+    from oracle import steps as OS
+    for seed in range(100):
+        for size in range(1, 9):
+            r_ref, r_hip = np.random.RandomState(seed), np.random.RandomState(seed)
+            ref = OS.sample_combinations(full_pool, size, rng=r_ref)
+            got = sample_subsets(r_hip, 19, size)
+            assert got.dtype == bool and got.shape == ref.shape == (size, 19)
+            assert np.array_equal(got, ref), 'seed %d size %d' % (seed, size)
+            assert r_ref.randint(1 << 30) == r_hip.randint(1 << 30), 'generator state diverged'
+    # the fixture captured from the reference itself: np.random.seed(4321), approx_m = 1
+    z = np.load(os.path.join(golden_dir, 'celeba19_b4.npz'), allow_pickle=False)
+    np.random.seed(4321)
+    assert np.array_equal(sample_subsets(np.random, 19, 1), z['combos'].astype(bool))
+
+
+def test_drop_in_sample_combinations_uses_the_global_generator_like_the_reference(full_pool):
+    from mvae_amd.celeba19 import train as T
+    from oracle import steps as OS
+    for seed in (0, 7, 4321):
+        np.random.seed(seed)
+        got = T.sample_combinations(full_pool, size=5)
+        ref = OS.sample_combinations(full_pool, 5, rng=np.random.RandomState(seed))
+        assert np.array_equal(got, ref)
+    # a partial pool (not all sizes present) goes through the same calls
+    part = full_pool[:400]
+    np.random.seed(3)
+    got = T.sample_combinations(part, size=4)
+    ref = OS.sample_combinations(part, 4, rng=np.random.RandomState(3))
+    assert np.array_equal(got, ref)
+
+
+def test_unrank_combination_is_itertools_order():
+    from itertools import combinations
+    from mvae_amd.engine import unrank_combination
+    for n, k in [(5, 2), (7, 3), (6, 5), (19, 2), (19, 18)]:
+        for i, c in enumerate(combinations(range(n), k)):
+            assert unrank_combination(n, k, i) == list(c)
+    with pytest.raises(IndexError):
+        unrank_combination(5, 2, 10)
+
+
+def test_sample_subsets_shape_and_edge_cases():
     a = sample_subsets(np.random.RandomState(3), 19, 6)
-    b = sample_subsets(np.random.RandomState(3), 19, 6)
-    assert a.shape == (6, 19) and a.dtype == bool and np.array_equal(a, b)
     sizes = a.sum(axis=1)
     assert (sizes >= 2).all() and (sizes <= 18).all()            # never a single modality, never all 19
     assert list(sizes) == sorted(sizes)                           # grouped by size like the reference
-    assert len({tuple(r) for r in a}) == 6                        # distinct
     assert sample_subsets(np.random.RandomState(0), 19, 0).shape == (0, 19)
 
 
-def test_sample_subsets_size_is_uniform_over_2_to_18():
-    rng = np.random.RandomState(11)
-    sizes = np.concatenate([sample_subsets(rng, 19, 1).sum(axis=1) for _ in range(3400)])
-    counts = np.bincount(sizes, minlength=19)[2:19]
-    assert counts.min() > 130 and counts.max() < 270              # 200 expected per size
+def test_step_tables_ring_on_cpu():
+    from mvae_amd.engine import StepTables
+    tb = StepTables(6, 'cpu', slots=2)
+    coef = tb.floats(2, 4)
+    for k in range(5):
+        wi, wf = tb.begin()
+        wi[0:2] = [k, -k]
+        wf[2:6] = 0.5 * k
+        tb.commit()
+    assert tb.ints(0, 2).tolist() == [4, -4] and coef.tolist() == [2.0] * 4
 
 
 def test_celeba19_train_helpers():
