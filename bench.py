@@ -300,6 +300,8 @@ def main():
                     help='tuning aid: run the data-parallel launch path (3 graphs + RCCL) even at world size 1')
     args = ap.parse_args()
     if args.force_tiling:
+        # the overrides exist only in the tuning build of the library
+        os.environ['MVAE_HIP_LIB'] = os.path.join(ROOT, 'multimodal-vae-public_amd', 'libmvae_hip_tuning.so')
         from mvae_amd import _lib
         wm, wn, sp, kw = (int(v) for v in args.force_tiling.split(','))
         _lib.lib().mvae_debug_set_tiling(wm, wn, sp)

@@ -14,7 +14,11 @@
  *     (`ws`, `ws_bytes`; size it with the matching *_ws_bytes query);
  *   - `stream` is a hipStream_t passed as void*; kernels are asynchronous, no host sync;
  *   - return 0 on success, <0 on error (MVAE_ERR_*); no C++ exception crosses the ABI;
- *   - re-entrant: no global mutable state.
+ *   - re-entrant: no global mutable state (launch plans are pure functions of the shapes).  The
+ *     tuning overrides at the end of this header exist only in the separate -DMVAE_TUNING build
+ *     (libmvae_hip_tuning.so, used by tools/gemm_bench.py); libmvae_hip.so does not export them;
+ *   - collectives are NOT part of this ABI: data-parallel replicas all-reduce the gradient arena with
+ *     torch.distributed (RCCL), see INTEGRATION.md.
  */
 #ifndef MVAE_HIP_H
 #define MVAE_HIP_H
@@ -46,12 +50,6 @@ int mvae_abi_version(void);
  * over reduce_len (split reductions, or the repacked weights of a transposed conv: pass
  * rows_out = Cin, cols_out = Cout*16 of the mirrored conv) */
 size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len);
-/* tuning hook: force the block tile (wm, wn in {1,2} = 64/128 rows/cols) and the number of
- * reduction splits of every subsequent GEMM-shaped launch; 0 = automatic.  Debug only. */
-void mvae_debug_set_tiling(int wm, int wn, int splits);
-/* tuning hook: force the number of k-wave groups (1, 2, 4) of 64x64-tile launches; 0 = automatic */
-void mvae_debug_set_kwaves(int kw);
-
 /* ------------------------------------------------------------------------------------
  * K1  Linear (nn.Linear forward / backward): mnist/model.py:75-78,95-98,117-119,136-139;
  *     fashionmnist/model.py:84-86,107-109,135-137,155-161; celeba/model.py:89-92,114,
@@ -322,6 +320,23 @@ int mvae_resize_crop_u8_to_f32(const uint8_t *src, float *dst, int B, int H, int
                                const int *bx_dev, int ksx, const int *ky_dev, const int *by_dev,
                                int ksy, int y0, int y1, mvae_stream_t stream);
 int mvae_u8_to_f32(const uint8_t *src, float *dst, size_t n, mvae_stream_t stream);
+
+#ifdef MVAE_TUNING
+/* ------------------------------------------------------------------------------------
+ * Tuning overrides -- libmvae_hip_tuning.so only (the same sources built with -DMVAE_TUNING).
+ * Process-global, not thread-safe, not part of the product ABI.
+ * ---------------------------------------------------------------------------------- */
+/* force the per-wave tile (wm, wn in {1,2}: 64/128 rows/cols per block) and the number of reduction
+ * splits of every subsequent GEMM-shaped launch; 0 = automatic; splits < 0: forward forms never split */
+void mvae_debug_set_tiling(int wm, int wn, int splits);
+/* force the number of k-wave groups (1, 2, 4) of 64x64-tile launches; 0 = automatic */
+void mvae_debug_set_kwaves(int kw);
+/* off != 0: never use the small (64x32 / 32x64 / 32x32, BK = 64) Linear layouts; waves in {4, 8}: force
+ * their block size; 0 = automatic */
+void mvae_debug_set_small(int off, int waves);
+/* blocks a split reduction aims for; 0 = automatic */
+void mvae_debug_set_split_target(long blocks);
+#endif
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,6 @@ P = c_void_p
 _SIGNATURES = {
     'mvae_abi_version': (c_int, []),
     'mvae_gemm_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'mvae_debug_set_tiling': (None, [c_int, c_int, c_int]),
-    'mvae_debug_set_kwaves': (None, [c_int]),
     'mvae_linear_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_float, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_wgrad': (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
@@ -94,6 +92,16 @@ _SIGNATURES = {
     'mvae_bce_elem_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
 }
 
+# tuning overrides: only exported by libmvae_hip_tuning.so (csrc built with -DMVAE_TUNING); bound when
+# MVAE_HIP_LIB points the loader at that build (tools/gemm_bench.py, bench.py --force-tiling)
+_TUNING_SIGNATURES = {
+    'mvae_debug_set_tiling': (None, [c_int, c_int, c_int]),
+    'mvae_debug_set_kwaves': (None, [c_int]),
+    'mvae_debug_set_small': (None, [c_int, c_int]),
+    'mvae_debug_set_split_target': (None, [ctypes.c_long]),
+}
+TUNING_LIB_PATH = os.path.join(_HERE, 'libmvae_hip_tuning.so')
+
 _lib = None
 
 
@@ -105,15 +113,21 @@ def exported_symbols():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get('MVAE_HIP_LIB') or LIB_PATH     # an alternative BUILD of the same library
+        if not os.path.exists(path):
             raise RuntimeError(
                 'libmvae_hip.so is not built (%s missing): run `make -C %s/csrc`; there is no '
-                'CPU fallback for the MVAE HIP path.' % (LIB_PATH, _HERE))
-        handle = ctypes.CDLL(LIB_PATH)
+                'CPU fallback for the MVAE HIP path.' % (path, _HERE))
+        handle = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _TUNING_SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         if handle.mvae_abi_version() != 2:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle

@@ -1,0 +1,784 @@
+// conv.hip -- Conv2d / ConvTranspose2d 4x4 (forward, data gradient, weight gradient) on the implicit-GEMM
+// kernel of gemm_core.h: the gather loaders, the three special-shape kernels and the C ABI.
+#include "gemm_core.h"
+
+namespace {
+
+// Geometry of a 4x4 convolution y[B,Cout,OH,OW] = conv(x[B,Cin,H,W], w[Cout,Cin,4,4]).
+struct ConvGeom {
+    int B, Cin, H, W, Cout, OH, OW, stride, pad;
+};
+
+// ---- gather loaders ----------------------------------------------------------------------
+// The k index of an element a thread fetches is  k0 + kq + STEP*v  with k0 a multiple of BK = 32,
+// kq = thread-constant (< STEP) and v the unrolled element counter.  STEP is a power of two, so the
+// (channel, tap-row, tap-col) fields of k are the OR of compile-time fields of STEP*v and the
+// thread-constant fields of kq: per element the address is ONE add of a wave-uniform offset, the
+// bounds test a compile-time shift of a precomputed bit mask.  (The first version decoded k and
+// re-tested the image bounds per element and was VALU-bound: 5 waves x ~250 VALU ops per k-step
+// against 1024 MFMA cycles.)
+
+// im2col of x for the forward conv: element (k = (ci,kh,kw), m = (b,oh,ow)); lanes along m.
+template <int TILE_>
+struct LdIm2col {
+    static constexpr int TILE = TILE_, BKV = BK;
+    static constexpr int NV = TILE * BK / NTHREADS;   // elements per thread
+    static constexpr int KSTEP = NTHREADS / TILE;     // 2 or 4: k rows covered per pass
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
+    const float *x; ConvGeom g; int Mtot;
+    int base, kq; unsigned vh, vwq;
+    __device__ void init(int tile0, int t, int) {
+        const int m = tile0 + (t % TILE);
+        kq = t / TILE;
+        unsigned vw = 0;
+        vh = 0; base = 0;
+        if (m < Mtot) {
+            const int ohw = g.OH * g.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            base = (b * g.Cin * g.H + ih0) * g.W + iw0 + kq;      // kw = kq + (KSTEP*v & 3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ih0 + q >= 0 && ih0 + q < g.H) vh |= 1u << q;
+                if (iw0 + q >= 0 && iw0 + q < g.W) vw |= 1u << q;
+            }
+        }
+        vwq = vw >> kq;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int hw = g.H * g.W;
+        const float *src = x + base + (k0 >> 4) * hw;
+        const int safe = (int)(x - src);              // offset of x[0]: always a legal address
+        const int krem = kend - k0 - kq;              // element valid iff KSTEP*v < krem
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = KSTEP * v;                  // compile-time after unrolling
+            const int kwl = c & 3, kh = (c >> 2) & 3, cil = c >> 4;
+            const bool ok = (c < krem) && ((vh >> kh) & 1u) && ((vwq >> kwl) & 1u);
+            const float val = src[ok ? cil * hw + kh * g.W + kwl : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = false;
+    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int m = t % TILE, kb = t / TILE;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+};
+
+// Transposed-conv (dgrad) gather of dy for the output parity class `cls` = (ph,pw) of dx:
+// element (k = (co,a,b), m = (n, ih', iw')) with ih = ih'*s + ph, kh = kh0 + s*a,
+// oh = (ih + pad - kh0)/s - a.  TPD = 4/s taps per dim (TLOG = log2 TPD); only the taps that can
+// reach the class are enumerated, so stride 2 does no multiply-by-zero work.
+template <int TILE_, int TLOG>
+struct LdDgradDyT {
+    static constexpr int TILE = TILE_, BKV = BK;
+    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int KSTEP = NTHREADS / TILE;
+    static constexpr int TMASK = (1 << TLOG) - 1;
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
+    const float *dy; ConvGeom g; int Mtot; int H2, W2;
+    int base, kq; unsigned vhq, vwq;
+    __device__ void init(int tile0, int t, int cls) {
+        const int ph = cls / g.stride, pw = cls % g.stride;
+        const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
+        const int m = tile0 + (t % TILE);
+        kq = t / TILE;
+        const int aq = (kq >> TLOG) & TMASK, bq = kq & TMASK;     // thread-constant tap fields
+        unsigned vh = 0, vw = 0;
+        base = 0;
+        if (m < Mtot) {
+            const int hw2 = H2 * W2;
+            const int n = m / hw2, rem = m - n * hw2;
+            const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
+            const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
+            const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
+            base = (n * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
+#pragma unroll
+            for (int a = 0; a <= TMASK; ++a) {
+                if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
+                if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
+            }
+        }
+        vhq = vh >> aq; vwq = vw >> bq;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int ohw = g.OH * g.OW;
+        const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
+        const int safe = (int)(dy - src);
+        const int krem = kend - k0 - kq;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = KSTEP * v;
+            const int bl = c & TMASK, al = (c >> TLOG) & TMASK, col = c >> (2 * TLOG);
+            const bool ok = (c < krem) && ((vhq >> al) & 1u) && ((vwq >> bl) & 1u);
+            const float val = src[ok ? col * ohw - al * g.OW - bl : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = false;
+    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int m = t % TILE, kb = t / TILE;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+};
+template <int TILE_> using LdDgradDyS2 = LdDgradDyT<TILE_, 1>;   // stride 2: 2x2 taps per class
+template <int TILE_> using LdDgradDyS1 = LdDgradDyT<TILE_, 2>;   // stride 1: all 4x4 taps
+
+// wgrad operands: the reduction runs over k = (b,oh,ow); lanes along k (spatially contiguous).
+// P: element (i = co, k) = dy[b][co][oh][ow].
+template <int TILE_>
+struct LdWgradDy {
+    static constexpr int TILE = TILE_, BKV = BK;
+    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int ISTEP = NTHREADS / BK;
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
+    const float *dy; ConvGeom g;
+    int ioff, nvalid;       // ioff = i * OHW of element 0; nvalid = how many of the NV rows are < Cout
+    __device__ void init(int tile0, int t, int) {
+        const int ib = tile0 + t / BK;
+        ioff = ib * g.OH * g.OW;
+        nvalid = (g.Cout - ib + ISTEP - 1) / ISTEP;     // rows ib + v*ISTEP < Cout  <=>  v < nvalid
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int k = k0 + (t % BK);
+        const int ohw = g.OH * g.OW;
+        const int b = k / ohw, sp = k - b * ohw;
+        const float *src = dy + (size_t)b * g.Cout * ohw + sp + ioff;
+        const int safe = (int)(dy - src);
+        const int nv = (k < kend) ? nvalid : 0;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float val = src[(v < nv) ? v * ISTEP * ohw : safe];
+            rg.v[v] = val;
+            okbits |= ((v < nv) ? 1u : 0u) << v;
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = false;
+    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int kl = t % BK, ib = t / BK;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+};
+
+// Q: element (k, j = (ci,kh,kw)) = x[b][ci][oh*s-p+kh][ow*s-p+kw];  j = j0 + jq + 8*v, jq = t/32 < 8.
+template <int TILE_>
+struct LdWgradX {
+    static constexpr int TILE = TILE_, BKV = BK;
+    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int JSTEP = NTHREADS / BK;       // 8
+    struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
+    const float *x; ConvGeom g; int J;
+    int joff, jq, nvalid;
+    __device__ void init(int tile0, int t, int) {
+        jq = t / BK;                                  // kw = jq & 3, kh = (jq >> 2) + 2*(v & 1), ci = j0/16 + (v >> 1)
+        joff = (tile0 >> 4) * g.H * g.W + (jq >> 2) * g.W + (jq & 3);
+        nvalid = (J - tile0 - jq + JSTEP - 1) / JSTEP;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int k = k0 + (t % BK);
+        const int ohw = g.OH * g.OW;
+        const int b = k / ohw, sp = k - b * ohw;
+        const int oh = sp / g.OW, ow = sp - oh * g.OW;
+        const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+        const int hw = g.H * g.W;
+        const float *src = x + (size_t)b * g.Cin * hw + ih0 * g.W + iw0 + joff;
+        const int safe = (int)(x - src);
+        const int iw = iw0 + (jq & 3), ihq = ih0 + (jq >> 2);
+        const bool okw = k < kend && iw >= 0 && iw < g.W;
+        const bool ok0 = okw && ihq >= 0 && ihq < g.H;            // kh = jq>>2       (v even)
+        const bool ok1 = okw && ihq + 2 >= 0 && ihq + 2 < g.H;    // kh = (jq>>2) + 2 (v odd)
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool ok = ((v & 1) ? ok1 : ok0) && v < nvalid;
+            const float val = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
+            rg.v[v] = val;
+            okbits |= (ok ? 1u : 0u) << v;
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = false;
+    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int kl = t % BK, jb = t / BK;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+};
+
+// wr[cls][(co,a,b)][ci] = w[co][ci][kh0 + s*a][kw0 + s*b]: the weights of one output parity class of
+// a transposed conv, reduction index major / input channel contiguous, so the dgrad-form GEMM
+// fetches them with coalesced float4 loads instead of a 64-byte-stride gather.
+__global__ __launch_bounds__(256) void repack_dgrad_weights_kernel(const float *w, float *wr, int Cout, int Cin,
+                                                                   int stride, int pad) {
+    const int tlog = (stride == 2) ? 1 : 2, tpd = 1 << tlog;
+    const int kc = Cout * tpd * tpd;                 // reduction length per class
+    const int total = stride * stride * kc * Cin;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ci = idx % Cin;
+        int rest = idx / Cin;
+        const int k = rest % kc, cls = rest / kc;
+        const int ph = cls / stride, pw = cls % stride;
+        const int kh0 = (ph + pad) % stride, kw0 = (pw + pad) % stride;
+        const int co = k >> (2 * tlog), a = (k >> tlog) & (tpd - 1), b = k & (tpd - 1);
+        wr[idx] = w[((co * Cin + ci) * 4 + kh0 + stride * a) * 4 + kw0 + stride * b];
+    }
+}
+
+inline ConvGeom make_geom(int B, int Cin, int H, int W, int Cout, int stride, int pad) {
+    ConvGeom g;
+    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.stride = stride; g.pad = pad;
+    g.OH = (H + 2 * pad - 4) / stride + 1;
+    g.OW = (W + 2 * pad - 4) / stride + 1;
+    return g;
+}
+
+inline bool conv_args_ok(int B, int Cin, int H, int W, int Cout, int stride, int pad) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H < 4 - 2 * pad || W < 4 - 2 * pad) return false;
+    if (!((stride == 2 && pad == 1) || (stride == 1 && pad == 0))) return false;
+    if (stride == 2 && ((H & 1) || (W & 1))) return false;
+    // int32 offsets inside the gathers
+    if ((long)B * Cin * H * W >= (1L << 31) || (long)B * Cout * H * W >= (1L << 31)) return false;
+    return true;
+}
+
+// ---- conv forward form: y[n][co][oh][ow] = sum_k w[co][k] * im2col(x)[k][(n,oh,ow)] ----
+int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const float *dpre,
+                  ConvGeom g, hipStream_t st) {
+    const int I = g.Cout, J = g.B * g.OH * g.OW, K = g.Cin * 16;
+    Plan pl = make_plan(I, J, K, false);
+    EpNCHW e;
+    e.out = pre; e.act = act; e.dpre = dpre;
+    e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
+    e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+    auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
+    auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
+    if (aligned16(w))
+        return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+    return launch_igemm<LdRowsKS, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+}
+
+// ---- direct transposed conv for <= 4 OUTPUT channels (ConvTranspose2d(32,3) / (64,1), stride 2,
+//      pad 1: celeba/model.py:126, fashionmnist/model.py:114).  As a GEMM these have a 3-row output
+//      tile (5 % MFMA utilisation); they are HBM/L1-bound streaming ops instead: one thread owns the
+//      2x2 output quad (2a..2a+1, 2b..2b+1) of every channel, which depends on the 3x3 dy
+//      neighbourhood (a-1..a+1, b-1..b+1) of each of the Cout input maps; weights sit in LDS. ----
+template <int C>
+__global__ __launch_bounds__(256) void convT_small_kernel(const float *dy, const float *w, float *out, float *act,
+                                                          const float *dpre, ConvGeom g, int total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [Cout][C][4][4]
+    for (int i = threadIdx.x; i < g.Cout * C * 16; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int OH = g.OH, OW = g.OW;                  // dy is [B][Cout][OH][OW]; out [B][C][2*OH][2*OW]
+    const int b = idx % OW, a = (idx / OW) % OH, n = idx / (OW * OH);
+    float acc[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f; }
+    const bool rm = a > 0, rp = a + 1 < OH, cm = b > 0, cp = b + 1 < OW;
+    const float *src = dy + ((size_t)n * g.Cout * OH + a) * OW + b;
+    for (int co = 0; co < g.Cout; ++co, src += OH * OW) {
+        float d[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool ok = (r == 1 || (r == 0 ? rm : rp)) && (q == 1 || (q == 0 ? cm : cp));
+                d[r][q] = ok ? src[(r - 1) * OW + (q - 1)] : 0.f;
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 *wp = reinterpret_cast<const float4 *>(wl + (co * C + c) * 16);
+            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];    // rows kh = 0..3, fields kw
+            // (ph,pw) = (0,0): kh in {1,3} <-> rows a, a-1 ; kw in {1,3} <-> cols b, b-1
+            acc[c][0] += w1.y * d[1][1] + w1.w * d[1][0] + w3.y * d[0][1] + w3.w * d[0][0];
+            // (0,1): kw in {0,2} <-> cols b+1, b
+            acc[c][1] += w1.x * d[1][2] + w1.z * d[1][1] + w3.x * d[0][2] + w3.z * d[0][1];
+            // (1,0): kh in {0,2} <-> rows a+1, a
+            acc[c][2] += w0.y * d[2][1] + w0.w * d[2][0] + w2.y * d[1][1] + w2.w * d[1][0];
+            acc[c][3] += w0.x * d[2][2] + w0.z * d[2][1] + w2.x * d[1][2] + w2.z * d[1][1];
+        }
+    }
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t o = (((size_t)n * C + c) * H + 2 * a + ph) * W + 2 * b;
+            float v0 = acc[c][ph * 2], v1 = acc[c][ph * 2 + 1];
+            if (dpre) { v0 *= swish_grad_(dpre[o]); v1 *= swish_grad_(dpre[o + 1]); }
+            if (out) *reinterpret_cast<float2 *>(out + o) = make_float2(v0, v1);
+            if (act) *reinterpret_cast<float2 *>(act + o) = make_float2(swishf_(v0), swishf_(v1));
+        }
+    }
+}
+
+inline bool conv_dgrad_small_ok(const ConvGeom &g) {
+    return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && g.H == 2 * g.OH && g.W == 2 * g.OW &&
+           (size_t)g.Cout * g.Cin * 16 * sizeof(float) <= 48 * 1024;
+}
+
+inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *act, const float *dpre,
+                            ConvGeom g, hipStream_t st) {
+    const int total = g.B * g.OH * g.OW;
+    const size_t lds = (size_t)g.Cout * g.Cin * 16 * sizeof(float);
+    const dim3 grid((total + 255) / 256), blk(256);
+    switch (g.Cin) {
+        case 1: hipLaunchKernelGGL(convT_small_kernel<1>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        case 2: hipLaunchKernelGGL(convT_small_kernel<2>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        case 3: hipLaunchKernelGGL(convT_small_kernel<3>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+        default: hipLaunchKernelGGL(convT_small_kernel<4>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
+    }
+    return mvae_launch_status();
+}
+
+// ---- stride-1 transposed conv as a DENSE GEMM + in-register/LDS col2im (ConvTranspose2d(256,128,4,1,0)
+//      5x5 -> 8x8 and the dgrad of Conv2d(128,256,4,1,0): celeba/model.py:85,117).  In the gather
+//      form only 39 % of the (output pixel, tap) pairs are inside the 5x5 input, so 61 % of the MFMA
+//      work multiplies zeros.  Here the GEMM is  col[(n,oh,ow)][(ci,kh,kw)] = sum_co dy[n,co,oh,ow] *
+//      w[co,ci,kh,kw]  (every product is real; the 25 positions of an image are padded to one 32-row
+//      MFMA tile = 78 % utilisation), and the scatter-add  dx[n,ci,oh+kh,ow+kw] += col  happens inside
+//      the wave that owns the tile: a wave holds one image x 2 input channels x 16 taps, i.e.
+//      everything two output planes need.  Block = 2 images x 4 channels; k loop over Cout. ----
+__global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
+                                                          const float *dpre, ConvGeom g) {
+    constexpr int BMX = 64, BNX = 64;
+    __shared__ __attribute__((aligned(16))) float Ps[2][BK][BMX + LPAD];
+    __shared__ __attribute__((aligned(16))) float Qs[2][BK][BNX + LPAD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int P = g.OH * g.OW;                      // positions per image (<= 32)
+    const int n0 = blockIdx.y * 2, ci0 = blockIdx.x * 4;
+    const int K = g.Cout, J = g.Cin * 16;
+    // P loader: lanes along the position axis, 4 k rows per pass
+    const int pi = t & 63, pkq = t >> 6;
+    const int pimg = pi >> 5, ppos = pi & 31;
+    const bool pok = ppos < P && n0 + pimg < g.B;
+    const float *psrc = dy + ((size_t)(pok ? n0 + pimg : 0) * K) * P + (pok ? ppos : 0);
+    // Q loader: weight rows are contiguous in (ci, tap): 16 float4 per k row, 2 per thread
+    const float *qsrc = w + (size_t)ci0 * 16;
+    float pr[8], pm[8];
+    float4 qr[2];
+    float qm[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int k = k0 + pkq + 4 * v;
+            pm[v] = (pok && k < K) ? 1.f : 0.f;
+            pr[v] = psrc[(size_t)min(k, K - 1) * P];
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int f = t + 256 * v, k = k0 + (f >> 4), c4 = (f & 15) * 4;
+            qm[v] = (k < K) ? 1.f : 0.f;
+            qr[v] = *reinterpret_cast<const float4 *>(qsrc + (size_t)min(k, K - 1) * J + c4);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) Ps[buf][pkq + 4 * v][pi] = pr[v] * pm[v];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int f = t + 256 * v;
+            *reinterpret_cast<float4 *>(&Qs[buf][f >> 4][(f & 15) * 4]) =
+                make_float4(qr[v].x * qm[v], qr[v].y * qm[v], qr[v].z * qm[v], qr[v].w * qm[v]);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int nsteps = (K + BK - 1) / BK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load((s + 1) * BK);
+        float a0 = Ps[buf][lrow][wi * 32 + lcol], b0 = Qs[buf][lrow][wj * 32 + lcol];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a1 = 0.f, b1 = 0.f;
+            if (kk + 1 < BK / 2) {
+                a1 = Ps[buf][(kk + 1) * 2 + lrow][wi * 32 + lcol];
+                b1 = Qs[buf][(kk + 1) * 2 + lrow][wj * 32 + lcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1; b0 = b1;
+        }
+        if (s + 1 < nsteps) store(buf ^ 1);
+        __syncthreads();
+    }
+    // col2im inside the wave: park the 32 (positions) x 32 (2 channels x 16 taps) tile in LDS ...
+    float *sc = &Ps[0][0][0] + wave * (32 * 33);        // 4 x 4224 B <= the P tile buffers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+        sc[row * 33 + lcol] = acc[r];
+    }
+    __syncthreads();
+    // ... and let each lane gather the <= 16 taps of its output pixels
+    const int n = n0 + wi;
+    if (n >= g.B) return;
+    const int HW = g.H * g.W;
+    for (int cl = 0; cl < 2; ++cl) {
+        const int ci = ci0 + wj * 2 + cl;
+        if (ci >= g.Cin) break;
+        for (int px = lane; px < HW; px += 64) {
+            const int ih = px / g.W, iw = px - ih * g.W;
+            float v = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oh = ih - kh;
+                if (oh < 0 || oh >= g.OH) continue;
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ow = iw - kw;
+                    if (ow < 0 || ow >= g.OW) continue;
+                    v += sc[(oh * g.OW + ow) * 33 + cl * 16 + kh * 4 + kw];
+                }
+            }
+            const size_t o = ((size_t)n * g.Cin + ci) * HW + px;
+            if (dpre) v *= swish_grad_(dpre[o]);
+            if (out) out[o] = v;
+            if (act) act[o] = swishf_(v);
+        }
+    }
+}
+
+inline bool conv_dgrad_s1_ok(const ConvGeom &g, const float *w) {
+    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && aligned16(w);
+}
+
+inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act, const float *dpre, ConvGeom g,
+                         hipStream_t st) {
+    dim3 grid(g.Cin / 4, (g.B + 1) / 2);
+    hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g);
+    return mvae_launch_status();
+}
+
+inline size_t dgrad_ws_floats(const ConvGeom &g) { return (size_t)g.Cout * g.Cin * 16; }
+
+// ---- conv dgrad form: dx[n][ci][ih][iw] = sum_(co,kh,kw) w[co][ci][kh][kw] * dy[n][co][oh][ow],
+//      one launch per output parity class (4 for stride 2, 1 for stride 1) on repacked weights ----
+int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, const float *dpre,
+                    ConvGeom g, void *ws, size_t ws_bytes, hipStream_t st) {
+    const int s = g.stride, tlog = (s == 2) ? 1 : 2;
+    const int H2 = g.H / s, W2 = g.W / s;
+    const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << (2 * tlog);
+    if (conv_dgrad_small_ok(g) && !MVAE_TUNE(wm)) return conv_dgrad_small(dy, w, dx, act, dpre, g, st);
+    if (conv_dgrad_s1_ok(g, w) && !MVAE_TUNE(wm)) return conv_dgrad_s1(dy, w, dx, act, dpre, g, st);
+    if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
+    float *wr = (float *)ws;
+    {
+        const int total = s * s * K * g.Cin;
+        int blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(repack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wr, g.Cout, g.Cin, s, g.pad);
+    }
+    Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
+    const bool vec = (g.Cin % 4 == 0) && aligned16(wr);
+    EpNCHW e;
+    e.out = dx; e.act = act; e.dpre = dpre;
+    e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
+    e.sy = s; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+    auto mp = [&](auto &p) {
+        p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.Klen = K; p.cls_stride = (size_t)K * g.Cin;
+    };
+    auto mq = [&](auto &q) { q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; };
+    SplitSink sink = make_sink(nullptr, I, J, false);
+    sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
+    if (vec) {
+        if (s == 2) return launch_igemm<LdRowsMN, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+        return launch_igemm<LdRowsMN, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    }
+    if (s == 2) return launch_igemm<LdRowsMNS, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    return launch_igemm<LdRowsMNS, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+}
+
+// ---- weight gradient of the <= 4-input-channel convs (Conv2d(3,32) / ConvTranspose2d(32,3) of CelebA,
+//      Conv2d(1,64) / ConvTranspose2d(64,1) of FashionMNIST; stride 2, pad 1).  The output is 32..64 x
+//      16..48 values over a reduction of B*OH*OW ~ 10^5..10^6: as an implicit GEMM that is ONE
+//      under-filled tile split 512 ways, a third of whose gathered columns are padding (62 / 107 us on
+//      CelebA B = 256).  It is an HBM-bound op (46 / 92 MB): here every wave streams whole output rows --
+//      unit (b, oh): the CO x OW slab of dy and the CI x 4 input rows it touches, both staged through
+//      the wave's own LDS with coalesced float4 loads -- and multiplies them with MFMAs (k = ow);
+//      per-block partials go to scratch and the ordinary split finish sums them in a fixed order. ----
+constexpr int SC_MAXW = 64;                 // input row length limit
+constexpr int SC_XW = SC_MAXW + 8;          // staged input row: 4 zero floats, the row, 4 zero floats
+constexpr int SC_DW = 33;                   // staged dy row (OW <= 32, odd pitch: conflict-free fragment reads)
+
+constexpr int SC_WAVES = 8;                 // waves per block, each streaming its own units
+
+template <int MT, int NT>
+__global__ __launch_bounds__(64 * SC_WAVES) void wgrad_smallcin_kernel(const float *dy, const float *x, float *ws, ConvGeom g,
+                                                             int units) {
+    extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+    constexpr int CO = 32 * MT;
+    constexpr int WAVE_FLOATS = CO * SC_DW + 16 * SC_XW;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float *dys = sc_lds + wave * WAVE_FLOATS;          // [CO][SC_DW]
+    float *xs = dys + CO * SC_DW;                      // [CI*4][SC_XW]
+    const int J = g.Cin * 16, OW = g.OW, W = g.W;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // zero the halos of the input rows once (the row bodies are rewritten per unit)
+    for (int i = lane; i < g.Cin * 4 * 8; i += 64) {
+        const int row = i >> 3, c = i & 7;
+        xs[row * SC_XW + (c < 4 ? c : W + c)] = 0.f;
+    }
+    const int lr = lane & 31, lk = lane >> 5;
+    // per-lane column j = (ci, kh, kw) of each column tile
+    int xoff[NT]; float xmask[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int j = b * 32 + lr;
+        const bool ok = j < J;
+        const int jj = ok ? j : 0;
+        xoff[b] = ((jj >> 4) * 4 + ((jj >> 2) & 3)) * SC_XW + 4 - 1 + (jj & 3);      // + 2*k at use
+        xmask[b] = ok ? 1.f : 0.f;
+    }
+    // registers of the NEXT unit: its global loads are in flight while this unit is multiplied
+    constexpr int NDY = 8 * MT;                 // float2 per lane for CO x OW <= 32*MT x 32
+    constexpr int NX = 4;                       // float4 per lane for <= 16 rows x 64
+    float2 dyr[NDY]; float4 xr[NX];
+    const int v2 = OW >> 1, v4 = W >> 2;
+    auto fetch = [&](int u) {
+        const int b = u / g.OH, oh = u - b * g.OH;
+        const float *dyb = dy + ((size_t)b * CO * g.OH + oh) * OW;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = lane + 64 * i;
+            const int co = min(e / v2, CO - 1), c2 = e % v2;       // clamped: always a legal address
+            dyr[i] = *reinterpret_cast<const float2 *>(dyb + (size_t)co * g.OH * OW + c2 * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = lane + 64 * i;
+            const int row = min(e / v4, g.Cin * 4 - 1), c4 = e % v4;
+            const int ci = row >> 2, ih = 2 * oh - 1 + (row & 3);
+            const int ihc = min(max(ih, 0), g.H - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)b * g.Cin + ci) * g.H + ihc) * W + c4 * 4);
+            const float m = (ih >= 0 && ih < g.H) ? 1.f : 0.f;      // rows outside the image are zero padding
+            xr[i] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = lane + 64 * i;
+            if (e < CO * v2) {
+                const int co = e / v2, c2 = e % v2;
+                dys[co * SC_DW + c2 * 2] = dyr[i].x; dys[co * SC_DW + c2 * 2 + 1] = dyr[i].y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = lane + 64 * i;
+            if (e < g.Cin * 4 * v4) {
+                const int row = e / v4, c4 = e % v4;
+                *reinterpret_cast<float4 *>(xs + row * SC_XW + 4 + c4 * 4) = xr[i];
+            }
+        }
+    };
+    const int nwaves = gridDim.x * SC_WAVES;
+    int u = blockIdx.x * SC_WAVES + wave;
+    if (u < units) fetch(u);
+    for (; u < units; u += nwaves) {
+        stage();
+        __builtin_amdgcn_wave_barrier();
+        if (u + nwaves < units) fetch(u + nwaves);
+        // ---- k = ow in pairs
+        for (int q = 0; q < (OW >> 1); ++q) {
+            const int k = 2 * q + lk;
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = dys[(a * 32 + lr) * SC_DW + k];
+#pragma unroll
+            for (int b2 = 0; b2 < NT; ++b2) bf[b2] = xs[xoff[b2] + 2 * k] * xmask[b2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < NT; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b2], acc[a][b2], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- sum the waves' partials in a fixed order, write this block's [CO][J] partial
+    __syncthreads();
+    float *red = sc_lds;                               // (SC_WAVES - 1) x MT*NT tiles of 1024 floats
+    if (wave > 0) {
+        float *dst = red + (wave - 1) * MT * NT * 1024 + lane;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * NT + b) * 16 + r) * 64] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float *out = ws + (size_t)blockIdx.x * CO * J;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r];
+#pragma unroll
+                for (int w2 = 0; w2 < SC_WAVES - 1; ++w2) v += red[w2 * MT * NT * 1024 + ((a * NT + b) * 16 + r) * 64 + lane];
+                const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, j = b * 32 + lr;
+                if (j < J) out[(size_t)co * J + j] = v;
+            }
+}
+
+inline bool wgrad_smallcin_ok(const ConvGeom &g) {
+    return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && (g.Cout == 32 || g.Cout == 64) && g.OW <= 32 &&
+           (g.OW & 1) == 0 && g.W <= SC_MAXW && (g.W & 3) == 0;
+}
+inline int wgrad_smallcin_blocks(const ConvGeom &g) {
+    const int units = g.B * g.OH;
+    int blocks = (units + SC_WAVES - 1) / SC_WAVES;
+    return blocks > 256 ? 256 : blocks;      // one 8-wave block per CU; more partials only slow the finish
+}
+
+// ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----
+int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int flags, void *ws,
+                    size_t ws_bytes, hipStream_t st) {
+    const int I = g.Cout, J = g.Cin * 16, K = g.B * g.OH * g.OW;
+    EpRowMajor e;
+    e.out = dw; e.act = nullptr; e.ld = J; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
+    e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = I; e.J = J;
+    e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+    if (wgrad_smallcin_ok(g) && !MVAE_TUNE(wm) && !MVAE_TUNE(splits) && ws) {
+        const int blocks = wgrad_smallcin_blocks(g);
+        if (ws_bytes >= (size_t)blocks * I * J * sizeof(float)) {
+            const int mt = I / 32, nt = (J + 31) / 32;
+            const size_t wave_b = ((size_t)I * SC_DW + 16 * SC_XW) * sizeof(float);
+            const size_t red_b = (size_t)(SC_WAVES - 1) * mt * nt * 1024 * sizeof(float);
+            const size_t lds = SC_WAVES * wave_b > red_b ? SC_WAVES * wave_b : red_b;
+#define MVAE_SC(MT_, NT_)                                                                                   \
+    {                                                                                                       \
+        auto kern = wgrad_smallcin_kernel<MT_, NT_>;                                                        \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);              \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SC_WAVES), lds, st, dy, x, (float *)ws, g, g.B * g.OH); \
+    }
+            if (mt == 1 && nt == 1) MVAE_SC(1, 1)
+            else if (mt == 1) MVAE_SC(1, 2)
+            else if (nt == 1) MVAE_SC(2, 1)
+            else MVAE_SC(2, 2)
+#undef MVAE_SC
+            SplitSink fs = make_sink(ws, I, J, false);
+            if (blocks > 16) {
+                hipLaunchKernelGGL((finish_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(256), 0, st, fs, blocks, e);
+            } else {
+                hipLaunchKernelGGL((finish_few_kernel<EpRowMajor>), dim3((J + 255) / 256, I), dim3(256), 0, st, fs,
+                                   blocks, e);
+            }
+            return mvae_launch_status();
+        }
+    }
+    Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
+    SplitSink sink = make_sink(ws, I, J, false);
+    if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
+    auto mp = [&](auto &p) { p.dy = dy; p.g = g; };
+    auto mq = [&](auto &q) { q.x = x; q.g = g; q.J = J; };
+    return launch_igemm<LdWgradDy, LdWgradX, EpRowMajor, false>(pl, mp, mq, e, I, J, K, sink, st);
+}
+
+}  // namespace
+
+
+MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
+                                   int H, int W, int Cout, int stride, int pad, mvae_stream_t stream) {
+    if (!x || !w || (!pre && !act) || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
+    return conv_fwd_impl(x, w, pre, act, nullptr, make_geom(B, Cin, H, W, Cout, stride, pad), (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_conv2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,
+                                     int Cin, int H, int W, int Cout, int stride, int pad, void *ws,
+                                     size_t ws_bytes, mvae_stream_t stream) {
+    if (!dy || !w || !dx || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
+    return conv_dgrad_impl(dy, w, dx, nullptr, pre_in, make_geom(B, Cin, H, W, Cout, stride, pad), ws, ws_bytes,
+                           (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_conv2d_k4_wgrad(const float *dy, const float *x, float *dw, int B, int Cin, int H, int W,
+                                     int Cout, int stride, int pad, int flags, void *ws, size_t ws_bytes,
+                                     mvae_stream_t stream) {
+    if (!dy || !x || !dw || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
+    return conv_wgrad_impl(dy, x, dw, make_geom(B, Cin, H, W, Cout, stride, pad), flags, ws, ws_bytes,
+                           (hipStream_t)stream);
+}
+
+// ConvTranspose2d(Cin -> Cout), x[B,Cin,H,W] -> y[B,Cout,OH,OW], OH = (H-1)*s - 2p + 4, w[Cin,Cout,4,4]:
+// the mirrored conv maps y-shaped tensors (its input, Cout channels) to x-shaped ones (its output).
+static inline bool convT_geom(int B, int Cin, int H, int W, int Cout, int stride, int pad, ConvGeom *g) {
+    const int OH = (H - 1) * stride - 2 * pad + 4, OW = (W - 1) * stride - 2 * pad + 4;
+    if (!conv_args_ok(B, Cout, OH, OW, Cin, stride, pad)) return false;
+    *g = make_geom(B, /*conv Cin*/ Cout, OH, OW, /*conv Cout*/ Cin, stride, pad);
+    return g->OH == H && g->OW == W;
+}
+
+MVAE_EXPORT int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
+                                    int H, int W, int Cout, int stride, int pad, void *ws, size_t ws_bytes,
+                                    mvae_stream_t stream) {
+    ConvGeom g;
+    if (!x || !w || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
+    return conv_dgrad_impl(x, w, pre, act, nullptr, g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,
+                                      int Cin, int H, int W, int Cout, int stride, int pad,
+                                      mvae_stream_t stream) {
+    ConvGeom g;
+    if (!dy || !w || !dx || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
+    return conv_fwd_impl(dy, w, dx, nullptr, pre_in, g, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_convT2d_k4_wgrad(const float *dy, const float *x, float *dw, int B, int Cin, int H, int W,
+                                      int Cout, int stride, int pad, int flags, void *ws, size_t ws_bytes,
+                                      mvae_stream_t stream) {
+    ConvGeom g;
+    if (!dy || !x || !dw || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
+    // mirrored conv: "dy" operand is the transpose's input x, "x" operand is the transpose's dy
+    return conv_wgrad_impl(x, dy, dw, g, flags, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,793 @@
+// gemm_core.h -- the dense contractions of the MVAE train step on fp32 MFMA (gfx950).
+//
+// One LDS-tiled kernel template, `igemm_kernel`, computes D[i][j] = sum_k P(i,k) * Q(k,j)
+// with v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on MI355X).  What differs between
+// Linear fwd/dgrad/wgrad, Conv2d 4x4 fwd/dgrad/wgrad and ConvTranspose2d is only
+//   * how the P and Q tiles are fetched from HBM (loader functors: row-major vector loads,
+//     implicit-im2col gathers, parity-decomposed transposed-conv gathers), and
+//   * what the epilogue does with the accumulator tile (bias / swish / dropout mask / swish'
+//     of the producer's pre-activation / accumulate / NCHW scatter).
+// The j axis is the lane axis of the MFMA result (32 consecutive j per store instruction),
+// so each op maps its memory-contiguous output axis to j.
+//
+// Tiling: 256 threads = 4 waves (2 x 2), each wave WM x WN MFMA tiles of 32x32
+// (block tile 64*WM x 64*WN), BK = 32.  Software pipeline: global -> registers two k-tiles
+// ahead (two register sets), registers -> LDS one tile ahead (two LDS buffers), ONE barrier per
+// k-step; the fp32 MFMA (64 cycles each) of tile t hides the HBM/L2 latency of tile t+2.
+// LDS tiles are [BK][tile + 4]: fragment reads are bank-conflict free (ds_read_b32, lanes
+// 0..31 consecutive), float4 tile rows stay 16-byte aligned.
+//
+// Long reductions with a small output (weight gradients over the batch; Linear layers with
+// 6400 inputs or outputs) are split across blockIdx.z into a caller-provided workspace and
+// finished by `finish_kernel`, which sums the splits in a fixed order and applies the same
+// epilogue functor: deterministic, no atomics.  Grouped launches (G same-shaped problems, the group
+// index on the grid's class slot) keep one partial region per class.
+//
+// Three shapes do not fit the template and have their own kernels below: the stride-1 transposed conv
+// (convT_s1_kernel: dense GEMM + col2im), the <= 4-output-channel transposed conv (convT_small_kernel)
+// and the weight gradient of the <= 4-input-channel conv (wgrad_smallcin_kernel).
+#include <cstdlib>
+
+#include "common.h"
+
+#pragma once
+#include <cstdlib>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Tuning overrides exist only in the -DMVAE_TUNING build (libmvae_hip_tuning.so, used by tools/gemm_bench.py);
+// the product library has no mutable global state: MVAE_TUNE(x) folds to 0.
+#ifdef MVAE_TUNING
+struct MvaeTune { int wm, wn, splits, kw, small_off, small_waves; long split_target; };
+extern MvaeTune g_mvae_tune;      // defined in linear.hip
+#define MVAE_TUNE(f) (g_mvae_tune.f)
+#else
+#define MVAE_TUNE(f) 0
+#endif
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LPAD = 4;
+constexpr int NTHREADS = 256;
+
+// ------------------------------------------------------------------------------------------
+// loaders.  init(tile0, t) once; load(k0, kend, t, regs) global -> registers;
+// store(lds, t, regs) registers -> the LDS image [BK][TILE + LPAD].
+// ------------------------------------------------------------------------------------------
+
+// All loads below are UNCONDITIONAL from clamped (always legal) addresses and the out-of-range lanes
+// are zeroed by MULTIPLYING with a 0/1 mask.  A load under a branch -- and hipcc turns
+// `ok ? load : 0` and even `load; if (!ok) x = 0` into one -- makes it drain the memory queue
+// (s_waitcnt vmcnt(0)) after every load, which serialises the two-tile prefetch; the multiply keeps
+// the load in straight-line code (x * 0.f cannot be folded without fast-math).
+__device__ __forceinline__ float mask0(bool ok) { return ok ? 1.f : 0.f; }
+
+// fragment of a k-major LDS image: elements (k0 .. k0+3, row) -- four ds_read_b32, lanes along `row`
+template <int PITCH_>
+__device__ __forceinline__ float4 frag_kmajor(float (*L)[PITCH_], int k0, int row) {
+    return make_float4(L[k0][row], L[k0 + 1][row], L[k0 + 2][row], L[k0 + 3][row]);
+}
+
+// S[r * ld + k]: reduction axis contiguous (x and w of Linear fwd, dy of dgrad, conv weights).
+// VEC: base 16-byte aligned, ld % 4 == 0 and Klen % 4 == 0 (float4 loads never straddle the end).
+// BKV: k-tile depth (32 for the conv forms; the small Linear GEMMs use 64 -- half the barriers).
+template <int TILE_, bool VEC, int BKV_ = BK>
+struct LdRowsKT {
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int NV = TILE * BKV / 4 / NTHREADS;
+    static_assert(NV >= 1, "tile too small for 256 mover threads");
+    struct Regs { float4 v[NV]; float m[VEC ? NV : 4 * NV]; };   // raw data + 0/1 masks (applied when staged)
+    const float *src; int ld; int R; int Klen;
+    size_t cls_stride = 0;                            // per-class (group) source offset
+    int r0;
+    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + NTHREADS * v;
+            const int r = r0 + f / (BKV / 4), k = k0 + (f % (BKV / 4)) * 4;
+            const float *row = src + (size_t)min(r, R - 1) * ld;
+            float4 x;
+            if (VEC) {
+                x = *reinterpret_cast<const float4 *>(row + min(k, Klen - 4));
+                rg.m[v] = mask0(r < R && k < kend);
+            } else {
+                x.x = row[min(k, Klen - 1)];     x.y = row[min(k + 1, Klen - 1)];
+                x.z = row[min(k + 2, Klen - 1)]; x.w = row[min(k + 3, Klen - 1)];
+                const bool rin = r < R;
+                rg.m[4 * v + 0] = mask0(rin && k < kend);     rg.m[4 * v + 1] = mask0(rin && k + 1 < kend);
+                rg.m[4 * v + 2] = mask0(rin && k + 2 < kend); rg.m[4 * v + 3] = mask0(rin && k + 3 < kend);
+            }
+            rg.v[v] = x;
+        }
+    }
+    // LDS image [TILE][BKV + 4]: the tile as it lies in memory (k contiguous), float4 stores, rows
+    // 16-byte aligned.  The row pitch 4 * odd makes the ds_read_b128 fragment reads -- lane (row, 4 k's)
+    // -- conflict-free (MI355X_MICROARCH.md, LDS: b128 lane groups of 16 rows on 64 banks).  The first
+    // version stored this operand transposed ([k][row], four 4-way-conflicting ds_write_b32 per float4):
+    // the LDS array, shared by the whole CU, was as busy as the MFMA pipe.
+    static constexpr bool RMAJOR = true;
+    static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
+    typedef float (*Tile)[PITCH];
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + NTHREADS * v;
+            const int r = f / (BKV / 4), kc = (f % (BKV / 4)) * 4;
+            const float m0 = rg.m[VEC ? v : 4 * v], m1 = rg.m[VEC ? v : 4 * v + 1];
+            const float m2 = rg.m[VEC ? v : 4 * v + 2], m3 = rg.m[VEC ? v : 4 * v + 3];
+            *reinterpret_cast<float4 *>(&L[r][kc]) =
+                make_float4(rg.v[v].x * m0, rg.v[v].y * m1, rg.v[v].z * m2, rg.v[v].w * m3);
+        }
+    }
+    // the 4 consecutive k's starting at k0 of tile row `row`: one ds_read_b128
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
+        return *reinterpret_cast<const float4 *>(&L[row][k0]);
+    }
+};
+template <int T> using LdRowsK = LdRowsKT<T, true>;
+template <int T> using LdRowsKS = LdRowsKT<T, false>;
+template <int T> using LdRowsK64 = LdRowsKT<T, true, 64>;
+template <int T> using LdRowsKS64 = LdRowsKT<T, false, 64>;
+
+// S[k * ld + r]: non-reduced axis contiguous (w of dgrad, dy and x of wgrad, repacked conv weights).
+// VEC: base 16-byte aligned, ld % 4 == 0 and R % 4 == 0.
+template <int TILE_, bool VEC, int BKV_ = BK>
+struct LdRowsMNT {
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int NV = TILE * BKV / 4 / NTHREADS;
+    static constexpr int V4 = TILE / 4;     // float4 per k row
+    static_assert(NV >= 1, "tile too small for 256 mover threads");
+    struct Regs { float4 v[NV]; float m[VEC ? NV : 4 * NV]; };
+    const float *src; int ld; int R; int Klen; size_t cls_stride;   // cls_stride: per-class source offset
+    int r0;
+    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + NTHREADS * v;
+            const int k = k0 + f / V4, r = r0 + (f % V4) * 4;
+            const float *row = src + (size_t)min(k, Klen - 1) * ld;
+            float4 x;
+            if (VEC) {
+                x = *reinterpret_cast<const float4 *>(row + min(r, R - 4));
+                rg.m[v] = mask0(k < kend && r < R);
+            } else {
+                x.x = row[min(r, R - 1)];     x.y = row[min(r + 1, R - 1)];
+                x.z = row[min(r + 2, R - 1)]; x.w = row[min(r + 3, R - 1)];
+                const bool kin = k < kend;
+                rg.m[4 * v + 0] = mask0(kin && r < R);     rg.m[4 * v + 1] = mask0(kin && r + 1 < R);
+                rg.m[4 * v + 2] = mask0(kin && r + 2 < R); rg.m[4 * v + 3] = mask0(kin && r + 3 < R);
+            }
+            rg.v[v] = x;
+        }
+    }
+    // LDS image [BKV][TILE + 4] (k-major: the non-reduced axis contiguous, as in memory)
+    static constexpr bool RMAJOR = false;
+    static constexpr int ROWS = BKV, PITCH = TILE + LPAD;
+    typedef float (*Tile)[PITCH];
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int f = t + NTHREADS * v;
+            const float4 x = rg.v[v];
+            const float m0 = rg.m[VEC ? v : 4 * v], m1 = rg.m[VEC ? v : 4 * v + 1];
+            const float m2 = rg.m[VEC ? v : 4 * v + 2], m3 = rg.m[VEC ? v : 4 * v + 3];
+            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = make_float4(x.x * m0, x.y * m1, x.z * m2, x.w * m3);
+        }
+    }
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
+};
+template <int T> using LdRowsMN = LdRowsMNT<T, true>;
+template <int T> using LdRowsMNS = LdRowsMNT<T, false>;
+template <int T> using LdRowsMN64 = LdRowsMNT<T, true, 64>;
+template <int T> using LdRowsMNS64 = LdRowsMNT<T, false, 64>;
+
+// ------------------------------------------------------------------------------------------
+// epilogues:  col(j) prepares the lane's column, put(i, j, v) consumes one element.
+// ------------------------------------------------------------------------------------------
+
+// Row-major destination D[i * ld + j] with the Linear fusions.
+struct EpRowMajor {
+    float *out; float *act; int ld;           // out = raw / pre-activation result, act = swish(result)
+    const float *bias;                        // per column j (Linear fwd)
+    const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
+    const float *mask; int ldm; float mask_scale;   // dropout keep-mask (fwd on act, bwd on the product)
+    int I, J; int accumulate;
+    size_t out_cs = 0, bias_cs = 0, dpre_cs = 0;    // grouped Linear: per-group offsets of out/act, bias, dpre
+    __device__ void set_class(int cls) {
+        if (out) out += (size_t)cls * out_cs;
+        if (act) act += (size_t)cls * out_cs;
+        if (bias) bias += (size_t)cls * bias_cs;
+        if (dpre) dpre += (size_t)cls * dpre_cs;
+    }
+    __device__ bool col(int j) const { return j < J; }
+    __device__ void put(int i, int j, float v) const {
+        if (i >= I) return;
+        if (bias) v += bias[j];
+        float m = 1.f;
+        if (mask) m = mask[(size_t)i * ldm + j] * mask_scale;
+        if (dpre) v *= m * swish_grad_(dpre[(size_t)i * ldp + j]);
+        const size_t idx = (size_t)i * ld + j;
+        if (accumulate) v += out[idx];
+        if (out) out[idx] = v;
+        if (act) act[idx] = swishf_(v) * m;
+    }
+};
+
+// NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
+// address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
+struct EpNCHW {
+    float *out; float *act; const float *dpre;
+    int C, HW, Wfull, H2, W2, sy, py, px, J;
+    int off;   // per-lane column offset, set by col()
+    __device__ void set_class(int cls) { if (sy > 1) { py = cls / sy; px = cls % sy; } }
+    __device__ bool col(int j) {
+        if (j >= J) return false;
+        const int hw2 = H2 * W2;
+        const int n = j / hw2, rem = j - n * hw2;
+        const int r = rem / W2, c = rem - r * W2;
+        off = n * C * HW + (r * sy + py) * Wfull + c * sy + px;
+        return true;
+    }
+    __device__ void put(int i, int, float v) const {
+        if (i >= C) return;
+        const int idx = off + i * HW;
+        if (dpre) v *= swish_grad_(dpre[idx]);
+        if (out) out[idx] = v;
+        if (act) act[idx] = swishf_(v);
+    }
+};
+
+// Where the raw partial tiles of a split reduction go (row-major [I][J] per split), plus the
+// optional row sums of P (bias gradient of a Linear wgrad).
+struct SplitSink {
+    float *ws; size_t stride; int I, J;       // partial (split, i, j) at ws[split*stride + i*J + j]
+    float *rowsum; size_t rowsum_stride; int rowsum_accumulate;   // (split, i) at rowsum[split*rowsum_stride + i]
+    int ncls;                                 // parity classes (transposed conv) / groups (grouped Linear) folded into gridDim.x
+    size_t rowsum_cls_stride;                 // grouped Linear wgrad: per-group offset of the bias gradient
+    float *rowsum_final; int rowsum_final_accumulate;   // split launches: where the finish kernel puts the summed row sums
+    size_t cls_region;                        // grouped + split: class c keeps its partials at ws + c * cls_region
+    size_t rowsum_final_cls_stride;           //                  and its bias gradient at rowsum_final + c * this
+};
+
+// finish kernels of a grouped launch: one grid slice per class
+__device__ __forceinline__ void sink_select_class(SplitSink &sink, int cls) {
+    sink.ws += (size_t)cls * sink.cls_region;
+    if (sink.rowsum) sink.rowsum += (size_t)cls * sink.cls_region;
+    if (sink.rowsum_final) sink.rowsum_final += (size_t)cls * sink.rowsum_final_cls_stride;
+}
+
+// the bias gradient of a split Linear wgrad: sum the per-split row sums in split order
+__device__ __forceinline__ void finish_rowsum(const SplitSink &sink, int splits, int i) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sink.rowsum[(size_t)z * sink.rowsum_stride + i];
+    float *dst = sink.rowsum_final + i;
+    if (sink.rowsum_final_accumulate) s += *dst;
+    *dst = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+// Wave layout: a k-group is WGM x WGN waves, each owning WM x WN MFMA tiles of 32x32 -- block tile
+// BM = 32*WM*WGM by BN = 32*WN*WGN -- and a block is KW k-groups: group kg takes every KW-th k-pair of
+// each LDS tile, the partial accumulators are summed through LDS at the end (fixed order).  The block has
+// 64*WGM*WGN*KW >= 256 threads; the first 256 fetch and stage the tiles, the rest only issue MFMAs.
+//   2x2 waves, KW = 1         the conv forms and every large GEMM: 64x64 .. 128x128 tiles
+//   2x2 waves, KW = 2 / 4     64x64 tile shared by 8 / 16 waves (long reductions with few tiles)
+//   1x4 waves                 32x128 tile for outputs with <= 32 rows (32-channel convs, 32x48 wgrads)
+//   2x1 / 1x2 / 1x1 waves with KW = 2 .. 8 (BK = 64)
+//                             the 512-wide MLP layers at batch 512-1024: a 1024x512 output is only 128
+//                             tiles of 64x64, half the CUs; 64x32 / 32x64 / 32x32 tiles give every CU a
+//                             block, the k-groups give every SIMD one or two waves with a K/KW-long MFMA
+//                             chain -- no split-K launch, no partials through HBM, no finish kernel.
+template <class P, class Q, class E, int WM, int WN, bool ROWSUM, int KW, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN * KW, (64 * WGM * WGN * KW == 256 ? 2 : 1))
+void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
+    constexpr int BKK = P::BKV;
+    constexpr int WPG = WGM * WGN;                  // waves per k-group
+    constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+    constexpr int NT = 64 * WPG * KW;
+    static_assert(P::TILE == BM && Q::TILE == BN, "loader tile mismatch");
+    static_assert(P::BKV == Q::BKV, "loaders disagree on the k-tile depth");
+    static_assert(NT >= NTHREADS && NT <= 1024, "a block needs 256 mover threads");
+    static_assert(BKK / 8 % KW == 0, "the 8-k chunks of a tile must divide over the k-groups");
+    static_assert(!ROWSUM || !P::RMAJOR, "row sums read a k-major P tile");
+    // dynamic LDS (the 128x128 tile needs 66 KiB, above the 64 KiB static limit); the only LDS
+    // object of the kernel, so its base is 16-byte aligned (cdna_hip_programming.md G17)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    typedef typename P::Tile PTile;
+    typedef typename Q::Tile QTile;
+    constexpr int P_FLOATS = P::ROWS * P::PITCH, Q_FLOATS = Q::ROWS * Q::PITCH;
+    PTile Ps[2] = {reinterpret_cast<PTile>(lds_raw), reinterpret_cast<PTile>(lds_raw + P_FLOATS)};
+    float *qbase = lds_raw + 2 * P_FLOATS;
+    QTile Qs[2] = {reinterpret_cast<QTile>(qbase), reinterpret_cast<QTile>(qbase + Q_FLOATS)};
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kg = wave / WPG, wq = wave % WPG;     // k-group of this wave, its slot inside the group
+    const int wi = wq / WGN, wj = wq % WGN;
+    const bool mover = (NT == NTHREADS) || t < NTHREADS;
+    const int tiles_j = gridDim.x / sink.ncls;
+    const int cls = blockIdx.x / tiles_j;
+    const int i0 = blockIdx.y * BM, j0 = (blockIdx.x - cls * tiles_j) * BN, split = blockIdx.z;
+    const int kbeg = split * klen;
+    const int kend = min(K, kbeg + klen);
+    const int nsteps = (kend - kbeg + BKK - 1) / BKK;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    p.init(i0, t, cls);
+    q.init(j0, t, cls);
+    e.set_class(cls);
+    typename P::Regs pr0, pr1;
+    typename Q::Regs qr0, qr1;
+    // db = sum over the reduction axis of P (dy^T): the bias gradient for free.  The 256 movers split the
+    // tile: thread t owns row t % BM and every RS_PARTS-th k of it; parts are summed through LDS at the end.
+    constexpr int RS_PARTS = NTHREADS / BM;
+    const bool rs_block = ROWSUM && blockIdx.x == cls * tiles_j;      // block-uniform
+    const int rs_row = t % BM, rs_part = t / BM;
+    float rsum = 0.f;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    auto compute = [&](int buf) {
+        if (ROWSUM) {
+            if (rs_block && mover) {
+#pragma unroll
+                for (int kk = 0; kk < BKK / RS_PARTS; ++kk) rsum += Ps[buf][kk * RS_PARTS + rs_part][rs_row];
+            }
+        }
+        // A k-tile is cut into chunks of 8 k's; k-group kg takes chunks kg, kg + KW, ...  Within a chunk
+        // lanes 0-31 hold k = 8c + j and lanes 32-63 k = 8c + 4 + j for the j-th of its 4 MFMAs (each
+        // 32x32x2 MFMA sums two k's; which two is free as long as both operands agree), so a row-major
+        // operand tile feeds 4 MFMAs with ONE ds_read_b128 per lane.  The reads of chunk ch+1 are issued
+        // before the MFMAs of chunk ch: the LDS latency hides behind 64-cycle matrix instructions.
+        constexpr int NCH = BKK / 8 / KW;
+        float4 a0[WM], b0[WN];
+#pragma unroll
+        for (int x = 0; x < WM; ++x) a0[x] = P::frag(Ps[buf], kg * 8 + 4 * lrow, (wi * WM + x) * 32 + lcol);
+#pragma unroll
+        for (int y = 0; y < WN; ++y) b0[y] = Q::frag(Qs[buf], kg * 8 + 4 * lrow, (wj * WN + y) * 32 + lcol);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            float4 a1[WM], b1[WN];
+            if (ch + 1 < NCH) {
+                const int k0 = ((ch + 1) * KW + kg) * 8 + 4 * lrow;
+#pragma unroll
+                for (int x = 0; x < WM; ++x) a1[x] = P::frag(Ps[buf], k0, (wi * WM + x) * 32 + lcol);
+#pragma unroll
+                for (int y = 0; y < WN; ++y) b1[y] = Q::frag(Qs[buf], k0, (wj * WN + y) * 32 + lcol);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+#pragma unroll
+                    for (int y = 0; y < WN; ++y) {
+                        const float av = j == 0 ? a0[x].x : j == 1 ? a0[x].y : j == 2 ? a0[x].z : a0[x].w;
+                        const float bv = j == 0 ? b0[y].x : j == 1 ? b0[y].y : j == 2 ? b0[y].z : b0[y].w;
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 1 < NCH) {
+#pragma unroll
+                for (int x = 0; x < WM; ++x) a0[x] = a1[x];
+#pragma unroll
+                for (int y = 0; y < WN; ++y) b0[y] = b1[y];
+            }
+        }
+    };
+
+    // prologue: tiles 0 and 1 in flight, tile 0 staged
+    if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
+    if (mover && nsteps > 1) { p.load(kbeg + BKK, kend, t, pr1); q.load(kbeg + BKK, kend, t, qr1); }
+    if (mover && nsteps > 0) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+    __syncthreads();
+    // two k-steps per trip (the register sets alternate); a lone last step is peeled off below so the
+    // loop has ONE exit -- with a break in the middle hipcc ping-ponged the accumulator between two
+    // register sets (16 v_mov + 17 wait states per k-step)
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
+        if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BKK, kend, t, pr0); q.load(kbeg + (s + 2) * BKK, kend, t, qr0); }
+        compute(0);
+        if (mover) { p.store(Ps[1], t, pr1); q.store(Qs[1], t, qr1); }
+        __syncthreads();
+        // odd step
+        if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BKK, kend, t, pr1); q.load(kbeg + (s + 3) * BKK, kend, t, qr1); }
+        compute(1);
+        if (mover && s + 2 < nsteps) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+        __syncthreads();
+    }
+    if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
+        compute(0);
+        __syncthreads();
+    }
+    if (ROWSUM) {
+        if (rs_block) {     // sum the RS_PARTS partial row sums in a fixed order (the tile buffers are free)
+            if (mover) lds_raw[rs_part * BM + rs_row] = rsum;
+            __syncthreads();
+            if (t < BM) {
+                rsum = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < RS_PARTS; ++pp) rsum += lds_raw[pp * BM + t];
+            }
+            __syncthreads();
+        }
+    }
+    constexpr bool COOP = KW > 1 && WPG < 4;        // the small layouts: tile-wide cooperative epilogue
+    if (COOP) {
+        // every wave parks its accumulators in LDS as tile[kg][i][j] (j along lanes: conflict-free), then all
+        // threads sum the KW partials of their outputs in k-group order and run the epilogue -- 32 or 64
+        // consecutive j per row, so stores stay full segments.  (With only the k-group-0 waves finishing the
+        // tile, one or two of eight waves carried all the bias / Swish / store work.)
+        constexpr int TP = BN + 1;                  // odd pitch: rows land on different banks
+        float *tile = lds_raw + kg * (BM * TP);
+#pragma unroll
+        for (int x = 0; x < WM; ++x)
+#pragma unroll
+            for (int y = 0; y < WN; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = (wi * WM + x) * 32 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+                    tile[il * TP + (wj * WN + y) * 32 + lcol] = acc[x][y][r];
+                }
+        __syncthreads();
+        const bool partial_c = gridDim.z > 1;
+        for (int el = t; el < BM * BN; el += NT) {
+            const int il = el / BN, jl = el % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < KW; ++g2) v += lds_raw[g2 * (BM * TP) + il * TP + jl];
+            const int i = i0 + il, j = j0 + jl;
+            if (partial_c) {
+                if (i < sink.I && j < sink.J)
+                    sink.ws[(size_t)cls * sink.cls_region + (size_t)split * sink.stride + (size_t)i * sink.J + j] = v;
+            } else if (e.col(j)) {
+                e.put(i, j, v);
+            }
+        }
+        if (ROWSUM) {
+            if (rs_block && t < BM && i0 + t < sink.I) {
+                float *dst = sink.rowsum + (size_t)cls * sink.rowsum_cls_stride + (size_t)split * sink.rowsum_stride + i0 + t;
+                if (!partial_c && sink.rowsum_accumulate) rsum += *dst;
+                *dst = rsum;
+            }
+        }
+        return;
+    }
+    if (KW > 1) {
+        // sum the k-groups' accumulators through LDS (the tile buffers are free after the last barrier)
+        constexpr int PER_WAVE = WM * WN * 16 * 64;
+        float *red = lds_raw;
+        if (kg > 0) {
+            float *dst = red + ((kg - 1) * WPG + wq) * PER_WAVE + lane;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((x * WN + y) * 16 + r) * 64] = acc[x][y][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g2 = 0; g2 < KW - 1; ++g2) {
+            const float *src = red + (g2 * WPG + wq) * PER_WAVE + lane;
+#pragma unroll
+            for (int x = 0; x < WM; ++x)
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][y][r] += src[((x * WN + y) * 16 + r) * 64];
+        }
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool partial = gridDim.z > 1;
+#pragma unroll
+    for (int y = 0; y < WN; ++y) {
+        const int j = j0 + (wj * WN + y) * 32 + lcol;
+        if (partial) {
+            if (j >= sink.J) continue;
+        } else if (!e.col(j)) {
+            continue;
+        }
+#pragma unroll
+        for (int x = 0; x < WM; ++x) {
+            const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ib + (r & 3) + 8 * (r >> 2);
+                if (partial) {
+                    if (i < sink.I)
+                        sink.ws[(size_t)cls * sink.cls_region + (size_t)split * sink.stride + (size_t)i * sink.J + j] = acc[x][y][r];
+                } else {
+                    e.put(i, j, acc[x][y][r]);
+                }
+            }
+        }
+    }
+    if (ROWSUM) {
+        if (rs_block && t < BM && i0 + t < sink.I) {     // t < BM <= 128: waves of k-group 0
+            float *dst = sink.rowsum + (size_t)cls * sink.rowsum_cls_stride + (size_t)split * sink.rowsum_stride + i0 + t;
+            if (!partial && sink.rowsum_accumulate) rsum += *dst;
+            *dst = rsum;
+        }
+    }
+}
+
+// Sum the split partials and run the epilogue on the result.  Block = 32 consecutive outputs x 8
+// split groups: group q adds splits q, q+8, ... (independent loads in flight instead of one serial
+// chain of `splits` dependent round trips), the 8 group sums are combined in a fixed order.
+template <class E>
+__global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits, E e) {
+    __shared__ float part[8][32];
+    sink_select_class(sink, blockIdx.z); e.set_class(blockIdx.z);
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + o, i = blockIdx.y;
+    float s = 0.f;
+    if (j < sink.J) {
+        const float *src = sink.ws + (size_t)i * sink.J + j;
+        for (int z = grp; z < splits; z += 8) s += src[(size_t)z * sink.stride];
+    }
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && j < sink.J && e.col(j)) {
+        s = ((part[0][o] + part[1][o]) + (part[2][o] + part[3][o])) +
+            ((part[4][o] + part[5][o]) + (part[6][o] + part[7][o]));
+        e.put(i, j, s);
+    }
+    if (sink.rowsum_final && blockIdx.x == 0) {      // block-uniform: the bias gradient of row i, 8 split groups
+        __syncthreads();
+        if (o == 0) {
+            float r = 0.f;
+            for (int z = grp; z < splits; z += 8) r += sink.rowsum[(size_t)z * sink.rowsum_stride + i];
+            part[grp][0] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float r = ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0])) +
+                      ((part[4][0] + part[5][0]) + (part[6][0] + part[7][0]));
+            float *dst = sink.rowsum_final + i;
+            if (sink.rowsum_final_accumulate) r += *dst;
+            *dst = r;
+        }
+    }
+}
+
+// few splits: one thread per output, the chain is short
+template <class E>
+__global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int splits, E e) {
+    sink_select_class(sink, blockIdx.z); e.set_class(blockIdx.z);
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (sink.rowsum_final && j == 0) finish_rowsum(sink, splits, i);
+    if (j >= sink.J || !e.col(j)) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
+    e.put(i, j, s);
+}
+
+// few splits, J % 4 == 0: one thread per 4 consecutive outputs, float4 partial loads
+template <class E>
+__global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int splits, E e) {
+    sink_select_class(sink, blockIdx.y); e.set_class(blockIdx.y);
+    const int jq = sink.J >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t nvec = (size_t)sink.I * jq;
+    if (idx >= nvec) {          // the launch carries I extra threads for the bias gradient
+        if (sink.rowsum_final && idx < nvec + sink.I) finish_rowsum(sink, splits, (int)(idx - nvec));
+        return;
+    }
+    const int i = (int)(idx / jq), j = (int)(idx - (size_t)i * jq) * 4;
+    const float *src = sink.ws + (size_t)i * sink.J + j;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)z * sink.stride);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (e.col(j)) e.put(i, j, s.x);
+    if (e.col(j + 1)) e.put(i, j + 1, s.y);
+    if (e.col(j + 2)) e.put(i, j + 2, s.z);
+    if (e.col(j + 3)) e.put(i, j + 3, s.w);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; };
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// Tile and split choice, from the measurements in profiles/ (tools/gemm_bench.py):
+// the gather-fed forward / dgrad forms and the large Linear layers run best on 64x64 tiles (5 waves per
+// SIMD hide the gather latency; 128-wide tiles drop to 2-3 waves), the conv weight-gradient form
+// (two gathers feeding a small output over a huge reduction) wants the arithmetic intensity of
+// 128-wide tiles.  Reductions are split until ~4 blocks per CU exist (>= 2 k-steps per split).
+// `small_ok` (the float4-loadable Linear forms): outputs of fewer than 256 tiles of 64x64 whose reduction
+// is short or whose 32x32 tiles still cover the chip use the small layouts -- one launch, no split.
+enum PlanKind { PLAN_FWD = 0, PLAN_CONV_WGRAD = 1, PLAN_LIN_WGRAD = 2 };
+
+inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLAN_FWD, int ncls = 1,
+                      bool small_ok = false) {
+    Plan p;
+    p.wm = 1; p.wn = 1; p.wgm = 2; p.wgn = 2; p.kw = 1; p.bk = BK;
+    const bool forced = MVAE_TUNE(wm) || MVAE_TUNE(wn) || MVAE_TUNE(kw);
+    if (small_ok && !forced && !MVAE_TUNE(small_off)) {
+        const long t64 = cdiv(I, 64) * cdiv(J, 64) * ncls, t32 = cdiv(I, 32) * cdiv(J, 32) * ncls;
+        if (t64 < 256 && (t32 >= 192 || K <= 1024)) {
+            // largest tile that still gives (nearly) every CU a block; between the two 2-tile shapes the one
+            // that pads less (ties: 32x64 -- the j axis is the contiguous store axis)
+            const long b_tall = cdiv(I, 64) * cdiv(J, 32) * ncls, b_wide = cdiv(I, 32) * cdiv(J, 64) * ncls;
+            long blocks;
+            if ((b_tall > b_wide ? b_tall : b_wide) >= 224) {
+                const bool tall = b_tall < b_wide;            // fewer blocks of equal size = less padding
+                p.wgm = tall ? 2 : 1; p.wgn = tall ? 1 : 2;
+                blocks = tall ? b_tall : b_wide;
+            } else {
+                p.wgm = 1; p.wgn = 1;
+                blocks = t32;
+            }
+            // one block per CU: 8 waves (two per SIMD); more blocks than CUs: 4 waves each
+            int waves = blocks <= 320 ? 8 : 4;
+            if (MVAE_TUNE(small_waves)) waves = MVAE_TUNE(small_waves);
+            p.kw = waves / (p.wgm * p.wgn);
+            p.bk = 64;
+            p.splits = 1;
+            p.klen = (int)(cdiv(K, p.bk) * p.bk);
+            return p;
+        }
+    }
+    const bool narrow = (I <= 32 && J >= 128 && !forced);
+    if (narrow) { p.wgm = 1; p.wgn = 4; }
+    if (kind == PLAN_CONV_WGRAD && !narrow) {
+        if (J >= 128) p.wn = 2;
+        if (I >= 128 && J >= 128) p.wm = 2;
+    }
+    if (MVAE_TUNE(wm)) p.wm = MVAE_TUNE(wm);
+    if (MVAE_TUNE(wn)) p.wn = MVAE_TUNE(wn);
+    const long tiles = narrow ? cdiv(J, 128) * ncls : cdiv(I, 64 * p.wm) * cdiv(J, 64 * p.wn) * ncls;
+    // fewer than one wave per SIMD (256 CUs x 4): let KW wave groups share each 64x64 tile
+    if (!narrow && p.wm == 1 && p.wn == 1 && K >= 4 * BK) {
+        if (tiles * 4 <= 256) p.kw = 4;
+        else if (tiles * 2 <= 256) p.kw = 2;
+    }
+    if (MVAE_TUNE(kw)) p.kw = (p.wm == 1 && p.wn == 1) ? MVAE_TUNE(kw) : 1;
+    long want = 1;
+    if (allow_split) {
+        // blocks to aim for (profiles/r01_split_sweep.txt): the Linear forward / dgrad forms want every
+        // CU busy and then as FEW splits as possible (each block keeps >= 8 k-steps, the finish reads
+        // less); the 128-wide conv weight-gradient tiles run two blocks per CU; everything else (Linear
+        // weight gradients, small conv outputs) is fastest with ~4 blocks per CU
+        const long target_tune = MVAE_TUNE(split_target);
+        long target_blocks = 1024 / p.kw;
+        if (kind == PLAN_FWD) target_blocks = (p.kw == 1) ? 512 : 256;
+        if (kind == PLAN_CONV_WGRAD && p.wm * p.wn >= 2) target_blocks = 512;
+        if (target_tune > 0) target_blocks = target_tune / p.kw;
+        want = (target_blocks + tiles / 2) / tiles;         // nearest: 800 tiles against 1024 is one round, not two
+        const long maxs = (K + 2 * BK - 1) / (2 * BK);
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        if (kind == PLAN_LIN_WGRAD && !MVAE_TUNE(kw) && !target_tune) {
+            // Linear weight gradients: plain 4-wave blocks, ~2 per CU, >= 8 k-steps each beat k-wave
+            // groups and deeper splits (512x512 over M = 1024: 36 vs 33 TFLOP/s; 784x512: 40 vs 32) --
+            // unless the reduction is too short to make enough blocks that way
+            const long maxs8 = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
+            long w1 = (512 + tiles / 2) / tiles;
+            if (w1 > maxs8) w1 = maxs8;
+            if (w1 < 1) w1 = 1;
+            if (tiles * w1 >= 128) { p.kw = 1; want = w1; }
+        }
+        if (want > (tiles <= 4 ? 512 : 64)) want = (tiles <= 4 ? 512 : 64);   // tiny outputs may split deeper
+        if (MVAE_TUNE(splits) > 0) want = MVAE_TUNE(splits);
+        if (MVAE_TUNE(splits) < 0 && kind == PLAN_FWD) want = 1;      // tuning: forward / dgrad forms never split
+    }
+    p.klen = (int)(((K + want - 1) / want + BK - 1) / BK * BK);
+    p.splits = (K + p.klen - 1) / p.klen;
+    return p;
+}
+
+// PL / QL: loader templates of the BK = 32 layouts; PS / QS: their BK = 64 versions for the small
+// layouts (SMALL = false: the caller has none -- the conv forms -- and the plan never asks for one).
+template <template <int> class PL, template <int> class QL, class E, bool ROWSUM, bool SMALL,
+          template <int> class PS, template <int> class QS, class PF, class QF>
+int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitSink sink, hipStream_t st) {
+#define MVAE_LAUNCH(PLD, QLD, WM, WN, KW, WGM, WGN)                                              \
+    {                                                                                            \
+        constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN, NT = 64 * WGM * WGN * KW;          \
+        PLD<TM> p; make_p(p);                                                                    \
+        QLD<TN> q; make_q(q);                                                                    \
+        dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
+        constexpr size_t tile_b = 2 * (PLD<TM>::ROWS * PLD<TM>::PITCH + QLD<TN>::ROWS * QLD<TN>::PITCH) * sizeof(float); \
+        constexpr size_t red_b = (WGM * WGN < 4 && KW > 1)                                       \
+            ? (size_t)KW * TM * (TN + 1) * sizeof(float)              /* cooperative epilogue */ \
+            : (size_t)(KW - 1) * WGM * WGN * WM * WN * 16 * 64 * sizeof(float);                  \
+        constexpr size_t lds = tile_b > red_b ? tile_b : red_b;                                  \
+        auto kern = igemm_kernel<PLD<TM>, QLD<TN>, E, WM, WN, ROWSUM, KW, WGM, WGN>;             \
+        static bool attr_done = false;   /* idempotent: a race only repeats the same call */    \
+        if (!attr_done) {                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            attr_done = true;                                                                    \
+        }                                                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p, q, e, K, pl.klen, sink);            \
+    }
+    bool launched = false;
+    if constexpr (SMALL) {
+        if (pl.bk == 64) {
+            launched = true;
+            if (pl.wgm == 2 && pl.kw == 4) MVAE_LAUNCH(PS, QS, 1, 1, 4, 2, 1)
+            else if (pl.wgm == 2) MVAE_LAUNCH(PS, QS, 1, 1, 2, 2, 1)
+            else if (pl.wgn == 2 && pl.kw == 4) MVAE_LAUNCH(PS, QS, 1, 1, 4, 1, 2)
+            else if (pl.wgn == 2) MVAE_LAUNCH(PS, QS, 1, 1, 2, 1, 2)
+            else if (pl.kw == 8) MVAE_LAUNCH(PS, QS, 1, 1, 8, 1, 1)
+            else MVAE_LAUNCH(PS, QS, 1, 1, 4, 1, 1)
+        }
+    }
+    if (!launched) {
+        if (pl.bk != BK) return MVAE_ERR_ARG;
+        if (pl.wgn == 4) MVAE_LAUNCH(PL, QL, 1, 1, 1, 1, 4)
+        else if (pl.wm == 2 && pl.wn == 2) MVAE_LAUNCH(PL, QL, 2, 2, 1, 2, 2)
+        else if (pl.wm == 2 && pl.wn == 1) MVAE_LAUNCH(PL, QL, 2, 1, 1, 2, 2)
+        else if (pl.wm == 1 && pl.wn == 2) MVAE_LAUNCH(PL, QL, 1, 2, 1, 2, 2)
+        else if (pl.kw == 4) MVAE_LAUNCH(PL, QL, 1, 1, 4, 2, 2)
+        else if (pl.kw == 2) MVAE_LAUNCH(PL, QL, 1, 1, 2, 2, 2)
+        else MVAE_LAUNCH(PL, QL, 1, 1, 1, 2, 2)
+    }
+#undef MVAE_LAUNCH
+    if (pl.splits > 1) {
+        if (pl.splits > 16) {
+            dim3 grid((J + 31) / 32, I, sink.ncls);
+            hipLaunchKernelGGL((finish_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        } else if (J % 4 == 0 && sink.stride % 4 == 0 && aligned16(sink.ws)) {
+            const size_t nvec = (size_t)I * (J / 4) + (sink.rowsum_final ? I : 0);
+            hipLaunchKernelGGL((finish_few_vec_kernel<E>), dim3((unsigned)((nvec + 255) / 256), sink.ncls), dim3(256), 0, st, sink,
+                               pl.splits, e);
+        } else {
+            dim3 grid((J + 255) / 256, I, sink.ncls);
+            hipLaunchKernelGGL((finish_few_kernel<E>), grid, dim3(256), 0, st, sink, pl.splits, e);
+        }
+    }
+    return mvae_launch_status();
+}
+
+template <template <int> class PL, template <int> class QL, class E, bool ROWSUM, class PF, class QF>
+int launch_igemm(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitSink sink, hipStream_t st) {
+    return launch_igemm_impl<PL, QL, E, ROWSUM, false, PL, QL>(pl, make_p, make_q, e, I, J, K, sink, st);
+}
+
+template <template <int> class PL, template <int> class QL, template <int> class PS, template <int> class QS,
+          class E, bool ROWSUM, class PF, class QF>
+int launch_igemm_small(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, SplitSink sink, hipStream_t st) {
+    return launch_igemm_impl<PL, QL, E, ROWSUM, true, PS, QS>(pl, make_p, make_q, e, I, J, K, sink, st);
+}
+
+inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
+    SplitSink s;
+    s.ws = (float *)ws; s.I = I; s.J = J;
+    s.stride = (size_t)I * J + (rowsum ? I : 0);
+    s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
+    s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0; s.cls_region = 0; s.rowsum_final_cls_stride = 0;
+    return s;
+}
+
+inline size_t split_ws_floats(int I, int J, int K) {
+    size_t best = 0;      // the caller does not say which op it sizes for: take the largest plan
+    for (int kind = 0; kind < 3; ++kind) {
+        Plan pl = make_plan(I, J, K, true, (PlanKind)kind);
+        if (pl.splits > 1 && (size_t)pl.splits > best) best = pl.splits;
+    }
+    return best * ((size_t)I * J + I);
+}
+
+}  // namespace

@@ -1,0 +1,172 @@
+// linear.hip -- Linear layers (forward, data gradient, weight gradient; single and grouped) on the GEMM
+// kernel of gemm_core.h, and the library-wide entry points.
+#include "gemm_core.h"
+
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+MVAE_EXPORT int mvae_abi_version(void) { return 2; }
+
+#ifdef MVAE_TUNING
+// tuning build only (libmvae_hip_tuning.so): force tile shapes / split counts for tools/gemm_bench.py
+MvaeTune g_mvae_tune = {0, 0, 0, 0, 0, 0, 0};
+MVAE_EXPORT void mvae_debug_set_tiling(int wm, int wn, int splits) {
+    g_mvae_tune.wm = wm; g_mvae_tune.wn = wn; g_mvae_tune.splits = splits;
+}
+MVAE_EXPORT void mvae_debug_set_kwaves(int kw) { g_mvae_tune.kw = kw; }
+MVAE_EXPORT void mvae_debug_set_small(int off, int waves) { g_mvae_tune.small_off = off; g_mvae_tune.small_waves = waves; }
+MVAE_EXPORT void mvae_debug_set_split_target(long blocks) { g_mvae_tune.split_target = blocks; }
+#endif
+
+MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len) {
+    if (rows_out <= 0 || cols_out <= 0 || reduce_len <= 0) return 0;
+    size_t n = split_ws_floats(rows_out, cols_out, reduce_len);
+    const size_t repack = (size_t)rows_out * cols_out;      // dgrad-form weight repack: Cin x (Cout*16)
+    if (MVAE_TUNE(splits) > 0) n = (size_t)MVAE_TUNE(splits) * ((size_t)rows_out * cols_out + rows_out);
+    const size_t smallcin = (size_t)512 * rows_out * cols_out;      // per-block partials of wgrad_smallcin_kernel
+    if (rows_out <= 64 && cols_out <= 64 && smallcin > n) n = smallcin;
+    return (n > repack ? n : repack) * sizeof(float);
+}
+
+// Linear layers.  G > 1: G independent problems of one shape in ONE launch (celeba19's 18 attribute
+// experts, celeba19/model.py:173-196) -- operand g lives at base + g * group stride; the group index
+// rides on the class slot of the grid, so a layer of all 18 experts is 18x the blocks instead of 18
+// under-filled launches.  With scratch a grouped launch may split the reduction like a single one:
+// class c keeps its partials in its own region of the scratch, the finish launch has one grid slice per class.
+struct LinGroups { int G; size_t a, b, c, d; };     // meaning of a..d per entry point below
+
+static int linear_fwd_impl(const float *x, int ldx, const float *w, const float *bias, float *pre, float *act,
+                           int ldy, const float *mask, float mask_scale, int M, int N, int K, void *ws,
+                           size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // gr: a = x stride, b = w stride, c = bias stride, d = pre/act stride
+    const bool vec = aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 && gr.b % 4 == 0;
+    Plan pl = make_plan(M, N, K, ws != nullptr, PLAN_FWD, gr.G, vec);
+    SplitSink sink = make_sink(ws, M, N, false);
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
+    EpRowMajor e;
+    e.out = pre; e.act = act; e.ld = ldy; e.bias = bias; e.dpre = nullptr; e.ldp = 0;
+    e.mask = mask; e.ldm = N; e.mask_scale = mask_scale; e.I = M; e.J = N; e.accumulate = 0;
+    e.out_cs = gr.d; e.bias_cs = gr.c;
+    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; q.cls_stride = gr.b; };
+    if (vec)
+        return launch_igemm_small<LdRowsK, LdRowsK, LdRowsK64, LdRowsK64, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
+    return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
+}
+
+static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *dx, int lddx, const float *pre_in,
+                             const float *mask, float mask_scale, int M, int N, int K, int flags, void *ws,
+                             size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // D[i = m][j = k] = sum_n dy[m][n] * w[n][k];  gr: a = dy stride, b = w stride, c = pre_in stride, d = dx stride
+    const bool vec = aligned16(dy) && aligned16(w) && lddy % 4 == 0 && N % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 &&
+                     gr.b % 4 == 0;
+    Plan pl = make_plan(M, K, N, ws != nullptr, PLAN_FWD, gr.G, vec);
+    SplitSink sink = make_sink(ws, M, K, false);
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
+    EpRowMajor e;
+    e.out = dx; e.act = nullptr; e.ld = lddx; e.bias = nullptr; e.dpre = pre_in; e.ldp = K;
+    e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
+    e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+    e.out_cs = gr.d; e.dpre_cs = gr.c;
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.Klen = N; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.Klen = N; q.cls_stride = gr.b; };
+    if (vec)
+        return launch_igemm_small<LdRowsK, LdRowsMN, LdRowsK64, LdRowsMN64, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
+    return launch_igemm<LdRowsKS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
+}
+
+static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db, int M, int N,
+                             int K, int flags, void *ws, size_t ws_bytes, LinGroups gr, hipStream_t st) {
+    // D[i = n][j = k] = sum_m dy[m][n] * x[m][k];  gr: a = dy stride, b = x stride, c = db stride, d = dw stride
+    const bool vec = aligned16(dy) && aligned16(x) && lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
+                     gr.a % 4 == 0 && gr.b % 4 == 0;
+    Plan pl = make_plan(N, K, M, ws != nullptr, PLAN_LIN_WGRAD, gr.G, vec);
+    SplitSink sink = make_sink(ws, N, K, db != nullptr);
+    sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
+    if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
+    const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+    EpRowMajor e;
+    e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
+    e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = N; e.J = K; e.accumulate = acc;
+    e.out_cs = gr.d;
+    auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = gr.a; };
+    auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = gr.b; };
+    int rc;
+    if (db) {
+        // row sums of P = dy^T are the bias gradient; partials live right after each dw partial
+        if (pl.splits == 1) {
+            sink.rowsum = db; sink.rowsum_stride = 0; sink.rowsum_accumulate = acc; sink.rowsum_cls_stride = gr.c;
+        } else {
+            sink.rowsum = (float *)ws + (size_t)N * K; sink.rowsum_stride = sink.stride; sink.rowsum_accumulate = 0;
+            sink.rowsum_cls_stride = sink.cls_region;
+            sink.rowsum_final = db; sink.rowsum_final_accumulate = acc;     // summed by the finish launch
+            sink.rowsum_final_cls_stride = gr.c;
+        }
+        rc = vec ? launch_igemm_small<LdRowsMN, LdRowsMN, LdRowsMN64, LdRowsMN64, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st)
+                 : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, true>(pl, mp, mq, e, N, K, M, sink, st);
+        if (rc) return rc;
+        return MVAE_OK;
+    }
+    return vec ? launch_igemm_small<LdRowsMN, LdRowsMN, LdRowsMN64, LdRowsMN64, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st)
+               : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
+}
+
+static const LinGroups kOneGroup = {1, 0, 0, 0, 0};
+
+MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,
+                                float *pre, float *act, int ldy, const float *mask, float mask_scale,
+                                int M, int N, int K, void *ws, size_t ws_bytes, mvae_stream_t stream) {
+    if (!x || !w || (!pre && !act) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return MVAE_ERR_ARG;
+    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, mask, mask_scale, M, N, K, ws, ws_bytes, kOneGroup,
+                           (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,
+                                  const float *pre_in, const float *mask, float mask_scale,
+                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                  mvae_stream_t stream) {
+    if (!dy || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
+    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, mask, mask_scale, M, N, K, flags, ws, ws_bytes,
+                             kOneGroup, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, float *dw, float *db,
+                                  int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                  mvae_stream_t stream) {
+    if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
+    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, ws, ws_bytes, kOneGroup, (hipStream_t)stream);
+}
+
+static inline bool groups_ok(int G) { return G >= 1 && G <= 4096; }
+
+MVAE_EXPORT int mvae_linear_fwd_grouped(const float *x, int ldx, size_t x_gs, const float *w, size_t w_gs,
+                                        const float *bias, size_t bias_gs, float *pre, float *act, int ldy,
+                                        size_t y_gs, int G, int M, int N, int K, void *ws, size_t ws_bytes,
+                                        mvae_stream_t stream) {
+    if (!x || !w || (!pre && !act) || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N)
+        return MVAE_ERR_ARG;
+    const LinGroups gr = {G, x_gs, w_gs, bias_gs, y_gs};
+    return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, nullptr, 1.f, M, N, K, ws, ws_bytes, gr, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_dgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *w, size_t w_gs,
+                                          float *dx, int lddx, size_t dx_gs, const float *pre_in, size_t pre_gs,
+                                          int G, int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                          mvae_stream_t stream) {
+    if (!dy || !w || !dx || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || lddx < K) return MVAE_ERR_ARG;
+    const LinGroups gr = {G, dy_gs, w_gs, pre_gs, dx_gs};
+    return linear_dgrad_impl(dy, lddy, w, dx, lddx, pre_in, nullptr, 1.f, M, N, K, flags, ws, ws_bytes, gr,
+                             (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_wgrad_grouped(const float *dy, int lddy, size_t dy_gs, const float *x, int ldx,
+                                          size_t x_gs, float *dw, size_t dw_gs, float *db, size_t db_gs, int G,
+                                          int M, int N, int K, int flags, void *ws, size_t ws_bytes,
+                                          mvae_stream_t stream) {
+    if (!dy || !x || !dw || !groups_ok(G) || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K) return MVAE_ERR_ARG;
+    const LinGroups gr = {G, dy_gs, x_gs, db_gs, dw_gs};
+    return linear_wgrad_impl(dy, lddy, x, ldx, dw, db, M, N, K, flags, ws, ws_bytes, gr, (hipStream_t)stream);
+}

@@ -14,9 +14,14 @@ from mvae_amd.arena import ParamArena
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
+def _header_functions(tuning=False):
+    """Functions include/mvae_hip.h declares: the product ABI, or (tuning=True) the block under
+    ``#ifdef MVAE_TUNING`` that only libmvae_hip_tuning.so exports."""
     text = open(os.path.join(ROOT, 'include', 'mvae_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    m = re.search(r'#ifdef MVAE_TUNING(.*?)#endif', text, flags=re.S)
+    assert m, 'the tuning block is missing from the header'
+    text = m.group(1) if tuning else text.replace(m.group(0), '')
     return sorted(set(re.findall(r'\b(mvae_[a-zA-Z0-9_]+)\s*\(', text)))
 
 
@@ -28,6 +33,21 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
     assert handle.mvae_abi_version() == 2
+
+
+def test_product_library_has_no_tuning_state():
+    """include/mvae_hip.h: 're-entrant: no global mutable state' -- the mvae_debug_* overrides live only in
+    the -DMVAE_TUNING build."""
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    tuning = _header_functions(tuning=True)
+    assert tuning and all(n.startswith('mvae_debug_') for n in tuning)
+    for name in tuning:
+        assert not hasattr(handle, name), 'libmvae_hip.so exports the tuning hook %s' % name
+    assert sorted(_lib._TUNING_SIGNATURES) == tuning
+    if os.path.exists(_lib.TUNING_LIB_PATH):
+        th = ctypes.CDLL(_lib.TUNING_LIB_PATH)
+        for name in tuning + _header_functions():
+            assert hasattr(th, name), 'tuning build lacks %s' % name
 
 
 def test_binding_table_matches_header():

@@ -51,15 +51,28 @@ def check_grads_vs_oracle(model, oracle, tol=REL_TOL):
     kind = model_kind(model)
     og = dict(oracle.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values())
-    worst = 0.0
+    worst, bad = 0.0, []
     for name, p in model.named_parameters():
         assert p.grad is not None, 'no gradient for ' + name
         ref = og[name].grad
         scale = max(ref.abs().max().item(), grad_floor(kind, name, gmax), 1e-30)
         err = (p.grad.detach().cpu() - ref).abs().max().item() / scale
-        assert err <= tol, 'grad %s: relative error %.3e' % (name, err)
+        if err > tol:
+            bad.append('%s %.3e' % (name, err))
         worst = max(worst, err)
+    assert not bad, 'gradients beyond %.0e: %s' % (tol, '; '.join(bad))
     return worst
+
+
+def hits_bce_jump(eng):
+    """The reference's hand-written BCE (mnist/train.py:73-74) has a gradient JUMP at a logit of exactly 0
+    (autograd gives 1 - t there, sigmoid(0) - t = 0.5 - t an ulp away).  A logit that
+    is a few ulps of its bias from zero can round to 0.0 on one side and not on the other -- then ONE
+    d loss / d logit differs by lambda/(2B) and every gradient behind it by ~1e-2, which says nothing about
+    the kernels.  Parity cases whose HIP logits contain an exact zero are re-drawn with the next seed."""
+    logits_lbl, _, _, logits_img, _, _ = eng._carry['keep'][-1]
+    return bool((logits_img == 0).any().item()) or (logits_lbl.dtype == torch.float32 and eng.model.LABEL_KIND != 'class'
+                                                     and bool((logits_lbl == 0).any().item()))
 
 
 def check_bn_vs(model, ref_sd, tol=1e-5):
@@ -117,15 +130,20 @@ def test_fused_step_matches_live_oracle(kind, batch):
 # fp32 error is largest.  Same bar: ELBO terms, every gradient 1e-4, BatchNorm running statistics 1e-5.
 @pytest.mark.parametrize('kind,batch', [('mnist', 512), ('fashionmnist', 1024), ('celeba', 256)])
 def test_fused_step_matches_live_oracle_at_baseline_batch(kind, batch):
-    oracle, model, d = build_pair(kind, weight_seed=37)
-    image, label = OS.synthetic_batch(kind, batch, seed=91)
-    torch.manual_seed(7)
-    noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
-    lam_i, lam_l, beta = 1.0, (10.0 if kind == 'celeba' else 50.0), 0.5
+    for attempt in range(4):
+        oracle, model, d = build_pair(kind, weight_seed=37)
+        image, label = OS.synthetic_batch(kind, batch, seed=91 + attempt)
+        torch.manual_seed(7)
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+        lam_i, lam_l, beta = 1.0, (10.0 if kind == 'celeba' else 50.0), 0.5
+        eng = BimodalStep(model, batch, lam_i, lam_l)
+        elbo = eng.terms_in_reference_order(eng.step(image.to(DEV), label.to(DEV), beta, noise=noise)).cpu()
+        if not hits_bce_jump(eng):
+            break
+    else:
+        pytest.fail('four consecutive draws with an exactly-zero logit')
     total, terms, lat = OS.bimodal_step(oracle, kind, image, label, noise, lam_i, lam_l, beta)
     total.backward()
-    eng = BimodalStep(model, batch, lam_i, lam_l)
-    elbo = eng.terms_in_reference_order(eng.step(image.to(DEV), label.to(DEV), beta, noise=noise)).cpu()
     assert_close(elbo[:3], torch.stack(terms).detach(), 'ELBO terms')
     assert_close(elbo[3], total.detach(), 'total')
     mu, lv, z = eng.last_latents
@@ -135,7 +153,7 @@ def test_fused_step_matches_live_oracle_at_baseline_batch(kind, batch):
         assert_close(lv[t], lat[c][1].detach(), 'logvar%d' % c)
     worst = check_grads_vs_oracle(model, oracle)
     check_bn_vs(model, oracle.state_dict())
-    print('%s B=%d (BASELINE size) worst gradient rel err %.2e' % (kind, batch, worst))
+    print('%s B=%d (BASELINE size, draw %d) worst gradient rel err %.2e' % (kind, batch, attempt, worst))
 
 
 @pytest.mark.parametrize('kind,batch', [('mnist', 24), ('fashionmnist', 9)])

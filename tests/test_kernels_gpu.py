@@ -34,7 +34,11 @@ def swish_grad(x):
 
 # ----------------------------------------------------------------------------- Linear
 LIN_SHAPES = [(128, 512, 784), (512, 128, 512), (37, 10, 512), (256, 512, 18), (300, 1, 512),
-              (64, 200, 6400), (1024, 6272, 512), (130, 100, 200), (3, 5, 7)]
+              (64, 200, 6400), (1024, 6272, 512), (130, 100, 200), (3, 5, 7),
+              # the MNIST step's shapes at batch 512 (rows of two ELBO terms = 1024): these run on the small
+              # 64x32 / 32x64 / 32x32 layouts with in-block k-groups instead of a split reduction
+              (1024, 512, 512), (512, 512, 512), (512, 512, 784), (1024, 784, 512), (1024, 512, 64),
+              (1024, 64, 512), (1000, 500, 516), (72, 36, 100)]
 
 
 @pytest.mark.parametrize('M,N,Kd', LIN_SHAPES)

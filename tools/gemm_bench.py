@@ -10,6 +10,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault('MVAE_HIP_LIB', os.path.join(ROOT, 'multimodal-vae-public_amd', 'libmvae_hip_tuning.so'))
+
 import torch  # noqa: E402
 
 import mvae_amd  # noqa: E402
@@ -78,47 +80,61 @@ def lin_cases(M, N, Kd, tag):
 
 
 def main():
-    cases = []
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv'])
+    args = ap.parse_args()
+    conv, lin = [], []
     B = 256
-    cases += conv_cases(B, 3, 64, 32, 2, 1, 'enc1 3->32 64x64')
-    cases += conv_cases(B, 32, 32, 64, 2, 1, 'enc2 32->64 32x32')
-    cases += conv_cases(B, 64, 16, 128, 2, 1, 'enc3 64->128 16x16')
-    cases += conv_cases(B, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1')
-    cases += convT_cases(2 * B, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1')
-    cases += convT_cases(2 * B, 128, 8, 64, 2, 1, 'dec2 128->64 8x8')
-    cases += convT_cases(2 * B, 64, 16, 32, 2, 1, 'dec3 64->32 16x16')
-    cases += convT_cases(2 * B, 32, 32, 3, 2, 1, 'dec4 32->3 32x32')
-    cases += lin_cases(B, 512, 6400, 'celeba 6400->512 M256')
-    cases += lin_cases(2 * B, 6400, 100, 'celeba 100->6400 M512')
-    cases += lin_cases(3 * B, 512, 512, 'celeba attr 512->512 M768')
-    cases += lin_cases(1024, 512, 512, 'mnist 512->512 M1024')
-    cases += lin_cases(512, 512, 784, 'mnist 784->512 M512')
-    cases += lin_cases(1024, 784, 512, 'mnist 512->784 M1024')
-    cases += lin_cases(512, 128, 512, 'mnist heads 512->128 M512')
+    conv += conv_cases(B, 3, 64, 32, 2, 1, 'enc1 3->32 64x64')
+    conv += conv_cases(B, 32, 32, 64, 2, 1, 'enc2 32->64 32x32')
+    conv += conv_cases(B, 64, 16, 128, 2, 1, 'enc3 64->128 16x16')
+    conv += conv_cases(B, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1')
+    conv += convT_cases(2 * B, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1')
+    conv += convT_cases(2 * B, 128, 8, 64, 2, 1, 'dec2 128->64 8x8')
+    conv += convT_cases(2 * B, 64, 16, 32, 2, 1, 'dec3 64->32 16x16')
+    conv += convT_cases(2 * B, 32, 32, 3, 2, 1, 'dec4 32->3 32x32')
+    lin += lin_cases(B, 512, 6400, 'celeba 6400->512 M256')
+    lin += lin_cases(2 * B, 6400, 100, 'celeba 100->6400 M512')
+    lin += lin_cases(3 * B, 512, 512, 'celeba attr 512->512 M768')
+    lin += lin_cases(1024, 512, 512, 'mnist 512->512 M1024')
+    lin += lin_cases(512, 512, 512, 'mnist 512->512 M512')
+    lin += lin_cases(512, 512, 784, 'mnist 784->512 M512')
+    lin += lin_cases(1024, 784, 512, 'mnist 512->784 M1024')
+    lin += lin_cases(1024, 512, 64, 'mnist 64->512 M1024')
+    lin += lin_cases(512, 128, 512, 'mnist heads 512->128 M512')
+    lin += lin_cases(1024, 6272, 512, 'fmnist 512->6272 M1024')
+    lin += lin_cases(1024, 512, 6272, 'fmnist 6272->512 M1024')
     lib = _lib.lib()
-    # (label, (wm, wn, splits), kwaves)
-    configs = [('auto', (0, 0, 0), 0), ('64x64 kw1', (1, 1, 0), 1), ('64x64 s1kw1', (1, 1, 1), 1),
-               ('s1 kw2', (1, 1, 1), 2), ('s1 kw4', (1, 1, 1), 4), ('s2 kw4', (1, 1, 2), 4),
-               ('s4 kw1', (1, 1, 4), 1), ('128x128', (2, 2, 0), 1), ('64x128', (1, 2, 0), 1)]
-    print('%-34s %8s | ' % ('op', 'GFLOP') + ' '.join('%11s' % c[0] for c in configs) + '   (TFLOP/s; us for auto)')
-    tot_auto = 0.0
-    for name, fl, fn in cases:
-        row = []
-        for cname, (wm, wn, sp), kw in configs:
-            lib.mvae_debug_set_tiling(wm, wn, sp)
-            lib.mvae_debug_set_kwaves(kw)
-            try:
-                ms = timeit(fn)
-                row.append(fl / (ms * 1e-3) / 1e12)
-                if cname == 'auto':
-                    t_auto = ms
-            except RuntimeError:
-                row.append(float('nan'))
-        lib.mvae_debug_set_tiling(0, 0, 0)
-        lib.mvae_debug_set_kwaves(0)
-        tot_auto += t_auto
-        print('%-34s %8.2f | ' % (name, fl / 1e9) + ' '.join('%11.1f' % v for v in row) + '   %8.1f us' % (t_auto * 1e3))
-    print('sum of auto times: %.3f ms' % tot_auto)
+    # (label, (wm, wn, splits), kwaves, (small_off, small_waves))
+    conv_cfg = [('auto', (0, 0, 0), 0, (0, 0)), ('64x64 kw1', (1, 1, 0), 1, (0, 0)), ('128x128', (2, 2, 0), 1, (0, 0)),
+                ('64x128', (1, 2, 0), 1, (0, 0)), ('128x64', (2, 1, 0), 1, (0, 0))]
+    lin_cfg = [('auto', (0, 0, 0), 0, (0, 0)), ('r1 plan', (0, 0, 0), 0, (1, 0)), ('small w4', (0, 0, 0), 0, (0, 4)),
+               ('small w8', (0, 0, 0), 0, (0, 8)), ('64x64 s1kw1', (1, 1, 1), 1, (1, 0)), ('s1 kw4', (1, 1, 1), 4, (1, 0))]
+    tot = {}
+    for title, cases, configs in (('conv', conv, conv_cfg), ('lin', lin, lin_cfg)):
+        if args.cases not in ('all', title):
+            continue
+        print('%-34s %8s | ' % ('op', 'GFLOP') + ' '.join('%11s' % c[0] for c in configs) + '   (TFLOP/s; us for auto)')
+        for name, fl, fn in cases:
+            row = []
+            for cname, (wm, wn, sp), kw, (soff, sw) in configs:
+                lib.mvae_debug_set_tiling(wm, wn, sp)
+                lib.mvae_debug_set_kwaves(kw)
+                lib.mvae_debug_set_small(soff, sw)
+                try:
+                    ms = timeit(fn)
+                    row.append(fl / (ms * 1e-3) / 1e12)
+                    tot[(title, cname)] = tot.get((title, cname), 0.0) + ms
+                    if cname == 'auto':
+                        t_auto = ms
+                except RuntimeError:
+                    row.append(float('nan'))
+            lib.mvae_debug_set_tiling(0, 0, 0)
+            lib.mvae_debug_set_kwaves(0)
+            lib.mvae_debug_set_small(0, 0)
+            print('%-34s %8.2f | ' % (name, fl / 1e9) + ' '.join('%11.1f' % v for v in row) + '   %8.1f us' % (t_auto * 1e3))
+        print('sum of times (ms): ' + '  '.join('%s %.3f' % (c[0], tot.get((title, c[0]), float('nan'))) for c in configs))
 
 
 if __name__ == '__main__':

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
+import os as _os
+_os.environ.setdefault("MVAE_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "multimodal-vae-public_amd", "libmvae_hip_tuning.so"))
 import torch  # noqa: E402
 
 import mvae_amd  # noqa: F401,E402
