@@ -336,6 +336,9 @@ void mvae_debug_set_kwaves(int kw);
 void mvae_debug_set_small(int off, int waves);
 /* blocks a split reduction aims for; 0 = automatic */
 void mvae_debug_set_split_target(long blocks);
+/* knock-out study of the direct Linear weight-gradient kernel: 1 = loads without MFMAs, 2 = MFMAs without
+ * loads (results are then meaningless); 0 = normal */
+void mvae_debug_set_knockout(int mode);
 #endif
 
 #ifdef __cplusplus

@@ -99,6 +99,7 @@ _TUNING_SIGNATURES = {
     'mvae_debug_set_kwaves': (None, [c_int]),
     'mvae_debug_set_small': (None, [c_int, c_int]),
     'mvae_debug_set_split_target': (None, [ctypes.c_long]),
+    'mvae_debug_set_knockout': (None, [c_int]),
 }
 TUNING_LIB_PATH = os.path.join(_HERE, 'libmvae_hip_tuning.so')
 

@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Tuning overrides exist only in the -DMVAE_TUNING build (libmvae_hip_tuning.so, used by tools/gemm_bench.py);
 // the product library has no mutable global state: MVAE_TUNE(x) folds to 0.
 #ifdef MVAE_TUNING
-struct MvaeTune { int wm, wn, splits, kw, small_off, small_waves; long split_target; };
+struct MvaeTune { int wm, wn, splits, kw, small_off, small_waves; long split_target; int knockout; };
 extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #define MVAE_TUNE(f) (g_mvae_tune.f)
 #else

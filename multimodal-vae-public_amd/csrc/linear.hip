@@ -1,6 +1,7 @@
 // linear.hip -- Linear layers (forward, data gradient, weight gradient; single and grouped) on the GEMM
 // kernel of gemm_core.h, and the library-wide entry points.
 #include "gemm_core.h"
+#include "linear_direct.h"
 
 
 // ==========================================================================================
@@ -10,13 +11,14 @@ MVAE_EXPORT int mvae_abi_version(void) { return 2; }
 
 #ifdef MVAE_TUNING
 // tuning build only (libmvae_hip_tuning.so): force tile shapes / split counts for tools/gemm_bench.py
-MvaeTune g_mvae_tune = {0, 0, 0, 0, 0, 0, 0};
+MvaeTune g_mvae_tune = {0, 0, 0, 0, 0, 0, 0, 0};
 MVAE_EXPORT void mvae_debug_set_tiling(int wm, int wn, int splits) {
     g_mvae_tune.wm = wm; g_mvae_tune.wn = wn; g_mvae_tune.splits = splits;
 }
 MVAE_EXPORT void mvae_debug_set_kwaves(int kw) { g_mvae_tune.kw = kw; }
 MVAE_EXPORT void mvae_debug_set_small(int off, int waves) { g_mvae_tune.small_off = off; g_mvae_tune.small_waves = waves; }
 MVAE_EXPORT void mvae_debug_set_split_target(long blocks) { g_mvae_tune.split_target = blocks; }
+MVAE_EXPORT void mvae_debug_set_knockout(int mode) { g_mvae_tune.knockout = mode; }
 #endif
 
 MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len) {
@@ -92,6 +94,8 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
     e.out = dw; e.act = nullptr; e.ld = K; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
     e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = N; e.J = K; e.accumulate = acc;
     e.out_cs = gr.d;
+    if (gr.G == 1 && wgrad_direct_ok(N, K, M))
+        return wgrad_direct_launch(dy, lddy, x, ldx, e, N, K, M, db, acc, st);
     auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = gr.a; };
     auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = gr.b; };
     int rc;

@@ -1,0 +1,172 @@
+// linear_direct.h -- the Linear weight gradient without LDS tiles and without block barriers.
+//
+//   dw[n][k] (+)= sum_m dy[m][n] * x[m][k],   db[n] (+)= sum_m dy[m][n]        (mnist/model.py:75-78,95-98 ... backward)
+//
+// Both operands have the NON-reduced axis contiguous, which is exactly the layout an MFMA fragment wants:
+// for the 32x32x2 fp32 MFMA lane (c, h) supplies A[i0 + c][m] and B[m][j0 + c] -- 32 consecutive floats of
+// row m of dy / x per half-wave, a full 128-byte segment.  So every wave loads its own fragments straight from
+// global memory (4 dword loads per operand per 8 rows of m, software-prefetched PD chunks ahead), owns one
+// 32x32 output tile over every KW-th 8-row chunk of the batch and never meets another wave until the end,
+// where the KW partial tiles are summed through LDS in a fixed order and all threads run the epilogue.
+// The LDS-tiled kernel spent half its time in the per-k-step barrier on these shapes (4 MFMAs per wave between
+// barriers); here the only synchronisation is the final reduction.
+#pragma once
+#include "gemm_core.h"
+
+namespace {
+
+#ifdef MVAE_TUNING
+#define MVAE_KO1 1
+#define MVAE_KO2 2
+#else
+#define MVAE_KO1 0
+#define MVAE_KO2 0
+#endif
+constexpr int WD_PD = 4;      // chunks (of 8 reduction rows) in flight per wave: 2 x 16 VGPRs
+
+// MODE (tuning build only: mvae_debug_set_knockout): 0 = the kernel; 1 = loads without the MFMAs; 2 = MFMAs
+// without the loads -- where the time of a launch goes.
+template <bool ROWSUM, int KW, int MODE = 0>
+__global__ __launch_bounds__(64 * KW) void wgrad_direct_kernel(const float *dy, int lddy, const float *x, int ldx,
+                                                              EpRowMajor e, int I, int J, int M, float *db,
+                                                              int db_accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float wd_lds[];
+    const int t = threadIdx.x, lane = t & 63, kg = t >> 6;
+    const int lcol = lane & 31, lrow = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    // 32-bit element offsets from the (wave-uniform) tensor bases: scalar base + vector offset addressing.
+    // Columns beyond the operand are clamped (their products land in outputs the epilogue drops).
+    const unsigned col_a = (unsigned)min(i0 + lcol, I - 1) * 4u, col_b = (unsigned)min(j0 + lcol, J - 1) * 4u;
+    const unsigned ulda = (unsigned)lddy * 4u, uldb = (unsigned)ldx * 4u;       // BYTE strides / offsets (< 4 GiB)
+    const char *dyb = reinterpret_cast<const char *>(dy), *xb = reinterpret_cast<const char *>(x);
+    const int full = M >> 3;                        // chunks of 8 reduction rows entirely inside the batch
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rs = 0.f;
+    // Two register sets of WD_PD chunks each: while one set is multiplied the other is in flight, and the
+    // loop body handles both (A: refill set 1, consume set 0; B: refill set 0, consume set 1), so a set is
+    // dead when its refill is issued and the loaded values stay in the registers the next trip reads --
+    // a rotating single set made hipcc copy 32 in-flight registers at the back edge behind s_waitcnt vmcnt(0).
+    float a0[WD_PD][4], b0[WD_PD][4], a1[WD_PD][4], b1[WD_PD][4];
+
+    auto fetch = [&](int c, float (&av)[4], float (&bv)[4]) {
+        const unsigned m0 = (unsigned)(c * 8 + 4 * lrow);
+        unsigned oa = m0 * ulda + col_a, ob = m0 * uldb + col_b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (MODE == 2) { av[q] = (float)oa; bv[q] = (float)ob; }
+            else { av[q] = *reinterpret_cast<const float *>(dyb + oa); bv[q] = *reinterpret_cast<const float *>(xb + ob); }
+            oa += ulda; ob += uldb;
+        }
+    };
+    auto mfma4 = [&](const float (&av)[4], const float (&bv)[4], float live) {
+        const float v0 = av[0] * live, v1 = av[1] * live, v2 = av[2] * live, v3 = av[3] * live;
+        if (ROWSUM) rs += (v0 + v1) + (v2 + v3);
+        if (MODE == 1) { acc[0] += (v0 * bv[0] + v1 * bv[1]) + (v2 * bv[2] + v3 * bv[3]); return; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, bv[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, bv[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, bv[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, bv[3], acc, 0, 0, 0);
+    };
+    // this wave's chunks: kg, kg + KW, ...  (all waves of the block stream through the same rows together).
+    // Every load is UNCONDITIONAL (chunk index clamped to this wave's last chunk; a surplus chunk is
+    // multiplied by zero): a load under a branch makes hipcc drain the whole memory queue.
+    const int n_my = (full - kg + KW - 1) / KW;     // may be 0 when the batch is shorter than 8 * KW rows
+    auto load_set = [&](int first, float (&as)[WD_PD][4], float (&bs)[WD_PD][4]) {
+#pragma unroll
+        for (int p = 0; p < WD_PD; ++p) fetch(kg + min(first + p, n_my - 1) * KW, as[p], bs[p]);
+    };
+    auto use_set = [&](int first, const float (&as)[WD_PD][4], const float (&bs)[WD_PD][4]) {
+#pragma unroll
+        for (int p = 0; p < WD_PD; ++p) mfma4(as[p], bs[p], (first + p < n_my) ? 1.f : 0.f);
+    };
+    if (n_my > 0) {
+        load_set(0, a0, b0);
+        for (int it = 0; it < n_my; it += 2 * WD_PD) {
+            load_set(it + WD_PD, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            use_set(it, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_set(it + 2 * WD_PD, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            use_set(it + WD_PD, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if ((M & 7) && kg == full % KW) {               // the ragged last chunk: rows past the batch are zero
+        float av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = full * 8 + 4 * lrow + q;
+            const float ok = (m < M) ? 1.f : 0.f;
+            const unsigned mc = (unsigned)min(m, M - 1);
+            av[q] = *reinterpret_cast<const float *>(dyb + (mc * ulda + col_a)) * ok;
+            bv[q] = *reinterpret_cast<const float *>(xb + (mc * uldb + col_b)) * ok;
+        }
+        mfma4(av, bv, 1.f);
+    }
+    // ---- reduce the KW partial tiles (fixed order) and run the epilogue with every thread
+    constexpr int TP = 33;
+    float *tile = wd_lds + kg * (32 * TP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[(4 * lrow + (r & 3) + 8 * (r >> 2)) * TP + lcol] = acc[r];
+    float *rsl = wd_lds + KW * (32 * TP);           // [KW][2][32] partial row sums
+    if (ROWSUM) rsl[(kg * 2 + lrow) * 32 + lcol] = rs;
+    __syncthreads();
+    for (int el = t; el < 32 * 32; el += 64 * KW) {
+        const int il = el >> 5, jl = el & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < KW; ++g2) v += wd_lds[g2 * (32 * TP) + il * TP + jl];
+        if (e.col(j0 + jl)) e.put(i0 + il, j0 + jl, v);
+    }
+    if (ROWSUM) {
+        if (blockIdx.x == 0 && t < 32 && i0 + t < I) {
+            float s = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 2 * KW; ++g2) s += rsl[g2 * 32 + t];
+            if (db_accumulate) s += db[i0 + t];
+            db[i0 + t] = s;
+        }
+    }
+}
+
+// one problem (no groups); returns false when the shape is better served by the tiled kernel
+inline bool wgrad_direct_ok(int I, int J, int M) {
+    const long tiles = cdiv(I, 32) * cdiv(J, 32);
+    if (MVAE_TUNE(small_off) || MVAE_TUNE(wm) || MVAE_TUNE(wn) || MVAE_TUNE(kw) || MVAE_TUNE(splits)) return false;
+    // enough tiles to occupy the chip, a reduction short enough that KW <= 16 waves per tile cover it
+    return tiles >= 16 && tiles <= 2048 && M <= 4096;
+}
+
+inline int wgrad_direct_launch(const float *dy, int lddy, const float *x, int ldx, EpRowMajor e, int I, int J, int M,
+                               float *db, int db_accumulate, hipStream_t st) {
+    const long tiles = cdiv(I, 32) * cdiv(J, 32);
+    const dim3 grid((unsigned)cdiv(J, 32), (unsigned)cdiv(I, 32));
+    int kw = tiles >= 192 ? 4 : (tiles >= 96 ? 8 : 16);
+    if (MVAE_TUNE(small_waves)) kw = MVAE_TUNE(small_waves);
+#define MVAE_WD(RS, KWV)                                                                                      \
+    {                                                                                                         \
+        constexpr size_t lds = ((size_t)KWV * 32 * 33 + (size_t)KWV * 64) * sizeof(float);                    \
+        auto kern = MVAE_TUNE(knockout) == 1 ? wgrad_direct_kernel<RS, KWV, MVAE_KO1>                          \
+                  : MVAE_TUNE(knockout) == 2 ? wgrad_direct_kernel<RS, KWV, MVAE_KO2> : wgrad_direct_kernel<RS, KWV, 0>; \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * KWV), lds, st, dy, lddy, x, ldx, e, I, J, M, db, db_accumulate); \
+    }
+    if (db) {
+        if (kw == 4) MVAE_WD(true, 4) else if (kw == 8) MVAE_WD(true, 8) else MVAE_WD(true, 16)
+    } else {
+        if (kw == 4) MVAE_WD(false, 4) else if (kw == 8) MVAE_WD(false, 8) else MVAE_WD(false, 16)
+    }
+#undef MVAE_WD
+    return mvae_launch_status();
+}
+
+}  // namespace

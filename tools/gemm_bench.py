@@ -82,7 +82,7 @@ def lin_cases(M, N, Kd, tag):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv'])
+    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv', 'knockout'])
     args = ap.parse_args()
     conv, lin = [], []
     B = 256
@@ -111,6 +111,19 @@ def main():
                 ('64x128', (1, 2, 0), 1, (0, 0)), ('128x64', (2, 1, 0), 1, (0, 0))]
     lin_cfg = [('auto', (0, 0, 0), 0, (0, 0)), ('r1 plan', (0, 0, 0), 0, (1, 0)), ('small w4', (0, 0, 0), 0, (0, 4)),
                ('small w8', (0, 0, 0), 0, (0, 8)), ('64x64 s1kw1', (1, 1, 1), 1, (1, 0)), ('s1 kw4', (1, 1, 1), 4, (1, 0))]
+    if args.cases == 'knockout':
+        # where the time of the direct Linear weight-gradient launches goes: loads only / MFMAs only
+        print('%-34s %10s %10s %10s   (us per launch)' % ('op', 'kernel', 'loads only', 'mfma only'))
+        for name, fl, fn in lin:
+            if 'wgrad' not in name:
+                continue
+            row = []
+            for mode in (0, 1, 2):
+                lib.mvae_debug_set_knockout(mode)
+                row.append(timeit(fn) * 1e3)
+            lib.mvae_debug_set_knockout(0)
+            print('%-34s %10.1f %10.1f %10.1f' % tuple([name] + row))
+        return
     tot = {}
     for title, cases, configs in (('conv', conv, conv_cfg), ('lin', lin, lin_cfg)):
         if args.cases not in ('all', title):
