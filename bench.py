@@ -85,71 +85,114 @@ def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, f
             img, lbl = batches[i % 4]
             elbo = eng.step(img, lbl, annealing(i))
             if dp is not None:
-                dp.wait()
-            opt.step()
+                dp.finish(opt)
+            else:
+                opt.step()
             return elbo
+    def timed(n, first):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(n):
+            last = one(first + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, last
+
     for i in range(warmup):
         one(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        elbo = one(warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt, elbo = timed(steps, warmup)
+    info = None
+    if dp is not None:
+        # what the data-parallel exchange costs: the same launch path with the collectives switched off
+        # (replicas diverge from here on -- nothing is measured after this)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        sizes = [(hi - lo) * 4 for lo, hi in dp.buckets.ranges]
+        dp.buckets.launch = lambda k: None
+        dp.buckets.wait = lambda k=None: None
+        n2 = max(5, steps // 2)
+        dt_off, _ = timed(n2, warmup + steps)
+        info = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()),
+                'allreduce_of_ones': ones.item(), 'bucket_bytes': sizes,
+                'ms_per_step_without_collectives': round(dt_off / n2 * 1e3, 4),
+                'exposed_comm_ms_per_step': round((dt / steps - dt_off / n2) * 1e3, 4)}
     loss = float(elbo[-1].item())
-    return dt, loss, (model, eng, opt, batches)
+    return dt, loss, (model, eng, opt, batches, info)
+
+
+def _spin_cycles_per_second():
+    """Calibrate torch.cuda._sleep (a spin kernel): cycles of its argument per second of GPU time."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record()
+    torch.cuda.synchronize()
+    return 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
 
 
 def roofline_from_profile(eng, opt, batches, n_steps=3):
-    """Which launches make up a step, and how fast each runs.
+    """Which launches make up a step, and how fast each runs IN the step.
 
-    Pass 1 (eager, ONE stream): every launcher of kernels.py is bracketed by HIP events and tagged
-    with its algorithmic work -- gives the call list (name, shape, calls per step).  Pass 2: each
-    distinct GEMM-shaped call, and the busiest HBM-bound one, is re-issued 20x inside a hipGraph and
-    timed with HIP events on the launch stream (KernelProfile.steady_state_ms): the average launch
-    duration with the queue kept full, free of host enqueue gaps.  achieved = algorithmic flops of
-    the call / that duration."""
+    Every launcher of kernels.py is bracketed by a pair of HIP events on the launch stream and tagged with
+    its algorithmic work; ``n_steps`` eager single-stream steps are enqueued BEHIND a spin kernel that
+    outlasts the host's enqueue time, so when the GPU reaches them the queue is full: an interval holds
+    the kernel(s) of one call plus its launch boundary, no host gap, and the caches are in the state the
+    step's previous kernel left them (in-situ).  achieved = algorithmic flops of the call / that interval,
+    averaged over the calls of the three steps.  For the dominant call the old hot-cache figure (the same
+    call re-issued 20x inside a hipGraph on the same operands) is reported next to it, labelled."""
     from mvae_amd.profiler import GEMM_COSTS, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, KernelProfile
     streams = (eng.side, eng.wg_main, eng.wg_side)
-    eng.side = eng.wg_main = eng.wg_side = None          # single stream for the call census
+    eng.side = eng.wg_main = eng.wg_side = None          # single stream: one ordered queue
     try:
-        for i in range(2):
-            eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
+        eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
+        host_s = time.perf_counter() - t0                # host time to enqueue one eager step
+        torch.cuda.synchronize()
+        spin = int(_spin_cycles_per_second() * (2.5 * host_s * n_steps + 0.005))
         with KernelProfile() as prof:
+            torch.cuda._sleep(spin)
             for i in range(n_steps):
                 eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
                 opt.step()
         rows = prof.summary()
         gemm = [r for r in rows if r['name'] in GEMM_COSTS]
         for r in gemm:
-            r['ms_avg'] = prof.steady_state_ms(r['name'], r['key'])
-            r['ms_total'] = r['ms_avg'] * r['calls']
             r['tflops'] = r['flops'] / (r['ms_avg'] * 1e-3) / 1e12
+        gemm.sort(key=lambda r: -r['ms_total'])
+        dom = gemm[0]
+        hot_ms = prof.steady_state_ms(dom['name'], dom['key'])
         hbm = [r for r in rows if r['name'] not in GEMM_COSTS and r['bytes'] > 0]
-        if hbm:
-            top = max(hbm, key=lambda r: r['ms_total'])
-            top['ms_avg'] = prof.steady_state_ms(top['name'], top['key'])
+        top = max(hbm, key=lambda r: r['ms_total']) if hbm else None
+        if top is not None:
             top['gbs'] = top['bytes'] / (top['ms_avg'] * 1e-3) / 1e9
     finally:
         eng.side, eng.wg_main, eng.wg_side = streams
-    gemm.sort(key=lambda r: -r['ms_total'])
-    dom = gemm[0]
     flops_step = sum(r['flops'] * r['calls'] for r in gemm) / n_steps
     ms_gemm = sum(r['ms_total'] for r in gemm) / n_steps
     roof = {
-        'bound': 'mfma', 'kernel': 'igemm_kernel<%s %s>' % (dom['name'], dom['key']),
+        'bound': 'mfma', 'kernel': '%s %s' % (dom['name'], dom['key']),
         'achieved': round(dom['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic_for(dom['name'], dom['key']),
         'avg_launch_ms': round(dom['ms_avg'], 5), 'algorithmic_flops_per_launch': dom['flops'],
-        'timing': 'HIP events around 5 replays of a hipGraph of 20 launches, on the launch stream',
+        'calls_per_step': dom['calls'] / n_steps,
+        'timing': 'in-situ: HIP event pairs on the launch stream around every call of %d eager single-stream '
+                  'steps enqueued behind a spin kernel (queue full, no host gap inside an interval; an interval '
+                  'includes the launch boundary)' % n_steps,
+        'hot_cache_reissue': {'avg_launch_ms': round(hot_ms, 5),
+                              'tflops': round(dom['flops'] / (hot_ms * 1e-3) / 1e12, 3),
+                              'frac': round(dom['flops'] / (hot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                              'timing': 'the same call re-issued 20x in a hipGraph on the same operands (L2/MALL hot)'},
         'all_gemm_kernels': {'tflops': round(flops_step / (ms_gemm * 1e-3) / 1e12, 3),
                              'frac': round(flops_step / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                              'ms_per_step': round(ms_gemm, 4), 'gflop_per_step': round(flops_step / 1e9, 3)},
@@ -161,15 +204,16 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
         roof['conv_kernels'] = {'tflops': round(fl / (ms * 1e-3) / 1e12, 3),
                                 'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 'ms_per_step': round(ms, 4), 'gflop_per_step': round(fl / 1e9, 3)}
-    if hbm:
+    if top is not None:
         roof['top_hbm_kernel'] = {'kernel': top['name'], 'gbs': round(top['gbs'], 1),
                                   'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5)}
+    roof['launches_per_step'] = sum(r['calls'] for r in rows) / n_steps
     roof['top_kernels'] = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_total'] / n_steps, 4),
                             'calls_per_step': r['calls'] / n_steps, 'tflops': round(r['tflops'], 2)} for r in gemm[:6]]
     return roof
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
 
 
 def traffic_for(name, key):
@@ -232,12 +276,33 @@ def elbo_delta(kind, batch=32):
             'worst_gradient_rel': float('%.3e' % worst), 'batch': batch, 'tolerance': 1e-4}
 
 
-def cpu_baseline(kind, batch, budget_s=15.0):
+def host_description():
+    """nproc and CPU model of this box (north_star: 'core count stated')."""
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except IOError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {'nproc': os.cpu_count() or 1, 'usable_cpus': usable, 'cpu_model': model}
+
+
+def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True):
     """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
-    host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s."""
+    host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s.
+    ``cores`` = the intra-op threads actually used (the fastest of a few counts: torch's CPU kernels do
+    not scale to every core of a big host); the box itself is described under ``host``."""
     from oracle import models as OM, steps as OS
     import numpy as np
-    cores = os.cpu_count() or 1
+    host = host_description()
+    cores = host['usable_cpus']
     cls, d = OM.MODELS[kind]
     torch.manual_seed(0)
     model = cls(d).train()
@@ -262,8 +327,6 @@ def cpu_baseline(kind, batch, budget_s=15.0):
         opt.step()
         return time.perf_counter() - t0
 
-    # torch's CPU kernels do not scale to every core of a big host (oversubscribed small ops get
-    # slower): probe a few intra-op thread counts and time the sample at the fastest one
     best = None
     probe = (16, 32) if kind == 'celeba19' else (8, 16, 32, 64)      # a celeba19 step is ~20 model() calls
     for th in [t for t in probe if t <= cores] or [cores]:
@@ -279,10 +342,14 @@ def cpu_baseline(kind, batch, budget_s=15.0):
         t_total += one_step(); n += 1
         if n >= 200:
             break
-    return {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '
-                      '%d threads' % (n, kind, batch, torch.__version__, threads),
-            'elbo_delta': elbo_delta(kind, 8 if kind == 'celeba19' else 32)}
+    out = {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+           'threads': threads, 'host': host,
+           'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '
+                     '%d intra-op threads (fastest of %s) on a %d-CPU host' % (
+                         n, kind, batch, torch.__version__, threads, list(probe), host['nproc'])}
+    if with_delta:
+        out['elbo_delta'] = elbo_delta(kind, 8 if kind == 'celeba19' else 32)
+    return out
 
 
 def main():
@@ -335,10 +402,21 @@ def main():
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'launch': 'eager' if args.no_graph else 'hipGraph replay', 'final_loss': round(loss, 3)},
     }
-    if rank == 0 and world == 1 and not args.no_extras:
-        model, eng, opt, batches = state
+    if state[4] is not None:
+        out['dist'] = state[4]
+        if rank == 0:
+            sys.stderr.write('[bench] world %d over %s (RCCL %s); all-reduce of ones = %g; buckets %s bytes; '
+                             'exposed communication %.4f ms/step\n' % (
+                                 state[4]['world_size'], state[4]['backend'], state[4]['rccl_version'],
+                                 state[4]['allreduce_of_ones'], state[4]['bucket_bytes'],
+                                 state[4]['exposed_comm_ms_per_step']))
+    if rank == 0 and world == 1 and not args.no_extras and not args.force_dp:
+        model, eng, opt, batches = state[:4]
         out['roofline'] = roofline_from_profile(eng, opt, batches)
         out['cpu_baseline'] = cpu_baseline(kind, batch)
+        if kind == 'mnist':
+            # BASELINE.json configs[0]: the reference's own CPU-runnable case, mnist batch 128
+            out['cpu_baseline']['cfg0_mnist_b128'] = cpu_baseline('mnist', 128, budget_s=6.0, with_delta=False)
         if kind == 'mnist' and args.batch is None:
             del state, model, eng, opt, batches
             torch.cuda.empty_cache()

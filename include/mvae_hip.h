@@ -272,6 +272,13 @@ int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t seed, uint64_
 int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                    int64_t *step_dev, mvae_stream_t stream);
+/* Adam over a range of the arena WITHOUT advancing `step_dev` (t = *step_dev + 1): data-parallel replicas
+ * update each gradient bucket as its all-reduce lands and advance the counter once per step with
+ * mvae_counter_add (mnist/train.py:219 is ONE optimizer.step(); the ranges partition it). */
+int mvae_adam_apply(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                    size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
+                    const int64_t *step_dev, mvae_stream_t stream);
+int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
 int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
 
 /* CelebA-19 term plumbing (celeba19/train.py:264-302, celeba19/model.py:56-60): gather the z blocks

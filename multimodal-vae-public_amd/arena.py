@@ -18,11 +18,13 @@ ALIGN = 4  # floats: every parameter starts 16-byte aligned for float4 loads
 
 
 class ParamArena(object):
-    def __init__(self, module, order=None, adjacent=()):
+    def __init__(self, module, order=None, adjacent=(), tail=()):
         """``order``: sub-modules in the order their gradients complete during backward
         (default: registration order).  ``adjacent``: tuples of parameters that must be laid
         out back to back (e.g. the mu / logvar heads of the MNIST encoders, so that both heads
-        are one GEMM)."""
+        are one GEMM).  ``tail``: modules whose parameters go to the very END of the arena -- the layers
+        whose gradients complete last (the image encoder's first layers): data-parallel replicas all-reduce
+        them as a small last bucket, ``tail_range``."""
         params = []
         seen = set()
         mods = list(order) if order is not None else [module]
@@ -31,6 +33,8 @@ class ParamArena(object):
                 if id(p) not in seen:
                     seen.add(id(p))
                     params.append(p)
+        tail_ids = set(id(p) for m in tail for p in m.parameters())
+        params = [p for p in params if id(p) not in tail_ids] + [p for p in params if id(p) in tail_ids]
         follow = {}
         for tup in adjacent:
             for a, b in zip(tup[:-1], tup[1:]):
@@ -74,9 +78,16 @@ class ParamArena(object):
                 p.grad = None
         if order is not None:
             for m in order:
-                offs = [p._arena_off for p in m.parameters()]
-                ends = [p._arena_off + p.numel() for p in m.parameters()]
-                self.module_ranges[m] = (min(offs), max(ends))
+                offs = [p._arena_off for p in m.parameters() if id(p) not in tail_ids]
+                ends = [p._arena_off + p.numel() for p in m.parameters() if id(p) not in tail_ids]
+                if offs:
+                    self.module_ranges[m] = (min(offs), max(ends))     # without the module's tail parameters
+        self.tail_range = None
+        if tail_ids:
+            offs = [p._arena_off for p in ordered if id(p) in tail_ids]
+            self.tail_range = (min(offs), self.numel)
+            if any(id(p) not in tail_ids for p in ordered if p._arena_off >= self.tail_range[0]):
+                raise RuntimeError('tail parameters are not contiguous at the end of the arena')
 
     def grad_view(self, p):
         o = p._arena_off

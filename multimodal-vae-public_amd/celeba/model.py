@@ -132,7 +132,10 @@ class MVAE(MVAEBase):
     label_decoder = property(lambda self: self.attrs_decoder)
 
     def arena_order(self):
-        return [self.image_decoder, self.attrs_decoder, self.image_encoder, self.attrs_encoder]
+        return [self.image_decoder, self.attrs_decoder, self.attrs_encoder, self.image_encoder]
+
+    def arena_tail(self):
+        return [self.image_encoder.features]
 
     def forward(self, image=None, attrs=None, eps=None, dropout_mask=None):
         mu, logvar, z = self._infer(image, attrs, eps, dropout_mask, want_z=True)

@@ -68,8 +68,11 @@ class MVAE(MVAEBase):
         self.image_encoder.__dict__['_owner'] = self
 
     def arena_order(self):
-        return ([self.image_decoder] + list(self.attr_decoders) + [self.image_encoder]
-                + list(self.attr_encoders))
+        return ([self.image_decoder] + list(self.attr_decoders) + list(self.attr_encoders)
+                + [self.image_encoder])
+
+    def arena_tail(self):
+        return [self.image_encoder.features]
 
     def forward(self, image=None, attrs=None, eps=None, dropout_mask=None):
         """``attrs``: list of 18 tensors [B] (or None for a missing attribute), like the

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
 }
 
 __global__ void bump_i64_kernel(int64_t *step) { *step += 1; }
+__global__ void add_i64_kernel(int64_t *counter, int64_t delta) { *counter += delta; }
 
 __global__ __launch_bounds__(256) void fill_kernel(float *out, size_t n, float value) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = value;
@@ -270,6 +271,25 @@ MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, 
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev);
     hipLaunchKernelGGL(bump_i64_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return mvae_launch_status();
+}
+
+// Adam over a RANGE of the arena without advancing the step counter: data-parallel replicas update bucket
+// k as soon as its all-reduce has landed (t = *step_dev + 1 for every range of the step), then advance the
+// counter once with mvae_counter_add.
+MVAE_EXPORT int mvae_adam_apply(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                double lr, double beta1, double beta2, double eps, float grad_scale,
+                                const int64_t *step_dev, mvae_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream) {
+    if (!counter_dev) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, delta);
     return mvae_launch_status();
 }
 

@@ -128,6 +128,7 @@ class _StepBase(object):
         self.seed = int(seed) or 1
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.on_bucket_ready = None     # parallel.py hooks gradient all-reduce launches here
+        self.n_buckets = 2              # decoders | encoders; 3: the image encoder's first layers apart
         self._graphs = None
         self._comm = None
         # independent stacks (image vs label side) run as two branches; each kernel here fills
@@ -188,16 +189,32 @@ class _StepBase(object):
             main.wait_stream(self.side)
             self._forked = False
 
-    # subclasses: _phase_a(image, label), _phase_b(), set_coefficients(beta), draw_noise()
+    def configure_buckets(self, n):
+        """Gradient buckets of the data-parallel exchange (parallel.bucket_ranges): 2 = decoders | encoders,
+        3 = decoders | encoders without the image encoder's first layers | those layers (arena tail)."""
+        if n not in (1, 2, 3):
+            raise ValueError('1, 2 or 3 gradient buckets')
+        if n == 3 and self.model.arena.tail_range is None:
+            raise ValueError('three buckets need an arena tail')
+        self.n_buckets = n
+
+    def _phases_b(self):
+        """The launch groups of phase B, one per encoder bucket."""
+        if self.n_buckets == 3:
+            return [lambda: self._phase_b('upper'), lambda: self._phase_b('lower')]
+        return [lambda: self._phase_b('all')]
+
+    # subclasses: _phase_a(image, label), _phase_b(part), set_coefficients(beta), draw_noise()
     def forward_backward(self, image, label):
         """Launch the whole forward + backward.  Gradients go to ``p.grad`` (the arena); returns
         the device tensor ``elbo[T+1]`` = per-term ELBOs (engine order) and their sum."""
         self._phase_a(image, label)
-        if self.on_bucket_ready is not None:
+        if self.on_bucket_ready is not None and self.n_buckets > 1:
             self.on_bucket_ready(0)      # decoder gradients are final
-        self._phase_b()
-        if self.on_bucket_ready is not None:
-            self.on_bucket_ready(1)      # encoder gradients are final
+        for k, part in enumerate(self._phases_b()):
+            part()
+            if self.on_bucket_ready is not None:
+                self.on_bucket_ready(k + 1 if self.n_buckets > 1 else 0)   # this group of encoder gradients is final
         return self.elbo
 
     def step(self, image, label, annealing_factor, noise=None):
@@ -229,7 +246,7 @@ class _StepBase(object):
         with torch.cuda.stream(side):
             for it in range(warmup):
                 before = [m._nbt_pending for m in bns]
-                self._body_a(); self._phase_b(); optimizer.step()
+                self._body_a(); self._phase_b('all'); optimizer.step()
                 # graph replays skip the host code that counts BatchNorm calls: remember the
                 # per-step increments of num_batches_tracked and re-apply them in replay()
                 self._bn_inc = [(m, m._nbt_pending - b) for m, b in zip(bns, before)]
@@ -238,18 +255,24 @@ class _StepBase(object):
         if comm is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._body_a(); self._phase_b(); optimizer.step()
+                self._body_a(); self._phase_b('all'); optimizer.step()
             self._graphs = (g,)
         else:
-            ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # data parallel: one graph per gradient bucket (A = forward + decoder backward, then one or two
+            # groups of encoder backward); the bucket all-reduces are issued between the replays, outside any
+            # capture, and Adam runs per bucket as they land (parallel.DataParallel.finish) -- eager launches,
+            # one kernel per bucket
             pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(ga, pool=pool):
+            graphs = [torch.cuda.CUDAGraph()]
+            with torch.cuda.graph(graphs[0], pool=pool):
                 self._body_a()
-            with torch.cuda.graph(gb, pool=pool):
-                self._phase_b()
-            with torch.cuda.graph(gc, pool=pool):
-                optimizer.step()
-            self._graphs = (ga, gb, gc)
+            for part in self._phases_b():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    part()
+                graphs.append(g)
+            self._graphs = tuple(graphs)
+            self._optimizer = optimizer
         _restore(self.model, optimizer, self.counter, snap)   # warm-up steps must leave no trace
         torch.cuda.synchronize(dev)
         self.on_bucket_ready = hook
@@ -269,16 +292,13 @@ class _StepBase(object):
         self.static_image.copy_(image, non_blocking=True)
         self.static_label.copy_(label, non_blocking=True)
         self.set_coefficients(annealing_factor)
-        if len(self._graphs) == 1:
+        if self._comm is None:
             self._graphs[0].replay()
         else:
-            ga, gb, gc = self._graphs
-            ga.replay()
-            self._comm.launch(0)      # decoder bucket: RCCL runs behind phase B
-            gb.replay()
-            self._comm.launch(1)
-            self._comm.wait()
-            gc.replay()
+            for k, g in enumerate(self._graphs):
+                g.replay()
+                self._comm.launch(k)      # bucket k's all-reduce runs behind the next graph / the Adam launches
+            self._comm.finish(self._optimizer)
         return self.elbo
 
 
@@ -533,40 +553,62 @@ class BimodalStep(_StepBase):
         if self._comm is not None or self.on_bucket_ready is not None:
             self._join_wgrad()      # data parallel: the decoder bucket is all-reduced after phase A
 
-    def _phase_b(self):
+    def _phase_b(self, part='all'):
+        """PoE backward + encoders backward.  ``part``: 'all', or for a data-parallel replica with three
+        gradient buckets 'upper' (everything but the image encoder's first layers -- the arena tail) then
+        'lower' (those layers), so the second bucket's all-reduce starts before the last convs are done."""
         m, B, D = self.model, self.B, self.D
         c = self._carry
-        heads_img, heads_lbl = c['heads_img'], c['heads_lbl']
-        # ---- PoE backward -> encoder heads
-        g_heads_img = torch.empty_like(heads_img)
-        g_heads_lbl = torch.empty_like(heads_lbl)
-        g_list = ([g_heads_img[:B], g_heads_img[B:]] if self.has_dropout else [g_heads_img]) + [g_heads_lbl]
-        K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
-                  self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
-                  dkl_per_term=True)
-        # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
-        #      gradients spread over this stream and the two weight-gradient streams
-        wl, wi = self._deferred(), self._deferred()
-        with self._branch():
-            L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
-        if self.has_dropout:
-            d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True, deferred=wi)
-            d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
-            K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
-            L.backward_tape(self.trunk, c['tape_trunk'], d_h, deferred=wi)
+        if part in ('all', 'upper'):
+            heads_img, heads_lbl = c['heads_img'], c['heads_lbl']
+            # ---- PoE backward -> encoder heads
+            g_heads_img = torch.empty_like(heads_img)
+            g_heads_lbl = torch.empty_like(heads_lbl)
+            g_list = ([g_heads_img[:B], g_heads_img[B:]] if self.has_dropout else [g_heads_img]) + [g_heads_lbl]
+            K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
+                      self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
+                      dkl_per_term=True)
+            c['keep_b'] = (g_heads_img, g_heads_lbl)
+        if part == 'all':
+            # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
+            #      gradients spread over this stream and the two weight-gradient streams
+            wl, wi = self._deferred(), self._deferred()
+            with self._branch():
+                L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
+            if self.has_dropout:
+                d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True, deferred=wi)
+                d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
+                K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
+                L.backward_tape(self.trunk, c['tape_trunk'], d_h, deferred=wi)
+            else:
+                L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, deferred=wi)
+            self._join()
+            if wi is not None:
+                fns = wi + wl
+                n = len(fns)
+                self._launch_deferred(fns[:n // 3], self.wg_main)
+                self._launch_deferred(fns[n // 3:2 * n // 3], self.wg_side)
+                for fn in fns[2 * n // 3:]:
+                    fn()
+                c.setdefault('deferred', []).append(fns)
+            self._join_wgrad()
+            return
+        # ---- three buckets: the image encoder's stack is cut where the arena tail begins
+        plan, tape = (self.trunk, c['tape_trunk']) if self.has_dropout else (m.image_encoder.plan(), c['tape_img'])
+        cut = L.tail_cut(plan, m.arena_tail())
+        if part == 'upper':
+            with self._branch():
+                L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], c['keep_b'][1])
+            g = c['keep_b'][0]
+            if self.has_dropout:
+                d_hd = L.backward_tape(self.head, c['tape_head'], g, need_input_grad=True)
+                g = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
+                K.dropout_fanin_bwd(d_hd, self.drop_masks, g, 1.0 / KEEP)
+                c['keep_b'] += (d_hd,)
+            c['g_cut'] = L.backward_tape(plan[cut:], tape[cut:], g, need_input_grad=True)
+            self._join()
         else:
-            L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, deferred=wi)
-        self._join()
-        if wi is not None:
-            fns = wi + wl
-            n = len(fns)
-            self._launch_deferred(fns[:n // 3], self.wg_main)
-            self._launch_deferred(fns[n // 3:2 * n // 3], self.wg_side)
-            for fn in fns[2 * n // 3:]:
-                fn()
-            c.setdefault('deferred', []).append(fns)
-        self._join_wgrad()
-        c['keep_b'] = (g_heads_img, g_heads_lbl)
+            L.backward_tape(plan[:cut], tape[:cut], c['g_cut'])
 
 
 # =====================================================================================
@@ -859,25 +901,33 @@ class Celeba19Step(_StepBase):
                  keep=(z, kl, zcat, logits_attr, tape_dec, rows_attr, dlog_attr, dzcat, attrs, image,
                        rows_a, rows_c, dlog_a, dlog_c))
 
-    def _phase_b(self):
+    def _phase_b(self, part='all'):
         m, B, D, n_img = self.model, self.B, self.D, self.n_img
         c = self._carry
-        g_img = torch.empty_like(c['heads_img'])
-        g_attr_all = torch.empty(N_ATTRS, B, 2 * D, dtype=torch.float32, device=self.dev)
-        g_attr = [g_attr_all[i] for i in range(N_ATTRS)]
-        g_list = [g_img[k * B:(k + 1) * B] for k in range(n_img)] + g_attr
-        K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
-                  self.coef[2], [g[:, :D] for g in g_list], [g[:, D:] for g in g_list], m.POE_VARIANT,
-                  dkl_per_term=True)
-        with self._branch():
-            if self.grouped:
-                L.backward_tape_grouped(self.enc_group, c['tape_enc'], g_attr_all)
-            else:
-                for i in range(N_ATTRS):
-                    L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
-        d_hd = L.backward_tape(self.head, c['tape_head'], g_img, need_input_grad=True)
-        d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
-        K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
-        L.backward_tape(self.trunk, c['tape_trunk'], d_h)
-        self._join()
-        c['keep_b'] = (g_img, g_attr_all)
+        if part in ('all', 'upper'):
+            g_img = torch.empty_like(c['heads_img'])
+            g_attr_all = torch.empty(N_ATTRS, B, 2 * D, dtype=torch.float32, device=self.dev)
+            g_attr = [g_attr_all[i] for i in range(N_ATTRS)]
+            g_list = [g_img[k * B:(k + 1) * B] for k in range(n_img)] + g_attr
+            K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
+                      self.coef[2], [g[:, :D] for g in g_list], [g[:, D:] for g in g_list], m.POE_VARIANT,
+                      dkl_per_term=True)
+            with self._branch():
+                if self.grouped:
+                    L.backward_tape_grouped(self.enc_group, c['tape_enc'], g_attr_all)
+                else:
+                    for i in range(N_ATTRS):
+                        L.backward_tape(self.enc_plans[i], c['tape_enc'][i], g_attr[i])
+            d_hd = L.backward_tape(self.head, c['tape_head'], g_img, need_input_grad=True)
+            d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
+            K.dropout_fanin_bwd(d_hd, self.drop_masks, d_h, 1.0 / KEEP)
+            c['keep_b'] = (g_img, g_attr_all, d_hd, d_h)
+            if part == 'all':
+                L.backward_tape(self.trunk, c['tape_trunk'], d_h)
+            else:   # data parallel, three buckets: stop where the arena tail (the conv stack) begins
+                cut = L.tail_cut(self.trunk, m.arena_tail())
+                c['g_cut'] = L.backward_tape(self.trunk[cut:], c['tape_trunk'][cut:], d_h, need_input_grad=True)
+            self._join()
+        else:
+            cut = L.tail_cut(self.trunk, m.arena_tail())
+            L.backward_tape(self.trunk[:cut], c['tape_trunk'][:cut], c['g_cut'])

@@ -99,7 +99,10 @@ class MVAE(MVAEBase):
     label_decoder = property(lambda self: self.text_decoder)
 
     def arena_order(self):
-        return [self.image_decoder, self.text_decoder, self.image_encoder, self.text_encoder]
+        return [self.image_decoder, self.text_decoder, self.text_encoder, self.image_encoder]
+
+    def arena_tail(self):
+        return [self.image_encoder.features]
 
     def forward(self, image=None, text=None, eps=None):
         mu, logvar, z = self._infer(image, text, eps, want_z=True)

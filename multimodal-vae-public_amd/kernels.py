@@ -523,6 +523,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
           'mvae_adam_step')
 
 
+def adam_apply(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """Adam on (a range of) the arena at step *step_dev + 1, without advancing the counter."""
+    _need_gpu(param, grad, exp_avg, exp_avg_sq, step_dev); _f32c(param, grad, exp_avg, exp_avg_sq)
+    check(_lib.lib().mvae_adam_apply(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                     lr, beta1, beta2, eps, grad_scale, _ptr(step_dev), _stream()),
+          'mvae_adam_apply')
+
+
+def counter_add(counter_dev, delta):
+    _need_gpu(counter_dev)
+    check(_lib.lib().mvae_counter_add(_ptr(counter_dev), int(delta), _stream()), 'mvae_counter_add')
+
+
 def fill_(out, value):
     _need_gpu(out); _f32c(out)
     check(_lib.lib().mvae_fill(_ptr(out), out.numel(), float(value), _stream()), 'mvae_fill')

@@ -208,6 +208,24 @@ def plan_params(plan):
     return ps
 
 
+def tail_cut(plan, tail_modules):
+    """Index k such that plan[:k] holds exactly the ops of ``tail_modules`` (the first layers of a stack).
+    ``backward_tape(plan[k:], tape[k:], g, need_input_grad=True)`` followed by
+    ``backward_tape(plan[:k], tape[:k], that gradient)`` equals one pass over the whole plan: the upper
+    slice's first Linear / conv finds no producer and leaves the Swish' of plan[k-1] to the lower slice,
+    which applies it first (its last op is activated) -- one extra elementwise launch."""
+    ids = set(id(x) for mod in tail_modules for x in flatten_modules([mod]))
+    k = 0
+    for i, op in enumerate(plan):
+        if id(op.mod) in ids:
+            k = i + 1
+    if k == 0 or any(id(op.mod) not in ids and op.kind != 'view' for op in plan[:k]):
+        raise RuntimeError('the arena tail is not a prefix of the stack')
+    while k < len(plan) and plan[k].kind == 'view':      # a view between the slices belongs to the lower one
+        k += 1
+    return k
+
+
 def n_dropout(plan):
     return sum(1 for op in plan if op.drop > 0)
 

@@ -101,7 +101,10 @@ class MVAE(MVAEBase):
     label_decoder = property(lambda self: self.text_decoder)
 
     def arena_order(self):
-        return [self.image_decoder, self.text_decoder, self.image_encoder, self.text_encoder]
+        return [self.image_decoder, self.text_decoder, self.text_encoder, self.image_encoder]
+
+    def arena_tail(self):
+        return [self.image_encoder.fc1]
 
     def arena_adjacent(self):
         out = []

@@ -63,6 +63,22 @@ class FusedAdam(torch.optim.Optimizer):
                     g['betas'][1], g['eps'], self.grad_scale)
         self._host_step += 1
 
+    @torch.no_grad()
+    def step_range(self, lo, hi):
+        """Adam on arena elements [lo, hi) at the CURRENT step (counter not advanced): data-parallel
+        replicas call this per gradient bucket as its all-reduce lands, then ``advance()`` once."""
+        arena = self._arena
+        if arena is None or arena is not getattr(self.param_groups[0]['params'][0], '_arena', None):
+            self._bind()
+            arena = self._arena
+        g = self.param_groups[0]
+        K.adam_apply(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, g['lr'],
+                     g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+
+    def advance(self):
+        K.counter_add(self._step_dev, 1)
+        self._host_step += 1
+
     # torch.optim.Adam-compatible checkpoint layout
     def state_dict(self):
         if self._arena is not None:

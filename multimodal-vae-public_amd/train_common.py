@@ -276,11 +276,13 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
                     eng = ragged[len(image)] = build_engine(len(image))
                     eng.counter = engine.counter      # one Philox stream: never replay the main engine's draws
                     if dp is not None:
+                        eng.configure_buckets(dp.n_buckets)
                         eng.on_bucket_ready = dp.buckets.launch
                 elbo = eng.step(image, label, annealing_factor)
                 if dp is not None:
-                    dp.wait()
-                optimizer.step()
+                    dp.finish(optimizer)      # Adam per gradient bucket as its all-reduce lands
+                else:
+                    optimizer.step()
             elif not args.no_graph:
                 if not captured[0]:
                     engine.capture(optimizer, image.shape[1:], label, comm=dp)
@@ -289,8 +291,9 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
             else:
                 elbo = engine.step(image, label, annealing_factor)
                 if dp is not None:
-                    dp.wait()
-                optimizer.step()
+                    dp.finish(optimizer)      # Adam per gradient bucket as its all-reduce lands
+                else:
+                    optimizer.step()
             pending.append((elbo[-1].clone(), len(image)))
             if batch_idx % args.log_interval == 0:
                 # ONE device->host sync per log line

@@ -71,3 +71,61 @@ def test_bucket_ranges_must_tile_the_arena():
         GradBuckets(flat, [(0, 40), (50, 100)])
     with pytest.raises(ValueError):
         GradBuckets(flat, [(0, 40), (40, 90)])
+
+
+@pytest.mark.parametrize('kind,n_latents,n_buckets', [('mnist', 64, 2), ('fashionmnist', 64, 3), ('celeba', 100, 3),
+                                                      ('celeba19', 100, 3)])
+def test_bucket_plan_per_model(kind, n_latents, n_buckets):
+    """Buckets follow backward completion: decoders | encoders | the image encoder's first layers (arena tail,
+    laid out LAST so the final all-reduce is the smallest); MNIST's 4 MB of encoders stay one bucket."""
+    sys.path.insert(0, ROOT)
+    import mvae_amd
+    from mvae_amd.arena import ParamArena
+    from mvae_amd.parallel import GradBuckets, bucket_ranges
+    model = getattr(mvae_amd, kind).model.MVAE(n_latents)
+    arena = ParamArena(model, order=model.arena_order(), adjacent=model.arena_adjacent(), tail=model.arena_tail())
+    ranges = bucket_ranges(model, arena)
+    assert len(ranges) == n_buckets
+    GradBuckets(arena.grad, ranges)                     # tiles the arena, no gaps
+    tail_params = [p for m in model.arena_tail() for p in m.parameters()]
+    assert tail_params and arena.tail_range[1] == arena.numel
+    for p in tail_params:
+        assert arena.tail_range[0] <= p._arena_off and p._arena_off + p.numel() <= arena.numel
+    if n_buckets == 3:
+        assert ranges[2] == arena.tail_range
+        sizes = [hi - lo for lo, hi in ranges]
+        assert sizes[2] < sizes[1] and sizes[2] * 4 < (4 << 20)      # the exposed collective is a few MB at most
+    # every decoder parameter is in bucket 0, no encoder parameter is
+    for name, p in model.named_parameters():
+        in0 = ranges[0][0] <= p._arena_off < ranges[0][1]
+        assert in0 == ('decoder' in name), name
+
+
+def _finish_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mvae_amd.parallel import GradBuckets
+    flat = torch.full((90,), float(rank + 1))
+    b = GradBuckets(flat, [(0, 40), (40, 80), (80, 90)])
+    order = []
+    for k in range(3):
+        b.launch(k)
+    for k in range(3):                                  # per-bucket fences, in bucket order (DataParallel.finish)
+        b.wait(k)
+        order.append(float(flat[b.ranges[k][0]]))
+    assert not b.pending
+    with pytest.raises(RuntimeError):
+        b.launch(0); b.launch(0)
+    b.wait()
+    torch.save(order, os.path.join(out_dir, 'order%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_bucket_fences_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_finish_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(os.path.join(str(tmp_path), 'order%d.pt' % r)) == [3.0, 3.0, 3.0]
