@@ -165,6 +165,12 @@ int mvae_bn_eval_fwd(const float *x, const float *gamma, const float *beta, floa
  * ---------------------------------------------------------------------------------- */
 int mvae_swish_fwd(const float *x, float *y, size_t n, mvae_stream_t stream);
 int mvae_swish_bwd(const float *dy, const float *x, float *dx, size_t n, mvae_stream_t stream);
+/* sample.py (mnist/sample.py:100-112, celeba/sample.py): std = exp(logvar/2) comes from mvae_reparam_fwd with
+ * mu = 0, eps = 1; z = eps * std + mu for n_samples draws of ONE posterior row is the periodic affine map
+ * below (period = n_latents; 1 for the prior N(0,1)); F.sigmoid on the image decoder's logits. */
+int mvae_sigmoid_fwd(const float *x, float *y, size_t n, mvae_stream_t stream);
+int mvae_affine_fwd(const float *x, const float *scale, const float *shift, float *y, size_t n, size_t period,
+                    mvae_stream_t stream);
 int mvae_embedding_swish_fwd(const void *idx, int idx_is_float, const float *w, float *act,
                              int R, int n_classes, int width, mvae_stream_t stream);
 int mvae_embedding_swish_bwd(const void *idx, int idx_is_float, const float *w,
@@ -254,6 +260,23 @@ int mvae_ce_fwd(const float *logits, const int64_t *label, float *row,
 int mvae_ce_bwd(const float *logits, const int64_t *label, const float *drow_dev,
                 float *dlogits, int R, int K, int rows_per_group, int label_rows,
                 mvae_stream_t stream);
+/* The ELBO of a whole fused step in one launch (mnist/train.py:57-58 batch mean per term, :214 sum of terms;
+ * celeba19/train.py:59,265-302).  Each part is a vector of loss rows in `groups` groups of `rows_per_group`;
+ * group g feeds term `term_of[g]` (device table) or `first_term + g`:
+ *     elbo[t] = sum over parts and groups of term t of  coef[g] * sum(rows of g),   elbo[T] = sum over everything,
+ * accumulated part by part, group by group (fixed order).  Optionally clears `zero[0..zero_n)` (the latent
+ * gradient the decoders' first layers accumulate into) and advances a Philox launch counter by `counter_inc`
+ * -- the step's bookkeeping that would otherwise be 5-6 single-purpose launches. */
+#define MVAE_ELBO_MAX_PARTS 4
+#define MVAE_ELBO_MAX_TERMS 40
+typedef struct {
+    const float *rows;      /* [groups * rows_per_group] */
+    const float *coef;      /* per group, device; NULL = 1 */
+    const int *term_of;     /* per group, device; NULL = first_term + group */
+    int first_term, groups, rows_per_group;
+} mvae_elbo_part;
+int mvae_elbo_reduce(const mvae_elbo_part *parts, int n_parts, float *elbo, int T, float *zero, size_t zero_n,
+                     uint64_t *counter_dev, uint64_t counter_inc, mvae_stream_t stream);
 /* out[g] (+)= coef[g] * sum_{r in group g} rows[r] for g < G; *total_out (+)= sum_g of those
  * (either destination may be NULL) */
 int mvae_group_sums(const float *rows, const float *coef_dev, float *out, float *total_out,
@@ -269,6 +292,10 @@ int mvae_group_sums(const float *rows, const float *coef_dev, float *out, float 
 int mvae_randn(float *out, size_t n, uint64_t seed, uint64_t *counter_dev, mvae_stream_t stream);
 int mvae_bernoulli(float *out, size_t n, float keep_prob, uint64_t seed, uint64_t *counter_dev,
                    mvae_stream_t stream);
+/* the same draws at launch index *counter_dev + counter_offset WITHOUT advancing the counter (a fused step
+ * advances it once, in mvae_elbo_reduce) */
+int mvae_philox_fill(float *out, size_t n, int bernoulli, float keep_prob, uint64_t seed,
+                     const uint64_t *counter_dev, uint64_t counter_offset, mvae_stream_t stream);
 int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                    int64_t *step_dev, mvae_stream_t stream);

@@ -27,6 +27,14 @@ class Experts(ctypes.Structure):
     _fields_ = [('mu', c_void_p * MAX_EXPERTS), ('logvar', c_void_p * MAX_EXPERTS)]
 
 
+class ElboPart(ctypes.Structure):
+    _fields_ = [('rows', c_void_p), ('coef', c_void_p), ('term_of', c_void_p), ('first_term', c_int),
+                ('groups', c_int), ('rows_per_group', c_int)]
+
+
+ELBO_MAX_PARTS = 4
+
+
 class ExpertGrads(ctypes.Structure):
     _fields_ = [('dmu', c_void_p * MAX_EXPERTS), ('dlogvar', c_void_p * MAX_EXPERTS)]
 
@@ -56,6 +64,8 @@ _SIGNATURES = {
     'mvae_bn_eval_fwd': (c_int, [P] * 6 + [c_int] * 3 + [c_float, c_int, P]),
     'mvae_swish_fwd': (c_int, [P, P, c_size_t, P]),
     'mvae_swish_bwd': (c_int, [P, P, P, c_size_t, P]),
+    'mvae_sigmoid_fwd': (c_int, [P, P, c_size_t, P]),
+    'mvae_affine_fwd': (c_int, [P, P, P, P, c_size_t, c_size_t, P]),
     'mvae_embedding_swish_fwd': (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
     'mvae_embedding_swish_bwd': (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_embedding_swish_fwd_grouped': (c_int, [P, c_int, c_size_t, P, c_size_t, P, c_size_t, c_int, c_int, c_int,
@@ -77,6 +87,8 @@ _SIGNATURES = {
     'mvae_ce_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_ce_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
+    'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),
     'mvae_randn': (c_int, [P, c_size_t, c_uint64, P, P]),
     'mvae_bernoulli': (c_int, [P, c_size_t, c_float, c_uint64, P, P]),
     'mvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P, P]),

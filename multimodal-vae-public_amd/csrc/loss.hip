@@ -137,6 +137,56 @@ __global__ __launch_bounds__(1024) void group_sums_kernel(const float *rows, con
     if (threadIdx.x == 0 && total_out) *total_out = accumulate ? *total_out + total : total;
 }
 
+// ---- the ELBO of a fused step in ONE launch (mnist/train.py:57-58,214; celeba19/train.py:59,265-302) ----
+// elbo[t] = sum over the parts that feed term t of coef * (sum of the part's rows of that term); elbo[T] = the
+// step's total, added up part by part in the order given (the order the separate group-sum launches had).
+// Block 0 does the sums and advances the step's Philox counter; every block helps clear `zero` (the shared
+// latent-gradient buffer the decoders' first layers accumulate into).
+struct ElboParts { mvae_elbo_part p[MVAE_ELBO_MAX_PARTS]; int n; };
+
+__global__ __launch_bounds__(1024) void elbo_reduce_kernel(ElboParts parts, float *elbo, int T, float *zero, size_t zero_n,
+                                                           uint64_t *counter, uint64_t counter_inc) {
+    const size_t zstride = (size_t)gridDim.x * 1024;
+    if (zero) {
+        const size_t z4 = aligned16_dev(zero) ? zero_n / 4 : 0;
+        for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < z4; i += zstride)
+            reinterpret_cast<float4 *>(zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = z4 * 4 + (size_t)blockIdx.x * 1024 + threadIdx.x; i < zero_n; i += zstride) zero[i] = 0.f;
+    }
+    if (blockIdx.x != 0) return;
+    __shared__ float red[16];
+    __shared__ float acc[MVAE_ELBO_MAX_TERMS + 1];
+    for (int t = threadIdx.x; t <= T; t += 1024) acc[t] = 0.f;
+    __syncthreads();
+    for (int q = 0; q < parts.n; ++q) {
+        const mvae_elbo_part &p = parts.p[q];
+        float part_total = 0.f;
+        if (p.rows_per_group == 1) {        // a table of ready sums (celeba19's attribute terms): sequential, in order
+            if (threadIdx.x == 0) {
+                for (int g = 0; g < p.groups; ++g) {
+                    const float v = (p.coef ? p.coef[g] : 1.f) * p.rows[g];
+                    acc[p.term_of ? p.term_of[g] : p.first_term + g] += v;
+                    part_total += v;
+                }
+                acc[T] += part_total;
+            }
+            __syncthreads();
+            continue;
+        }
+        for (int g = 0; g < p.groups; ++g) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < p.rows_per_group; i += 1024) s += p.rows[(size_t)g * p.rows_per_group + i];
+            s = block_sum(s, red) * (p.coef ? p.coef[g] : 1.f);
+            if (threadIdx.x == 0) acc[p.term_of ? p.term_of[g] : p.first_term + g] += s;
+            part_total += s;
+        }
+        if (threadIdx.x == 0) acc[T] += part_total;
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t <= T; t += 1024) elbo[t] = acc[t];
+    if (threadIdx.x == 0 && counter) *counter += counter_inc;
+}
+
 int bce_launch(BceArgs a, hipStream_t st) {
     if (!a.logits || !a.target || a.R <= 0 || a.P <= 0 || a.rows_per_group <= 0 || a.target_rows <= 0 ||
         a.target_div <= 0 || a.t_cs <= 0 || a.t_rs <= 0)
@@ -190,6 +240,25 @@ MVAE_EXPORT int mvae_ce_bwd(const float *logits, const int64_t *label, const flo
         return MVAE_ERR_ARG;
     hipLaunchKernelGGL(ce_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, label,
                        drow_dev, (float *)nullptr, dlogits, R, K, rows_per_group, label_rows);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_elbo_reduce(const mvae_elbo_part *parts, int n_parts, float *elbo, int T, float *zero,
+                                 size_t zero_n, uint64_t *counter_dev, uint64_t counter_inc, mvae_stream_t stream) {
+    if (!parts || n_parts <= 0 || n_parts > MVAE_ELBO_MAX_PARTS || !elbo || T <= 0 || T > MVAE_ELBO_MAX_TERMS)
+        return MVAE_ERR_ARG;
+    ElboParts ps;
+    ps.n = n_parts;
+    for (int q = 0; q < n_parts; ++q) {
+        ps.p[q] = parts[q];
+        if (!ps.p[q].rows || ps.p[q].groups <= 0 || ps.p[q].rows_per_group <= 0) return MVAE_ERR_ARG;
+        if (!ps.p[q].term_of && (ps.p[q].first_term < 0 || ps.p[q].first_term + ps.p[q].groups > T)) return MVAE_ERR_ARG;
+    }
+    size_t blocks = zero ? (zero_n / 4 + 1023) / 1024 : 1;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(elbo_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, ps, elbo, T, zero,
+                       zero ? zero_n : 0, counter_dev, counter_inc);
     return mvae_launch_status();
 }
 

@@ -16,6 +16,20 @@ __global__ __launch_bounds__(256) void swish_fwd_kernel(const float *x, float *y
         y[i] = swishf_(x[i]);
 }
 
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float *x, float *y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = sigmoidf_(x[i]);
+}
+
+// y[i] = x[i] * scale[i % period] + shift[i % period]
+__global__ __launch_bounds__(256) void affine_fwd_kernel(const float *x, const float *scale, const float *shift, float *y,
+                                                         size_t n, size_t period) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t j = i % period;
+        y[i] = x[i] * scale[j] + shift[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void swish_bwd_kernel(const float *dy, const float *x, float *dx, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         dx[i] = dy[i] * swish_grad_(x[i]);
@@ -105,8 +119,9 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 
 // mode 0: standard normal (Box-Muller on pairs), mode 1: Bernoulli(keep) in {0,1}
 __global__ __launch_bounds__(256) void philox_fill_kernel(float *out, size_t n, uint64_t seed,
-                                                          const uint64_t *counter, int mode, float keep) {
-    const uint64_t launch = *counter;
+                                                          const uint64_t *counter, int mode, float keep,
+                                                          uint64_t counter_offset = 0) {
+    const uint64_t launch = *counter + counter_offset;
     const size_t groups = (n + 3) / 4;
     for (size_t gidx = (size_t)blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += (size_t)gridDim.x * 256) {
         uint32_t r[4];
@@ -191,6 +206,22 @@ MVAE_EXPORT int mvae_swish_fwd(const float *x, float *y, size_t n, mvae_stream_t
     return mvae_launch_status();
 }
 
+MVAE_EXPORT int mvae_sigmoid_fwd(const float *x, float *y, size_t n, mvae_stream_t stream) {
+    if (!x || !y) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_affine_fwd(const float *x, const float *scale, const float *shift, float *y, size_t n,
+                                size_t period, mvae_stream_t stream) {
+    if (!x || !scale || !shift || !y || period == 0) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(affine_fwd_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
+                       n, period);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_swish_bwd(const float *dy, const float *x, float *dx, size_t n, mvae_stream_t stream) {
     if (!dy || !x || !dx) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
@@ -248,8 +279,20 @@ static int philox_launch(float *out, size_t n, uint64_t seed, uint64_t *counter_
     if (n == 0) return MVAE_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(philox_fill_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, st, out, n, seed,
-                       (const uint64_t *)counter_dev, mode, keep);
+                       (const uint64_t *)counter_dev, mode, keep, (uint64_t)0);
     hipLaunchKernelGGL(bump_u64_kernel, dim3(1), dim3(1), 0, st, counter_dev);
+    return mvae_launch_status();
+}
+
+// The same draws without the counter bump: launch index = *counter_dev + counter_offset.  A fused step draws
+// its noise tensors at offsets 0, 1, ... and advances the counter once (mvae_elbo_reduce), so a step costs
+// no single-thread bump launches.
+MVAE_EXPORT int mvae_philox_fill(float *out, size_t n, int bernoulli, float keep_prob, uint64_t seed,
+                                 const uint64_t *counter_dev, uint64_t counter_offset, mvae_stream_t stream) {
+    if (!out || !counter_dev) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       seed, counter_dev, bernoulli ? 1 : 0, keep_prob, counter_offset);
     return mvae_launch_status();
 }
 

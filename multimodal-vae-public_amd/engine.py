@@ -455,9 +455,10 @@ class BimodalStep(_StepBase):
             self.drop_masks[1].copy_(noise['mask'][1].to(self.dev))
 
     def draw_noise(self):
-        K.randn_(self.noise, self.seed, self.counter)
+        # launch indices counter + 0 / + 1; the counter itself advances once per step (phase A's bookkeeping)
+        K.philox_fill(self.noise, self.seed, self.counter, 0)
         if self.has_dropout:
-            K.bernoulli_(self.drop_masks, KEEP, self.seed ^ 0x9E3779B97F4A7C15, self.counter)
+            K.philox_fill(self.drop_masks, self.seed ^ 0x9E3779B97F4A7C15, self.counter, 1, keep_prob=KEEP)
 
     def terms_in_reference_order(self, elbo):
         """elbo[T+1] (engine order) -> [joint, image, label] + [total]."""
@@ -537,14 +538,14 @@ class BimodalStep(_StepBase):
             self._launch_deferred(wi, self.wg_main)     # decoder weight gradients run behind phase B
             self._join()
             keep_dec = (logits_lbl, tape_dl, dlog_lbl, logits_img, tape_di, dlog_img)
-        # ---- ELBO per term and total (mnist/train.py:57-58,214)
-        elbo = self.elbo
-        K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
-        K.group_sums(rows_img, self.coef[0, i0:i0 + ni], elbo[i0:i0 + ni], elbo[T:], ni, B, accumulate=True)
-        K.group_sums(rows_lbl, self.coef[1, l0:l0 + nl], elbo[l0:l0 + nl], elbo[T:], nl, B, accumulate=True)
-        # ---- both decoders' first layers -> the shared dz
+        # ---- ELBO per term and total (mnist/train.py:57-58,214), the cleared dz and the step's Philox counter
+        #      advance: one bookkeeping launch
         dz = torch.empty(T, B, D, dtype=torch.float32, device=self.dev)
-        K.fill_(dz, 0.0)
+        K.elbo_reduce([(kl, self.coef[2], None, 0, T, B),
+                       (rows_img, self.coef[0, i0:i0 + ni], None, i0, ni, B),
+                       (rows_lbl, self.coef[1, l0:l0 + nl], None, l0, nl, B)], self.elbo, T, zero=dz,
+                      counter_dev=self.counter, counter_inc=2 if self.has_dropout else 1)
+        # ---- both decoders' first layers -> the shared dz
         L.first_linear_dgrad(m.image_decoder.plan(), g_img, dz[i0:i0 + ni].reshape(ni * B, D), True)
         L.first_linear_dgrad(m.label_decoder.plan(), g_lbl, dz[l0:l0 + nl].reshape(nl * B, D), True)
         # everything a branch allocated stays referenced until the next step's first fork
@@ -780,8 +781,8 @@ class Celeba19Step(_StepBase):
                 self.drop_masks[k].fill_(1.0)      # expert masked out of the PoE: value irrelevant
 
     def draw_noise(self):
-        K.randn_(self.noise, self.seed, self.counter)
-        K.bernoulli_(self.drop_masks, KEEP, self.seed ^ 0x9E3779B97F4A7C15, self.counter)
+        K.philox_fill(self.noise, self.seed, self.counter, 0)
+        K.philox_fill(self.drop_masks, self.seed ^ 0x9E3779B97F4A7C15, self.counter, 1, keep_prob=KEEP)
 
     def step(self, image, attrs, annealing_factor, noise=None, combos=None):
         self.set_terms(combos if combos is not None else sample_subsets(self.rng, 1 + N_ATTRS, self.M), commit=False)
@@ -890,13 +891,12 @@ class Celeba19Step(_StepBase):
                             input_grad_out=dz[t_s:T].reshape(M * B, D), input_grad_accumulate=True)
         self._join()
         K.block_scatter_add(dzcat, self.term_of_slot, dz, T, B * D)
-        # ---- ELBO per term and total (celeba19/train.py:59,265-302)
-        elbo = self.elbo
-        K.group_sums(kl, self.coef[2], elbo[:T], elbo[T:], T, B, accumulate=False)
-        K.group_sums(rows_a, self.coef[0, 0:2], elbo[0:2], elbo[T:], 2, B, accumulate=True)
+        # ---- ELBO per term and total (celeba19/train.py:59,265-302) + the Philox counter advance: one launch
+        parts = [(kl, self.coef[2], None, 0, T, B), (rows_a, self.coef[0, 0:2], None, 0, 2, B)]
         if M > 0:
-            K.group_sums(rows_c, self.coef[0, t_s:T], elbo[t_s:T], elbo[T:], M, B, accumulate=True)
-        K.scatter_sums(rows_attr, self.coef_attr, self.term_of_slot, elbo[:T], elbo[T:], accumulate_total=True)
+            parts.append((rows_c, self.coef[0, t_s:T], None, t_s, M, B))
+        parts.append((rows_attr, self.coef_attr, self.term_of_slot, 0, N_ATTRS * S, 1))
+        K.elbo_reduce(parts, self.elbo, T, counter_dev=self.counter, counter_inc=2)
         c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_attr=heads_attr,
                  keep=(z, kl, zcat, logits_attr, tape_dec, rows_attr, dlog_attr, dzcat, attrs, image,
                        rows_a, rows_c, dlog_a, dlog_c))

@@ -334,6 +334,27 @@ def bn_eval_fwd(x, gamma, beta, y, running_mean, running_var, eps=1e-5, swish=Tr
 
 
 # ---------------------------------------------------------------------------- elementwise / embedding
+def reparam_fwd(mu, logvar, eps, z):
+    """z = eps * exp(logvar / 2) + mu (mnist/model.py:29-35), elementwise."""
+    _need_gpu(mu, logvar, eps, z); _f32c(mu, logvar, eps, z)
+    check(_lib.lib().mvae_reparam_fwd(_ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream()),
+          'mvae_reparam_fwd')
+
+
+def sigmoid_fwd(x, y):
+    _need_gpu(x, y); _f32c(x, y)
+    check(_lib.lib().mvae_sigmoid_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), 'mvae_sigmoid_fwd')
+
+
+def affine_fwd(x, scale, shift, y):
+    """y = x * scale + shift with scale / shift of ``period`` = scale.numel() elements repeated along x."""
+    _need_gpu(x, scale, shift, y); _f32c(x, scale, shift, y)
+    if scale.numel() != shift.numel() or x.numel() % scale.numel():
+        raise RuntimeError('affine_fwd: scale/shift must have equal sizes dividing x')
+    check(_lib.lib().mvae_affine_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), x.numel(), scale.numel(),
+                                     _stream()), 'mvae_affine_fwd')
+
+
 def swish_fwd(x, y):
     _need_gpu(x, y); _f32c(x, y)
     check(_lib.lib().mvae_swish_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), 'mvae_swish_fwd')
@@ -503,7 +524,34 @@ def group_sums(rows, coef, out, total, G, rows_per_group, accumulate=False):
                                      ACCUMULATE if accumulate else 0, _stream()), 'mvae_group_sums')
 
 
+def elbo_reduce(parts, elbo, T, zero=None, counter_dev=None, counter_inc=0):
+    """parts: [(rows, coef or None, term_of or None, first_term, groups, rows_per_group)] -- see
+    mvae_elbo_reduce in include/mvae_hip.h.  Overwrites elbo[0..T]."""
+    if not 0 < len(parts) <= _lib.ELBO_MAX_PARTS:
+        raise RuntimeError('1..%d ELBO parts per launch' % _lib.ELBO_MAX_PARTS)
+    arr = (_lib.ElboPart * len(parts))()
+    for q, (rows, coef, term_of, first, groups, rpg) in enumerate(parts):
+        _need_gpu(rows, coef, term_of); _f32c(rows, coef)
+        if rows.numel() < groups * rpg:
+            raise RuntimeError('ELBO part %d: %d values for %d x %d' % (q, rows.numel(), groups, rpg))
+        arr[q] = _lib.ElboPart(_ptr(rows), _ptr(coef), _ptr(term_of), int(first), int(groups), int(rpg))
+    _need_gpu(elbo, zero, counter_dev); _f32c(elbo, zero)
+    check(_lib.lib().mvae_elbo_reduce(arr, len(parts), _ptr(elbo), int(T), _ptr(zero),
+                                      0 if zero is None else zero.numel(), _ptr(counter_dev), int(counter_inc),
+                                      _stream()), 'mvae_elbo_reduce')
+
+
 # ---------------------------------------------------------------------------- noise / optimiser
+def philox_fill(out, seed, counter_dev, offset=0, keep_prob=None):
+    """Standard normal (keep_prob None) or Bernoulli(keep_prob) draws at launch index *counter_dev + offset;
+    the counter is NOT advanced (the fused step does that once per step in elbo_reduce)."""
+    _need_gpu(out, counter_dev); _f32c(out)
+    check(_lib.lib().mvae_philox_fill(_ptr(out), out.numel(), 0 if keep_prob is None else 1,
+                                      0.0 if keep_prob is None else float(keep_prob), seed, _ptr(counter_dev),
+                                      int(offset), _stream()), 'mvae_philox_fill')
+
+
+
 def randn_(out, seed, counter_dev):
     _need_gpu(out, counter_dev); _f32c(out)
     check(_lib.lib().mvae_randn(_ptr(out), out.numel(), seed, _ptr(counter_dev), _stream()), 'mvae_randn')

@@ -21,6 +21,8 @@ import zlib
 import numpy as np
 import torch
 
+from . import kernels as K
+
 # the 18 attributes celeba/datasets.py:34 keeps, in column order (names from the CelebA annotation
 # header; indices 4,5,8,9,11,12,15,17,18,20,21,22,26,28,31,32,33,35 of the 40)
 CELEBA_ATTRS = ['Bald', 'Bangs', 'Black_Hair', 'Blond_Hair', 'Brown_Hair', 'Bushy_Eyebrows', 'Eyeglasses',
@@ -80,7 +82,11 @@ def posterior(model, image=None, label=None):
             mu, logvar = model.infer(image=image, attrs=label)
         else:
             mu, logvar = model.infer(image=image, text=label)
-    return mu, logvar.mul(0.5).exp_()
+    # std = exp(logvar / 2) (mnist/sample.py:100): the reparameterisation kernel at mu = 0, eps = 1
+    mu, logvar = mu.contiguous(), logvar.contiguous()
+    std = torch.empty_like(logvar)
+    K.reparam_fwd(torch.zeros_like(logvar), logvar, torch.ones_like(logvar), std)
+    return mu, std
 
 
 def generate(model, n_samples, mu, std, eps=None):
@@ -89,9 +95,13 @@ def generate(model, n_samples, mu, std, eps=None):
     dev = next(model.parameters()).device
     if eps is None:
         eps = torch.randn(n_samples, model.n_latents)
-    z = eps.to(dev) * std.expand(n_samples, model.n_latents) + mu.expand(n_samples, model.n_latents)
+    eps = eps.to(dev).float().contiguous()
+    z = torch.empty_like(eps)
+    K.affine_fwd(eps, std.reshape(-1).contiguous(), mu.reshape(-1).contiguous(), z)     # one posterior row, n draws
     with torch.no_grad():
-        img = torch.sigmoid(model.image_decoder(z))
+        logits = model.image_decoder(z).contiguous()
+        img = torch.empty_like(logits)
+        K.sigmoid_fwd(logits, img)                                                     # F.sigmoid, mnist/sample.py:111
         lbl = model.label_decoder(z)
     return z, img, lbl
 

@@ -513,3 +513,75 @@ def test_fused_adam_matches_torch_adam():
     assert_close(p, pr.detach(), 'adam params', tol=1e-6)
     assert_close(m, opt.state[pr]['exp_avg'], 'adam m', tol=1e-6)
     assert_close(v, opt.state[pr]['exp_avg_sq'], 'adam v', tol=1e-6)
+
+
+def test_adam_apply_over_ranges_equals_one_step():
+    """Data-parallel replicas run Adam per gradient bucket (mvae_adam_apply: no counter advance) and advance
+    the step once: identical to one mvae_adam_step over the whole arena."""
+    n = 10008
+    p0, m0, v0, gr = g(n, seed=120), g(n, seed=121).abs() * 0.1, g(n, seed=122).abs() * 0.1, g(n, seed=123)
+    step_a = torch.full((1,), 3, dtype=torch.int64, device=DEV); step_b = step_a.clone()
+    pa, ma, va = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    pb, mb, vb = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    K.adam_step(pa, dev(gr), ma, va, step_a, 1e-3, grad_scale=0.5)
+    gd = dev(gr)
+    for lo, hi in ((0, 4000), (4000, 9000), (9000, n)):
+        K.adam_apply(pb[lo:hi], gd[lo:hi], mb[lo:hi], vb[lo:hi], step_b, 1e-3, grad_scale=0.5)
+    assert step_b.item() == 3
+    K.counter_add(step_b, 1)
+    assert step_b.item() == step_a.item() == 4
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+def test_philox_fill_matches_the_bumping_entry_points():
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    a = torch.empty(4099, device=DEV); m = torch.empty(4099, device=DEV)
+    K.randn_(a, 77, ctr); K.bernoulli_(m, 0.9, 78, ctr)          # launch indices 0 and 1, counter -> 2
+    ctr2 = torch.zeros(1, dtype=torch.int64, device=DEV)
+    a2 = torch.empty_like(a); m2 = torch.empty_like(m)
+    K.philox_fill(a2, 77, ctr2, 0)
+    K.philox_fill(m2, 78, ctr2, 1, keep_prob=0.9)
+    assert ctr2.item() == 0 and torch.equal(a, a2) and torch.equal(m, m2)
+
+
+def test_elbo_reduce_equals_the_separate_launches():
+    T, B = 5, 37
+    kl, ri, rl = g(T * B, seed=130), g(2 * B, seed=131), g(3 * B, seed=132)
+    ck, ci, cl = torch.rand(T), torch.rand(2), torch.rand(3)
+    vals, cv = g(9, seed=133), torch.rand(9)
+    term_of = torch.tensor([0, 4, 4, 1, 2, 0, 3, 3, 1], dtype=torch.int32)
+    # the separate launches the fused step used to issue
+    out = torch.zeros(T + 1, device=DEV)
+    K.group_sums(dev(kl), dev(ck), out[:T], out[T:], T, B, accumulate=False)
+    K.group_sums(dev(ri), dev(ci), out[1:3], out[T:], 2, B, accumulate=True)
+    K.group_sums(dev(rl), dev(cl), out[2:5], out[T:], 3, B, accumulate=True)
+    K.scatter_sums(dev(vals), dev(cv), dev(term_of), out[:T], out[T:], accumulate_total=True)
+    fused = torch.full((T + 1,), 7.0, device=DEV)
+    zero = torch.full((4099,), 3.0, device=DEV)
+    ctr = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+    K.elbo_reduce([(dev(kl), dev(ck), None, 0, T, B), (dev(ri), dev(ci), None, 1, 2, B), (dev(rl), dev(cl), None, 2, 3, B),
+                   (dev(vals), dev(cv), dev(term_of), 0, 9, 1)], fused, T, zero=zero, counter_dev=ctr, counter_inc=2)
+    assert_close(fused, out, 'fused ELBO vs separate launches', tol=1e-6)
+    ref = torch.zeros(T + 1, dtype=torch.float64)
+    ref[:T] += (kl.double().reshape(T, B).sum(1) * ck.double())
+    ref[1:3] += ri.double().reshape(2, B).sum(1) * ci.double()
+    ref[2:5] += rl.double().reshape(3, B).sum(1) * cl.double()
+    for j in range(9):
+        ref[term_of[j]] += cv[j].double() * vals[j].double()
+    ref[T] = ref[:T].sum()
+    assert_close(fused, ref, 'fused ELBO vs fp64', tol=1e-5)
+    assert zero.abs().max().item() == 0 and ctr.item() == 7
+    with pytest.raises(RuntimeError):
+        K.elbo_reduce([(dev(kl), dev(ck), None, 3, T, B)], fused, T)          # terms 3..7 do not fit T = 5
+
+
+def test_sigmoid_and_affine():
+    x = g(3, 17, seed=140)
+    y = torch.empty(3, 17, device=DEV)
+    K.sigmoid_fwd(dev(x), y)
+    assert_close(y, torch.sigmoid(x), 'sigmoid', tol=1e-6)
+    sc, sh = g(17, seed=141), g(17, seed=142)
+    K.affine_fwd(dev(x), dev(sc), dev(sh), y)
+    assert_close(y, x * sc + sh, 'affine (row broadcast)', tol=1e-6)
+    K.affine_fwd(dev(x), torch.ones(1, device=DEV), torch.zeros(1, device=DEV), y)
+    assert torch.equal(y.cpu(), x)
