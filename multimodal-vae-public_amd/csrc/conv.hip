@@ -2,6 +2,12 @@
 // kernel of gemm_core.h: the gather loaders, the three special-shape kernels and the C ABI.
 #include "gemm_core.h"
 
+// k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
+// tap fields for 32)
+#ifndef MVAE_CONV_BK
+#define MVAE_CONV_BK 32
+#endif
+
 namespace {
 
 // Geometry of a 4x4 convolution y[B,Cout,OH,OW] = conv(x[B,Cin,H,W], w[Cout,Cin,4,4]).
@@ -19,10 +25,10 @@ struct ConvGeom {
 // against 1024 MFMA cycles.)
 
 // im2col of x for the forward conv: element (k = (ci,kh,kw), m = (b,oh,ow)); lanes along m.
-template <int TILE_>
-struct LdIm2col {
-    static constexpr int TILE = TILE_, BKV = BK;
-    static constexpr int NV = TILE * BK / NTHREADS;   // elements per thread
+template <int TILE_, int BKV_ = MVAE_CONV_BK>
+struct LdIm2colT {
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int NV = TILE * BKV / NTHREADS;  // elements per thread
     static constexpr int KSTEP = NTHREADS / TILE;     // 2 or 4: k rows covered per pass
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int Mtot;
@@ -64,7 +70,7 @@ struct LdIm2col {
         rg.ok = okbits;
     }
     static constexpr bool RMAJOR = false;
-    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    static constexpr int ROWS = BKV, PITCH = TILE + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
     __device__ void store(Tile L, int t, const Regs &rg) const {
@@ -74,14 +80,16 @@ struct LdIm2col {
     }
 };
 
+template <int T> using LdIm2col = LdIm2colT<T>;
+
 // Transposed-conv (dgrad) gather of dy for the output parity class `cls` = (ph,pw) of dx:
 // element (k = (co,a,b), m = (n, ih', iw')) with ih = ih'*s + ph, kh = kh0 + s*a,
 // oh = (ih + pad - kh0)/s - a.  TPD = 4/s taps per dim (TLOG = log2 TPD); only the taps that can
 // reach the class are enumerated, so stride 2 does no multiply-by-zero work.
-template <int TILE_, int TLOG>
+template <int TILE_, int TLOG, int BKV_ = MVAE_CONV_BK>
 struct LdDgradDyT {
-    static constexpr int TILE = TILE_, BKV = BK;
-    static constexpr int NV = TILE * BK / NTHREADS;
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int NV = TILE * BKV / NTHREADS;
     static constexpr int KSTEP = NTHREADS / TILE;
     static constexpr int TMASK = (1 << TLOG) - 1;
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
@@ -128,7 +136,7 @@ struct LdDgradDyT {
         rg.ok = okbits;
     }
     static constexpr bool RMAJOR = false;
-    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    static constexpr int ROWS = BKV, PITCH = TILE + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
     __device__ void store(Tile L, int t, const Regs &rg) const {
@@ -139,6 +147,11 @@ struct LdDgradDyT {
 };
 template <int TILE_> using LdDgradDyS2 = LdDgradDyT<TILE_, 1>;   // stride 2: 2x2 taps per class
 template <int TILE_> using LdDgradDyS1 = LdDgradDyT<TILE_, 2>;   // stride 1: all 4x4 taps
+// the weight-side loaders of those two forms at the same k-tile depth
+template <int T> using LdRowsKC = LdRowsKT<T, true, MVAE_CONV_BK>;
+template <int T> using LdRowsKSC = LdRowsKT<T, false, MVAE_CONV_BK>;
+template <int T> using LdRowsMNC = LdRowsMNT<T, true, MVAE_CONV_BK>;
+template <int T> using LdRowsMNSC = LdRowsMNT<T, false, MVAE_CONV_BK>;
 
 // wgrad operands: the reduction runs over k = (b,oh,ow); lanes along k (spatially contiguous).
 // P: element (i = co, k) = dy[b][co][oh][ow].
@@ -278,8 +291,8 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
     if (aligned16(w))
-        return launch_igemm<LdRowsK, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
-    return launch_igemm<LdRowsKS, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+        return launch_igemm<LdRowsKC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
+    return launch_igemm<LdRowsKSC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
 }
 
 // ---- direct transposed conv for <= 4 OUTPUT channels (ConvTranspose2d(32,3) / (64,1), stride 2,
@@ -516,11 +529,11 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     SplitSink sink = make_sink(nullptr, I, J, false);
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
     if (vec) {
-        if (s == 2) return launch_igemm<LdRowsMN, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
-        return launch_igemm<LdRowsMN, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+        if (s == 2) return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+        return launch_igemm<LdRowsMNC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
     }
-    if (s == 2) return launch_igemm<LdRowsMNS, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
-    return launch_igemm<LdRowsMNS, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    if (s == 2) return launch_igemm<LdRowsMNSC, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
+    return launch_igemm<LdRowsMNSC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
 // ---- weight gradient of the <= 4-input-channel convs (Conv2d(3,32) / ConvTranspose2d(32,3) of CelebA,

@@ -39,6 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Tuning overrides exist only in the -DMVAE_TUNING build (libmvae_hip_tuning.so, used by tools/gemm_bench.py);
 // the product library has no mutable global state: MVAE_TUNE(x) folds to 0.
+#ifndef MVAE_SETPRIO
+#define MVAE_SETPRIO 0          // 1: raise the wave priority around each MFMA group (measured: see DESIGN.md)
+#endif
 #ifdef MVAE_TUNING
 struct MvaeTune { int wm, wn, splits, kw, small_off, small_waves; long split_target; int knockout; };
 extern MvaeTune g_mvae_tune;      // defined in linear.hip
@@ -303,9 +306,9 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     typedef typename P::Tile PTile;
     typedef typename Q::Tile QTile;
     constexpr int P_FLOATS = P::ROWS * P::PITCH, Q_FLOATS = Q::ROWS * Q::PITCH;
-    PTile Ps[2] = {reinterpret_cast<PTile>(lds_raw), reinterpret_cast<PTile>(lds_raw + P_FLOATS)};
-    float *qbase = lds_raw + 2 * P_FLOATS;
-    QTile Qs[2] = {reinterpret_cast<QTile>(qbase), reinterpret_cast<QTile>(qbase + Q_FLOATS)};
+    // buffer b of the two-stage LDS ring (computed, not tabulated: b is a run-time value in the 2 x 2 path)
+    auto Ps = [&](int b) { return reinterpret_cast<PTile>(lds_raw + b * P_FLOATS); };
+    auto Qs = [&](int b) { return reinterpret_cast<QTile>(lds_raw + 2 * P_FLOATS + b * Q_FLOATS); };
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kg = wave / WPG, wq = wave % WPG;     // k-group of this wave, its slot inside the group
@@ -343,55 +346,98 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         if (ROWSUM) {
             if (rs_block && mover) {
 #pragma unroll
-                for (int kk = 0; kk < BKK / RS_PARTS; ++kk) rsum += Ps[buf][kk * RS_PARTS + rs_part][rs_row];
+                for (int kk = 0; kk < BKK / RS_PARTS; ++kk) rsum += Ps(buf)[kk * RS_PARTS + rs_part][rs_row];
             }
         }
         // A k-tile is cut into chunks of 8 k's; k-group kg takes chunks kg, kg + KW, ...  Within a chunk
         // lanes 0-31 hold k = 8c + j and lanes 32-63 k = 8c + 4 + j for the j-th of its 4 MFMAs (each
         // 32x32x2 MFMA sums two k's; which two is free as long as both operands agree), so a row-major
-        // operand tile feeds 4 MFMAs with ONE ds_read_b128 per lane.  The reads of chunk ch+1 are issued
-        // before the MFMAs of chunk ch: the LDS latency hides behind 64-cycle matrix instructions.
-        constexpr int NCH = BKK / 8 / KW;
-        float4 a0[WM], b0[WN];
+        // operand tile feeds 4 MFMAs with ONE ds_read_b128 per lane (fetched a whole chunk ahead); a k-major
+        // tile is read one value per MFMA, one MFMA ahead (4 + 4 live registers at 2 x 2 tiles per wave --
+        // whole-chunk prefetch of both operands spilled the 128 x 128 kernels).  Either way the LDS latency
+        // hides behind the 64-cycle matrix instructions.
+        constexpr int NCH = BKK / 8 / KW, NS = NCH * 4;
+        auto krow = [&](int st) { return ((st >> 2) * KW + kg) * 8 + 4 * lrow + (st & 3); };   // tile row of step st
+        float4 pa[WM], pa_n[WM], qb[WN], qb_n[WN];      // row-major operands: this chunk's / the next chunk's 4 k's
+        float sa[WM], sa_n[WM], sb[WN], sb_n[WN];       // k-major operands: this step's / the next step's value
 #pragma unroll
-        for (int x = 0; x < WM; ++x) a0[x] = P::frag(Ps[buf], kg * 8 + 4 * lrow, (wi * WM + x) * 32 + lcol);
+        for (int x = 0; x < WM; ++x) {
+            if (P::RMAJOR) pa[x] = P::frag(Ps(buf), krow(0), (wi * WM + x) * 32 + lcol);
+            else sa[x] = Ps(buf)[krow(0)][(wi * WM + x) * 32 + lcol];
+        }
 #pragma unroll
-        for (int y = 0; y < WN; ++y) b0[y] = Q::frag(Qs[buf], kg * 8 + 4 * lrow, (wj * WN + y) * 32 + lcol);
+        for (int y = 0; y < WN; ++y) {
+            if (Q::RMAJOR) qb[y] = Q::frag(Qs(buf), krow(0), (wj * WN + y) * 32 + lcol);
+            else sb[y] = Qs(buf)[krow(0)][(wj * WN + y) * 32 + lcol];
+        }
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            float4 a1[WM], b1[WN];
-            if (ch + 1 < NCH) {
-                const int k0 = ((ch + 1) * KW + kg) * 8 + 4 * lrow;
-#pragma unroll
-                for (int x = 0; x < WM; ++x) a1[x] = P::frag(Ps[buf], k0, (wi * WM + x) * 32 + lcol);
-#pragma unroll
-                for (int y = 0; y < WN; ++y) b1[y] = Q::frag(Qs[buf], k0, (wj * WN + y) * 32 + lcol);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int st = 0; st < NS; ++st) {
+            const int j = st & 3;
+            if (j == 0 && st + 4 < NS) {                // row-major operands: the next chunk, a chunk ahead
 #pragma unroll
                 for (int x = 0; x < WM; ++x)
+                    if (P::RMAJOR) pa_n[x] = P::frag(Ps(buf), krow(st + 4), (wi * WM + x) * 32 + lcol);
 #pragma unroll
-                    for (int y = 0; y < WN; ++y) {
-                        const float av = j == 0 ? a0[x].x : j == 1 ? a0[x].y : j == 2 ? a0[x].z : a0[x].w;
-                        const float bv = j == 0 ? b0[y].x : j == 1 ? b0[y].y : j == 2 ? b0[y].z : b0[y].w;
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
-                    }
+                for (int y = 0; y < WN; ++y)
+                    if (Q::RMAJOR) qb_n[y] = Q::frag(Qs(buf), krow(st + 4), (wj * WN + y) * 32 + lcol);
+            }
+            if (st + 1 < NS) {                          // k-major operands: the next step's values
+#pragma unroll
+                for (int x = 0; x < WM; ++x)
+                    if (!P::RMAJOR) sa_n[x] = Ps(buf)[krow(st + 1)][(wi * WM + x) * 32 + lcol];
+#pragma unroll
+                for (int y = 0; y < WN; ++y)
+                    if (!Q::RMAJOR) sb_n[y] = Qs(buf)[krow(st + 1)][(wj * WN + y) * 32 + lcol];
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (ch + 1 < NCH) {
+#if MVAE_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-                for (int x = 0; x < WM; ++x) a0[x] = a1[x];
+            for (int x = 0; x < WM; ++x)
 #pragma unroll
-                for (int y = 0; y < WN; ++y) b0[y] = b1[y];
+                for (int y = 0; y < WN; ++y) {
+                    const float av = !P::RMAJOR ? sa[x] : j == 0 ? pa[x].x : j == 1 ? pa[x].y : j == 2 ? pa[x].z : pa[x].w;
+                    const float bv = !Q::RMAJOR ? sb[y] : j == 0 ? qb[y].x : j == 1 ? qb[y].y : j == 2 ? qb[y].z : qb[y].w;
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][y], 0, 0, 0);
+                }
+#if MVAE_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < WM; ++x) {
+                if (!P::RMAJOR) sa[x] = sa_n[x];
+                else if (j == 3) pa[x] = pa_n[x];
+            }
+#pragma unroll
+            for (int y = 0; y < WN; ++y) {
+                if (!Q::RMAJOR) sb[y] = sb_n[y];
+                else if (j == 3) qb[y] = qb_n[y];
             }
         }
     };
 
+    // 2 or 4 tiles per wave: 32 - 64 MFMAs (2048 - 4096 cycles) per k-step cover a global-load latency,
+    // so ONE tile in flight in registers is enough -- the second register stage made the 128 x 128 kernels
+    // spill (256 VGPRs)
+    constexpr bool DEEP = WM * WN < 2;
+    if (!DEEP) {
+        if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
+        if (mover && nsteps > 0) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = s + 1 < nsteps;
+            if (mover && more) { p.load(kbeg + (s + 1) * BKK, kend, t, pr0); q.load(kbeg + (s + 1) * BKK, kend, t, qr0); }
+            compute(s & 1);
+            if (mover && more) { p.store(Ps((s + 1) & 1), t, pr0); q.store(Qs((s + 1) & 1), t, qr0); }
+            __syncthreads();
+        }
+    } else {
     // prologue: tiles 0 and 1 in flight, tile 0 staged
     if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
     if (mover && nsteps > 1) { p.load(kbeg + BKK, kend, t, pr1); q.load(kbeg + BKK, kend, t, qr1); }
-    if (mover && nsteps > 0) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+    if (mover && nsteps > 0) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
     __syncthreads();
     // two k-steps per trip (the register sets alternate); a lone last step is peeled off below so the
     // loop has ONE exit -- with a break in the middle hipcc ping-ponged the accumulator between two
@@ -401,17 +447,18 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
         if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BKK, kend, t, pr0); q.load(kbeg + (s + 2) * BKK, kend, t, qr0); }
         compute(0);
-        if (mover) { p.store(Ps[1], t, pr1); q.store(Qs[1], t, qr1); }
+        if (mover) { p.store(Ps(1), t, pr1); q.store(Qs(1), t, qr1); }
         __syncthreads();
         // odd step
         if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BKK, kend, t, pr1); q.load(kbeg + (s + 3) * BKK, kend, t, qr1); }
         compute(1);
-        if (mover && s + 2 < nsteps) { p.store(Ps[0], t, pr0); q.store(Qs[0], t, qr0); }
+        if (mover && s + 2 < nsteps) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
         __syncthreads();
     }
     if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
         compute(0);
         __syncthreads();
+    }
     }
     if (ROWSUM) {
         if (rs_block) {     // sum the RS_PARTS partial row sums in a fixed order (the tile buffers are free)
