@@ -33,16 +33,18 @@ struct LdIm2colT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int Mtot;
     int base, kq; unsigned vh, vwq;
+    int off[NV]; unsigned okfull;                     // full k-tiles: per-element offsets and validity are thread constants
     __device__ void init(int tile0, int t, int) {
         const int m = tile0 + (t % TILE);
         kq = t / TILE;
         unsigned vw = 0;
         vh = 0; base = 0;
+        int ih0 = 0, iw0 = 0;
         if (m < Mtot) {
             const int ohw = g.OH * g.OW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            ih0 = oh * g.stride - g.pad; iw0 = ow * g.stride - g.pad;
             base = (b * g.Cin * g.H + ih0) * g.W + iw0 + kq;      // kw = kq + (KSTEP*v & 3)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -51,10 +53,33 @@ struct LdIm2colT {
             }
         }
         vwq = vw >> kq;
+        // a tap outside the image reads the (always inside) tap (kh, kw) = (pad, pad) of the same channel
+        // instead and is zeroed by its validity bit; a lane without an output position reads image 0's
+        const int hw = g.H * g.W;
+        const int inside = g.pad * g.W + g.pad - kq;  // relative to base: tap (kh, kw) = (pad, pad)
+        okfull = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = KSTEP * v;
+            const int kwl = c & 3, kh = (c >> 2) & 3, cil = c >> 4;
+            const bool ok = ((vh >> kh) & 1u) && ((vwq >> kwl) & 1u);
+            off[v] = cil * hw + (ok ? kh * g.W + kwl : inside);
+            okfull |= (ok ? 1u : 0u) << v;
+        }
+        if (m >= Mtot) {                              // base = 0: keep every address inside the tensor
+#pragma unroll
+            for (int v = 0; v < NV; ++v) off[v] = ((KSTEP * v) >> 4) * hw;
+        }
     }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int hw = g.H * g.W;
         const float *src = x + base + (k0 >> 4) * hw;
+        if (k0 + BKV <= kend) {                       // block-uniform: the whole k-tile is inside the reduction
+#pragma unroll
+            for (int v = 0; v < NV; ++v) rg.v[v] = src[off[v]];
+            rg.ok = okfull;
+            return;
+        }
         const int safe = (int)(x - src);              // offset of x[0]: always a legal address
         const int krem = kend - k0 - kq;              // element valid iff KSTEP*v < krem
         unsigned okbits = 0;
@@ -80,7 +105,88 @@ struct LdIm2colT {
     }
 };
 
+// The same gather staged ROW-major -- LDS image [m][k], k contiguous.  A thread owns one output position m
+// and whole 4-k groups: k = (ci, kh, kw) with kw fastest, so a group is the 4 horizontal taps of one (ci, kh)
+// -- 4 adjacent input floats -- and goes to LDS as ONE float4.  Fragments are then ds_read_b128 (4 MFMAs per
+// read) like the weight operand's.  With the k-major image every MFMA of every wave cost two 256-byte
+// ds_read_b32; at 16 waves per CU (64x64 tiles, one 32x32 accumulator per wave) that alone kept the LDS
+// port ~75 % busy and held the conv kernels near 50 % of the MFMA rate.
+template <int TILE_, int BKV_ = MVAE_CONV_BK>
+struct LdIm2colR {
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int GPT = NTHREADS / TILE;       // thread slots along the 4-k groups
+    static constexpr int NG = BKV / 4;                // 4-k groups per k-tile
+    static constexpr int NV4 = NG / GPT;              // groups per thread
+    static_assert(NG % GPT == 0 && NV4 >= 1, "tile / k-depth combination not covered");
+    struct Regs { float4 v[NV4]; unsigned ok; };      // raw data + 4 validity bits per group
+    const float *x; ConvGeom g; int Mtot;
+    int base, gq; unsigned vh, vw;
+    __device__ void init(int tile0, int t, int) {
+        const int m = tile0 + (t % TILE);
+        gq = t / TILE;
+        vh = 0; vw = 0; base = 0;
+        if (m < Mtot) {
+            const int ohw = g.OH * g.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            base = (b * g.Cin * g.H + ih0) * g.W + iw0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ih0 + q >= 0 && ih0 + q < g.H) vh |= 1u << q;
+                if (iw0 + q >= 0 && iw0 + q < g.W) vw |= 1u << q;
+            }
+        }
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int hw = g.H * g.W;
+        const float *src = x + base + (k0 >> 4) * hw;
+        const int safe = (int)(x - src);              // offset of x[0]: always a legal address
+        const int grem = (kend - k0) >> 2;            // groups of this tile inside the reduction (K % 16 == 0)
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const int gk = gq + GPT * v;              // group = (ci_local, kh)
+            const int kh = gk & 3, cil = gk >> 2;
+            const bool okg = gk < grem && ((vh >> kh) & 1u);
+            const int off = cil * hw + kh * g.W;
+            float e[4];
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const bool ok = okg && ((vw >> kw) & 1u);
+                e[kw] = src[ok ? off + kw : safe];
+                okbits |= (ok ? 1u : 0u) << (4 * v + kw);
+            }
+            rg.v[v] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = true;
+    static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
+        return *reinterpret_cast<const float4 *>(&L[row][k0]);
+    }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int m = t % TILE;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const unsigned b = rg.ok >> (4 * v);
+            *reinterpret_cast<float4 *>(&L[m][4 * (gq + GPT * v)]) =
+                make_float4(rg.v[v].x * mask0(b & 1u), rg.v[v].y * mask0(b & 2u), rg.v[v].z * mask0(b & 4u),
+                            rg.v[v].w * mask0(b & 8u));
+        }
+    }
+};
+#ifndef MVAE_GATHER_ROWMAJOR
+#define MVAE_GATHER_ROWMAJOR 0      // measured (r2): no gain over the k-major image, see DESIGN.md
+#endif
+#if MVAE_GATHER_ROWMAJOR
+template <int T> using LdIm2col = LdIm2colR<T>;
+#else
 template <int T> using LdIm2col = LdIm2colT<T>;
+#endif
+
 
 // Transposed-conv (dgrad) gather of dy for the output parity class `cls` = (ph,pw) of dx:
 // element (k = (co,a,b), m = (n, ih', iw')) with ih = ih'*s + ph, kh = kh0 + s*a,
@@ -95,6 +201,7 @@ struct LdDgradDyT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
+    int off[NV]; unsigned okfull;                     // full k-tiles: thread-constant offsets and validity
     __device__ void init(int tile0, int t, int cls) {
         const int ph = cls / g.stride, pw = cls % g.stride;
         const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
@@ -103,6 +210,7 @@ struct LdDgradDyT {
         const int aq = (kq >> TLOG) & TMASK, bq = kq & TMASK;     // thread-constant tap fields
         unsigned vh = 0, vw = 0;
         base = 0;
+        int a_in = 0, b_in = 0;                       // a tap of this position that IS inside dy
         if (m < Mtot) {
             const int hw2 = H2 * W2;
             const int n = m / hw2, rem = m - n * hw2;
@@ -112,15 +220,39 @@ struct LdDgradDyT {
             base = (n * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
 #pragma unroll
             for (int a = 0; a <= TMASK; ++a) {
-                if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
-                if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
+                if (ohb - a >= 0 && ohb - a < g.OH) { vh |= 1u << a; a_in = a; }
+                if (owb - a >= 0 && owb - a < g.OW) { vw |= 1u << a; b_in = a; }
             }
         }
         vhq = vh >> aq; vwq = vw >> bq;
+        const int ohw = g.OH * g.OW;
+        const bool lane_ok = m < Mtot && vh != 0 && vw != 0;
+        // relative to base (which already holds -aq, -bq): the inside tap (a_in, b_in)
+        const int inside = -(a_in - aq) * g.OW - (b_in - bq);
+        okfull = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = KSTEP * v;
+            const int bl = c & TMASK, al = (c >> TLOG) & TMASK, col = c >> (2 * TLOG);
+            const bool ok = ((vhq >> al) & 1u) && ((vwq >> bl) & 1u);
+            off[v] = col * ohw + (ok ? -al * g.OW - bl : inside);
+            okfull |= (ok ? 1u : 0u) << v;
+        }
+        if (!lane_ok) {                               // nothing of this lane is inside: read image 0, channel rows only
+            okfull = 0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) off[v] = ((KSTEP * v) >> (2 * TLOG)) * ohw - base;
+        }
     }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int ohw = g.OH * g.OW;
         const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
+        if (k0 + BKV <= kend) {                       // block-uniform: the whole k-tile is inside the reduction
+#pragma unroll
+            for (int v = 0; v < NV; ++v) rg.v[v] = src[off[v]];
+            rg.ok = okfull;
+            return;
+        }
         const int safe = (int)(dy - src);
         const int krem = kend - k0 - kq;
         unsigned okbits = 0;
@@ -145,8 +277,86 @@ struct LdDgradDyT {
         for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
+// Row-major staging of the same gather (see LdIm2colR): a 4-k group is the 2x2 taps of one output channel
+// (stride 2) or the 4 horizontal taps of one (channel, vertical tap) (stride 1).
+template <int TILE_, int TLOG, int BKV_ = MVAE_CONV_BK>
+struct LdDgradDyR {
+    static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr int GPT = NTHREADS / TILE;
+    static constexpr int NG = BKV / 4;
+    static constexpr int NV4 = NG / GPT;
+    static_assert(NG % GPT == 0 && NV4 >= 1, "tile / k-depth combination not covered");
+    struct Regs { float4 v[NV4]; unsigned ok; };
+    const float *dy; ConvGeom g; int Mtot; int H2, W2;
+    int base, gq; unsigned vh, vw;
+    __device__ void init(int tile0, int t, int cls) {
+        const int ph = cls / g.stride, pw = cls % g.stride;
+        const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
+        const int m = tile0 + (t % TILE);
+        gq = t / TILE;
+        vh = 0; vw = 0; base = 0;
+        if (m < Mtot) {
+            const int hw2 = H2 * W2;
+            const int n = m / hw2, rem = m - n * hw2;
+            const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
+            const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
+            const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
+            base = (n * g.Cout * g.OH + ohb) * g.OW + owb;
+#pragma unroll
+            for (int a = 0; a < (1 << TLOG); ++a) {
+                if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
+                if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
+            }
+        }
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+        const int ohw = g.OH * g.OW;
+        const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
+        const int safe = (int)(dy - src);
+        const int grem = (kend - k0) >> 2;
+        unsigned okbits = 0;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const int gk = gq + GPT * v;
+            // stride 2 (TLOG 1): group = channel, elements (a, b) = (e >> 1, e & 1);
+            // stride 1 (TLOG 2): group = (channel, a), elements b = e
+            const int col = TLOG == 1 ? gk : gk >> 2, a_g = TLOG == 1 ? 0 : gk & 3;
+            float e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = TLOG == 1 ? (q >> 1) : a_g, b = TLOG == 1 ? (q & 1) : q;
+                const bool ok = gk < grem && ((vh >> a) & 1u) && ((vw >> b) & 1u);
+                e[q] = src[ok ? col * ohw - a * g.OW - b : safe];
+                okbits |= (ok ? 1u : 0u) << (4 * v + q);
+            }
+            rg.v[v] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        rg.ok = okbits;
+    }
+    static constexpr bool RMAJOR = true;
+    static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
+    typedef float (*Tile)[PITCH];
+    static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
+        return *reinterpret_cast<const float4 *>(&L[row][k0]);
+    }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int m = t % TILE;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const unsigned b = rg.ok >> (4 * v);
+            *reinterpret_cast<float4 *>(&L[m][4 * (gq + GPT * v)]) =
+                make_float4(rg.v[v].x * mask0(b & 1u), rg.v[v].y * mask0(b & 2u), rg.v[v].z * mask0(b & 4u),
+                            rg.v[v].w * mask0(b & 8u));
+        }
+    }
+};
+#if MVAE_GATHER_ROWMAJOR
+template <int TILE_> using LdDgradDyS2 = LdDgradDyR<TILE_, 1>;   // stride 2: 2x2 taps per class
+template <int TILE_> using LdDgradDyS1 = LdDgradDyR<TILE_, 2>;   // stride 1: all 4x4 taps
+#else
 template <int TILE_> using LdDgradDyS2 = LdDgradDyT<TILE_, 1>;   // stride 2: 2x2 taps per class
 template <int TILE_> using LdDgradDyS1 = LdDgradDyT<TILE_, 2>;   // stride 1: all 4x4 taps
+#endif
 // the weight-side loaders of those two forms at the same k-tile depth
 template <int T> using LdRowsKC = LdRowsKT<T, true, MVAE_CONV_BK>;
 template <int T> using LdRowsKSC = LdRowsKT<T, false, MVAE_CONV_BK>;
@@ -185,7 +395,7 @@ struct LdWgradDy {
         rg.ok = okbits;
     }
     static constexpr bool RMAJOR = false;
-    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
     __device__ void store(Tile L, int t, const Regs &rg) const {
@@ -233,7 +443,7 @@ struct LdWgradX {
         rg.ok = okbits;
     }
     static constexpr bool RMAJOR = false;
-    static constexpr int ROWS = BK, PITCH = TILE + LPAD;
+    static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
     __device__ void store(Tile L, int t, const Regs &rg) const {
