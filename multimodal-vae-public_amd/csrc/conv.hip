@@ -494,6 +494,12 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
                   ConvGeom g, hipStream_t st) {
     const int I = g.Cout, J = g.B * g.OH * g.OW, K = g.Cin * 16;
     Plan pl = make_plan(I, J, K, false);
+    // >= 128 output channels and enough columns for >= 384 blocks of 128 x 64: two accumulators per wave share
+    // every gathered fragment (dec2 / dec1 dgrad at 512 images: 91 -> 99 and 77 -> 80 TFLOP/s; at 256 images the
+    // grid would be one block per CU and 64 x 64 tiles win)
+    if (pl.wm == 1 && pl.wn == 1 && pl.kw == 1 && pl.wgn == 2 && I >= 128 && !MVAE_TUNE(wm) && !MVAE_TUNE(wn) &&
+        cdiv(I, 128) * cdiv(J, 64) >= 384)
+        pl.wm = 2;
     EpNCHW e;
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;

@@ -39,6 +39,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Tuning overrides exist only in the -DMVAE_TUNING build (libmvae_hip_tuning.so, used by tools/gemm_bench.py);
 // the product library has no mutable global state: MVAE_TUNE(x) folds to 0.
+#ifndef MVAE_STAGGER
+#define MVAE_STAGGER 0          // > 0: s_sleep units (64 cycles) per CU slot at kernel start (experiment)
+#endif
 #ifndef MVAE_SETPRIO
 #define MVAE_SETPRIO 0          // 1: raise the wave priority around each MFMA group (measured: see DESIGN.md)
 #endif
@@ -329,6 +332,17 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+#if MVAE_STAGGER
+    // experiment: de-phase the blocks that share a CU (block b lands in slot (b / 256) % 4 of its CU when the
+    // grid is dispatched in order), so that their non-MFMA phases do not coincide
+    {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned slot = (lin >> 8) & 3u;
+        if (slot == 1) __builtin_amdgcn_s_sleep(MVAE_STAGGER);
+        else if (slot == 2) __builtin_amdgcn_s_sleep(2 * MVAE_STAGGER);
+        else if (slot == 3) __builtin_amdgcn_s_sleep(3 * MVAE_STAGGER);
+    }
+#endif
     p.init(i0, t, cls);
     q.init(j0, t, cls);
     e.set_class(cls);

@@ -32,9 +32,29 @@ __device__ __forceinline__ void bn_slice_loop(const BnShape &sh, int g, int c, i
     if (sh.vec) {
         const int hw4 = sh.HW >> 2, tx = threadIdx.x & (sh.tx - 1), ty = threadIdx.x / sh.tx;
         const int ny = BN_THREADS / sh.tx;
-        for (int b = b_lo + ty; b < b_hi; b += ny) {
-            const size_t base = ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW;
-            for (int q = tx; q < hw4; q += sh.tx) f4(base + 4 * (size_t)q);
+        // four rows (or four float4 columns) per trip: independent loads in flight instead of one per iteration
+        if (hw4 <= sh.tx) {
+            const bool col_ok = tx < hw4;
+            const size_t row_stride = (size_t)sh.C * sh.HW;
+            int b = b_lo + ty;
+            size_t base = ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW + 4 * (size_t)tx;
+            for (; b + 3 * ny < b_hi; b += 4 * ny, base += 4 * ny * row_stride) {
+                if (col_ok) {
+                    f4(base); f4(base + ny * row_stride); f4(base + 2 * ny * row_stride); f4(base + 3 * ny * row_stride);
+                }
+            }
+            for (; b < b_hi; b += ny, base += ny * row_stride)
+                if (col_ok) f4(base);
+        } else {
+            for (int b = b_lo + ty; b < b_hi; b += ny) {
+                const size_t base = ((size_t)(g * sh.B + b) * sh.C + c) * sh.HW;
+                int q = tx;
+                for (; q + 3 * sh.tx < hw4; q += 4 * sh.tx) {
+                    f4(base + 4 * (size_t)q); f4(base + 4 * (size_t)(q + sh.tx));
+                    f4(base + 4 * (size_t)(q + 2 * sh.tx)); f4(base + 4 * (size_t)(q + 3 * sh.tx));
+                }
+                for (; q < hw4; q += sh.tx) f4(base + 4 * (size_t)q);
+            }
         }
     } else {
         const int n_lo = b_lo * sh.HW, n_hi = b_hi * sh.HW;
@@ -52,7 +72,7 @@ __device__ __forceinline__ void st4(float *p, size_t o, float4 v) { *reinterpret
 // (x - p) and (x - p)^2 with the pivot p = first element of the slice (a sample of the same
 // distribution, so |p - mean| ~ std and M2 = S2 - S1^2/n loses at most a bit or two); slices are
 // then merged with Chan's formula.  (A second pass for the centred sum cost 25 % of the forward.)
-__global__ __launch_bounds__(BN_THREADS) void bn_partial_stats_kernel(const float *x, float *ws, BnShape sh) {
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_stats_kernel(const float *__restrict__ x, float *__restrict__ ws, BnShape sh) {
     __shared__ float red[16];
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
     const int b_lo = s * sh.rows, b_hi = min(sh.B, b_lo + sh.rows);
@@ -94,8 +114,8 @@ __device__ inline void bn_merge(const float *ws, const BnShape &sh, int g, int c
 
 // y = swish?(gamma * ((x - mean) * invstd) + beta); also saves mean/invstd and advances the
 // running statistics (one block per channel does that, sequentially over groups).
-__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x, const float *gamma,
-                                                                  const float *beta, float *y, const float *ws,
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *__restrict__ x, const float *gamma,
+                                                                  const float *beta, float *__restrict__ y, const float *ws,
                                                                   float *save_mean, float *save_invstd,
                                                                   float *running_mean, float *running_var,
                                                                   BnShape sh, float eps, float momentum,
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *x
 }
 
 // ws[((g*C + c)*S + s)*2 + {0,1}] = (sum dh, sum dh * xhat), dh = dy * swish'(h)
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *dy, const float *x,
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                     const float *gamma, const float *beta,
                                                                     const float *save_mean,
                                                                     const float *save_invstd, float *ws,
@@ -169,11 +189,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
     }
 }
 
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *dy, const float *x,
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                   const float *gamma, const float *beta,
                                                                   const float *save_mean,
                                                                   const float *save_invstd, const float *ws,
-                                                                  float *dx, float *dgamma, float *dbeta,
+                                                                  float *__restrict__ dx, float *dgamma, float *dbeta,
                                                                   BnShape sh, int swish, int accumulate) {
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
     const float *p = ws + (size_t)(g * sh.C + c) * sh.S * 2;

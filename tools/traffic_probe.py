@@ -35,9 +35,10 @@ def run(name, key):
     import mvae_amd  # noqa: F401
     from mvae_amd import kernels as K
     dev = 'cuda'
-    d = parse_key(key)
-    M, N, Kd = d['M'], d['N'], d['K']
     r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    if (name, key) not in CONV_CASES:
+        d = parse_key(key)
+        M, N, Kd = d['M'], d['N'], d['K']
     if name == 'linear_fwd':
         x, w, b, pre, act = r(M, Kd), r(N, Kd), r(N), torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
         fn = lambda: K.linear_fwd(x, w, b, pre, act)  # noqa: E731
@@ -47,17 +48,60 @@ def run(name, key):
     elif name == 'linear_wgrad':
         dy, x, dw, db = r(M, N), r(M, Kd), torch.empty(N, Kd, device=dev), torch.empty(N, device=dev)
         fn = lambda: K.linear_wgrad(dy, x, dw, db)  # noqa: E731
+    elif (name, key) in CONV_CASES:
+        fn = conv_case(K, name, key)
     else:
-        raise SystemExit('unknown op %s' % name)
+        raise SystemExit('unknown op %s %s' % (name, key))
     for _ in range(N_CALLS):
         fn()
     torch.cuda.synchronize()
 
 
+# conv launches bench.py may name as dominant on the CelebA step: (profiler name, key) -> ConvTranspose2d / Conv2d
+# layer (B, Cin, H, Cout, stride, pad) of celeba/model.py:77-86,117-126 at 2 x 256 decoder rows / 256 encoder rows
+CONV_CASES = {
+    ('convT2d_dgrad', '512x256x5x5'): ('convT', 512, 256, 5, 128, 1, 0),
+    ('convT2d_fwd', '512x128x8x8'): ('convT', 512, 256, 5, 128, 1, 0),
+    ('convT2d_wgrad', '256x128x4x4'): ('convT', 512, 256, 5, 128, 1, 0),
+    ('convT2d_fwd', '512x32x32x32'): ('convT', 512, 64, 16, 32, 2, 1),
+    ('conv2d_fwd', '256x64x16x16'): ('conv', 256, 32, 32, 64, 2, 1),
+}
+
+
+def conv_case(K, name, key):
+    import torch
+    kind, B, Cin, H, Cout, s, p = CONV_CASES[(name, key)]
+    r = lambda *sh: torch.randn(*sh, device='cuda')  # noqa: E731
+    if kind == 'convT':
+        OH = (H - 1) * s - 2 * p + 4
+        x, w = r(B, Cin, H, H), r(Cin, Cout, 4, 4)
+        y, dy, dx, dw = torch.empty(B, Cout, OH, OH, device='cuda'), r(B, Cout, OH, OH), torch.empty_like(x), torch.empty_like(w)
+        return {'convT2d_fwd': lambda: K.convT2d_fwd(x, w, y, None, s, p),
+                'convT2d_dgrad': lambda: K.convT2d_dgrad(dy, w, dx, None, s, p),
+                'convT2d_wgrad': lambda: K.convT2d_wgrad(dy, x, dw, s, p)}[name]
+    OH = (H + 2 * p - 4) // s + 1
+    x, w = r(B, Cin, H, H), r(Cout, Cin, 4, 4)
+    y, dy, dx, dw = torch.empty(B, Cout, OH, OH, device='cuda'), r(B, Cout, OH, OH), torch.empty_like(x), torch.empty_like(w)
+    return {'conv2d_fwd': lambda: K.conv2d_fwd(x, w, y, None, s, p),
+            'conv2d_dgrad': lambda: K.conv2d_dgrad(dy, w, dx, None, s, p),
+            'conv2d_wgrad': lambda: K.conv2d_wgrad(dy, x, dw, s, p)}[name]
+
+
+def algorithmic_bytes(name, key):
+    """Bytes a launch must move at least: every operand read once, the result written once."""
+    if (name, key) in CONV_CASES:
+        kind, B, Cin, H, Cout, s, p = CONV_CASES[(name, key)]
+        OH = (H - 1) * s - 2 * p + 4 if kind == 'convT' else (H + 2 * p - 4) // s + 1
+        return 4 * (B * Cin * H * H + B * Cout * OH * OH + Cin * Cout * 16)
+    d = parse_key(key)
+    M, N, Kd = d['M'], d['N'], d['K']
+    return 4 * (M * N + M * Kd + N * Kd + (N if name == 'linear_wgrad' else 0))
+
+
 def _per_call_kib(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)).fetchall()
-    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|finish|splitk_reduce', n)]
+    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_smallcin|repack_dgrad', n)]
     per_kernel = {}
     for n, v in ours:
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:90]
@@ -69,9 +113,7 @@ def _per_call_kib(db, counter):
 def collect(fetch_db, write_db, out_json, name, key):
     f_kib, f_detail = _per_call_kib(fetch_db, 'FETCH_SIZE')
     w_kib, w_detail = _per_call_kib(write_db, 'WRITE_SIZE')
-    d = parse_key(key)
-    M, N, Kd = d['M'], d['N'], d['K']
-    algorithmic = 4 * (M * N + M * Kd + N * Kd + (N if name == 'linear_wgrad' else 0))
+    algorithmic = algorithmic_bytes(name, key)
     ent = {
         'hbm_bytes_per_launch': int(round((2.0 * f_kib + w_kib) * 1024)),
         'fetch_size_kib_reported': round(f_kib, 1), 'fetch_correction': 2.0,
