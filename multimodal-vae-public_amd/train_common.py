@@ -203,11 +203,15 @@ def _find_idx(root, stem):
 
 def _real_loaders(kind, batch_size, device, rank=0, data_dir='./data', world=1):
     """The loaders of mnist/train.py:159-165 / fashionmnist/train.py:159-165 from the IDX files under
-    ``data_dir`` (where torchvision's ``download=True`` puts them); this box has no network, so they
-    must already be there.  CelebA's image folder + attribute file parsing is out of scope
-    (celeba/datasets.py): use --synthetic."""
-    if kind not in ('mnist', 'fashionmnist'):
-        raise SystemExit('the CelebA dataset loader is out of scope here: run with --synthetic')
+    ``data_dir`` (where torchvision's ``download=True`` puts them), and of celeba/train.py:146-156 /
+    celeba19/train.py from the aligned-CelebA folder layout (``img_align_celeba/``, ``Anno/``, ``Eval/``) via
+    ``celeba.datasets.CelebaLoader``.  This box has no network, so the files must already be there."""
+    if kind in ('celeba', 'celeba19'):
+        from .celeba.datasets import CelebaLoader
+        if not os.path.isfile(os.path.join(data_dir, 'Eval/list_eval_partition.txt')):
+            raise SystemExit('no CelebA files under %s (no network to download them): run with --synthetic' % data_dir)
+        return (CelebaLoader('train', data_dir, batch_size, True, device, seed=1234, rank=rank, world=world),
+                CelebaLoader('val', data_dir, batch_size, False, device))
     paths = [_find_idx(data_dir, stem) for stem in ('train-images-idx3-ubyte', 'train-labels-idx1-ubyte',
                                                     't10k-images-idx3-ubyte', 't10k-labels-idx1-ubyte')]
     if any(p is None for p in paths):
