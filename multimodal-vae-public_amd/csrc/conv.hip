@@ -586,38 +586,43 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
     return mvae_launch_status();
 }
 
-// ---- stride-1 transposed conv as a DENSE GEMM + in-register/LDS col2im (ConvTranspose2d(256,128,4,1,0)
+// ---- stride-1 transposed conv as a DENSE GEMM + col2im through LDS (ConvTranspose2d(256,128,4,1,0)
 //      5x5 -> 8x8 and the dgrad of Conv2d(128,256,4,1,0): celeba/model.py:85,117).  In the gather
 //      form only 39 % of the (output pixel, tap) pairs are inside the 5x5 input, so 61 % of the MFMA
 //      work multiplies zeros.  Here the GEMM is  col[(n,oh,ow)][(ci,kh,kw)] = sum_co dy[n,co,oh,ow] *
-//      w[co,ci,kh,kw]  (every product is real; the 25 positions of an image are padded to one 32-row
-//      MFMA tile = 78 % utilisation), and the scatter-add  dx[n,ci,oh+kh,ow+kw] += col  happens inside
-//      the wave that owns the tile: a wave holds one image x 2 input channels x 16 taps, i.e.
-//      everything two output planes need.  Block = 2 images x 4 channels; k loop over Cout. ----
+//      w[co,ci,kh,kw]  -- every product is real -- and the scatter-add  dx[n,ci,oh+kh,ow+kw] += col  happens
+//      inside the block, which owns whole images: NI = 128 / (OH*OW) images (5 for the 5x5 maps: 125 of the
+//      128 tile rows are real; the first version padded each image to a 32-row MFMA tile, 78 %) x 4 input
+//      channels x 16 taps.  4 waves, each 64 rows x 32 columns = two accumulators sharing the weight
+//      fragments; k loop over Cout; the finished 128 x 64 tile is parked in LDS and every thread gathers the
+//      <= 16 taps of its output pixels. ----
+constexpr int S1_ROWS = 128, S1_COLS = 64;
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
-                                                          const float *dpre, ConvGeom g) {
-    constexpr int BMX = 64, BNX = 64;
-    __shared__ __attribute__((aligned(16))) float Ps[2][BK][BMX + LPAD];
-    __shared__ __attribute__((aligned(16))) float Qs[2][BK][BNX + LPAD];
+                                                          const float *dpre, ConvGeom g, int NI) {
+    constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
+    constexpr int P_FL = BK * PP, Q_FL = BK * QP;
+    __shared__ __attribute__((aligned(16))) float s1_lds[2 * P_FL + 2 * Q_FL > S1_ROWS * TP ? 2 * P_FL + 2 * Q_FL : S1_ROWS * TP];
+    auto Ps = [&](int b2) { return reinterpret_cast<float (*)[PP]>(s1_lds + b2 * P_FL); };
+    auto Qs = [&](int b2) { return reinterpret_cast<float (*)[QP]>(s1_lds + 2 * P_FL + b2 * Q_FL); };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int P = g.OH * g.OW;                      // positions per image (<= 32)
-    const int n0 = blockIdx.y * 2, ci0 = blockIdx.x * 4;
+    const int n0 = blockIdx.y * NI, ci0 = blockIdx.x * 4;
     const int K = g.Cout, J = g.Cin * 16;
-    // P loader: lanes along the position axis, 4 k rows per pass
-    const int pi = t & 63, pkq = t >> 6;
-    const int pimg = pi >> 5, ppos = pi & 31;
-    const bool pok = ppos < P && n0 + pimg < g.B;
+    // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass
+    const int pr_ = t & 127, pkq = t >> 7;
+    const int pimg = pr_ / P, ppos = pr_ - pimg * P;
+    const bool pok = pimg < NI && n0 + pimg < g.B;
     const float *psrc = dy + ((size_t)(pok ? n0 + pimg : 0) * K) * P + (pok ? ppos : 0);
     // Q loader: weight rows are contiguous in (ci, tap): 16 float4 per k row, 2 per thread
     const float *qsrc = w + (size_t)ci0 * 16;
-    float pr[8], pm[8];
+    float pr[16], pm[16];
     float4 qr[2];
     float qm[2];
     auto load = [&](int k0) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int k = k0 + pkq + 4 * v;
+        for (int v = 0; v < 16; ++v) {
+            const int k = k0 + pkq + 2 * v;
             pm[v] = (pok && k < K) ? 1.f : 0.f;
             pr[v] = psrc[(size_t)min(k, K - 1) * P];
         }
@@ -630,17 +635,19 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) Ps[buf][pkq + 4 * v][pi] = pr[v] * pm[v];
+        for (int v = 0; v < 16; ++v) Ps(buf)[pkq + 2 * v][pr_] = pr[v] * pm[v];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int f = t + 256 * v;
-            *reinterpret_cast<float4 *>(&Qs[buf][f >> 4][(f & 15) * 4]) =
+            *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) =
                 make_float4(qr[v].x * qm[v], qr[v].y * qm[v], qr[v].z * qm[v], qr[v].w * qm[v]);
         }
     };
-    f32x16 acc;
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
     const int nsteps = (K + BK - 1) / BK;
     load(0);
@@ -649,56 +656,61 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) load((s + 1) * BK);
-        float a0 = Ps[buf][lrow][wi * 32 + lcol], b0 = Qs[buf][lrow][wj * 32 + lcol];
+        float a0[2], b0;
+        a0[0] = Ps(buf)[lrow][wi * 64 + lcol]; a0[1] = Ps(buf)[lrow][wi * 64 + 32 + lcol];
+        b0 = Qs(buf)[lrow][wj * 32 + lcol];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a1 = 0.f, b1 = 0.f;
+            float a1[2] = {0.f, 0.f}, b1 = 0.f;
             if (kk + 1 < BK / 2) {
-                a1 = Ps[buf][(kk + 1) * 2 + lrow][wi * 32 + lcol];
-                b1 = Qs[buf][(kk + 1) * 2 + lrow][wj * 32 + lcol];
+                a1[0] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + lcol];
+                a1[1] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + 32 + lcol];
+                b1 = Qs(buf)[(kk + 1) * 2 + lrow][wj * 32 + lcol];
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a0 = a1; b0 = b1;
+            a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
         }
         if (s + 1 < nsteps) store(buf ^ 1);
         __syncthreads();
     }
-    // col2im inside the wave: park the 32 (positions) x 32 (2 channels x 16 taps) tile in LDS ...
-    float *sc = &Ps[0][0][0] + wave * (32 * 33);        // 4 x 4224 B <= the P tile buffers
+    // col2im: park the 128 (packed positions) x 64 (4 channels x 16 taps) tile in LDS ...
+    float *sc = s1_lds;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
-        sc[row * 33 + lcol] = acc[r];
-    }
-    __syncthreads();
-    // ... and let each lane gather the <= 16 taps of its output pixels
-    const int n = n0 + wi;
-    if (n >= g.B) return;
-    const int HW = g.H * g.W;
-    for (int cl = 0; cl < 2; ++cl) {
-        const int ci = ci0 + wj * 2 + cl;
-        if (ci >= g.Cin) break;
-        for (int px = lane; px < HW; px += 64) {
-            const int ih = px / g.W, iw = px - ih * g.W;
-            float v = 0.f;
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh) {
-                const int oh = ih - kh;
-                if (oh < 0 || oh >= g.OH) continue;
-#pragma unroll
-                for (int kw = 0; kw < 4; ++kw) {
-                    const int ow = iw - kw;
-                    if (ow < 0 || ow >= g.OW) continue;
-                    v += sc[(oh * g.OW + ow) * 33 + cl * 16 + kh * 4 + kw];
-                }
-            }
-            const size_t o = ((size_t)n * g.Cin + ci) * HW + px;
-            if (dpre) v *= swish_grad_(dpre[o]);
-            if (out) out[o] = v;
-            if (act) act[o] = swishf_(v);
+        for (int r = 0; r < 16; ++r) {
+            const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            sc[row * TP + wj * 32 + lcol] = acc[x][r];
         }
+    __syncthreads();
+    // ... and let every thread gather the <= 16 taps of its output pixels (image, channel, pixel)
+    const int HW = g.H * g.W;
+    const int per_img = 4 * HW;
+    for (int idx = t; idx < NI * per_img; idx += 256) {
+        const int img = idx / per_img, rem = idx - img * per_img;
+        const int cl = rem / HW, px = rem - cl * HW;
+        const int n = n0 + img, ci = ci0 + cl;
+        if (n >= g.B || ci >= g.Cin) continue;
+        const int ih = px / g.W, iw = px - ih * g.W;
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int oh = ih - kh;
+            if (oh < 0 || oh >= g.OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ow = iw - kw;
+                if (ow < 0 || ow >= g.OW) continue;
+                v += sc[(img * P + oh * g.OW + ow) * TP + cl * 16 + kh * 4 + kw];
+            }
+        }
+        const size_t o = ((size_t)n * g.Cin + ci) * HW + px;
+        if (dpre) v *= swish_grad_(dpre[o]);
+        if (out) out[o] = v;
+        if (act) act[o] = swishf_(v);
     }
 }
 
@@ -708,8 +720,9 @@ inline bool conv_dgrad_s1_ok(const ConvGeom &g, const float *w) {
 
 inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act, const float *dpre, ConvGeom g,
                          hipStream_t st) {
-    dim3 grid(g.Cin / 4, (g.B + 1) / 2);
-    hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g);
+    const int NI = S1_ROWS / (g.OH * g.OW);         // whole images per block
+    dim3 grid(g.Cin / 4, (g.B + NI - 1) / NI);
+    hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g, NI);
     return mvae_launch_status();
 }
 
