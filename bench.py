@@ -10,12 +10,25 @@ resident in HBM.  Default workload = BASELINE.json config
 n-latents 64, batch 512 per GPU.  Weak scaling: the per-GPU batch is fixed as N grows.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      -- the dominant kernel of the step, timed live with HIP events on the launch
-                   stream (profiler.KernelProfile) in this same process,
+  roofline      -- the dominant GEMM-shaped call of the step, IN SITU: every launcher is bracketed by HIP
+                   events on the launch stream (profiler.KernelProfile) and eager single-stream steps are
+                   enqueued behind a spin kernel that outlasts the host's enqueue time, so an interval
+                   is the call's kernel(s) plus its launch boundary, with the caches as the previous kernel
+                   left them.  ``hot_cache_reissue`` = the same call re-issued back to back in a hipGraph
+                   (round 1's figure), ``conv_kernels`` / ``all_gemm_kernels`` = the in-situ aggregates,
+                   ``top_hbm_kernel`` = the HBM-bound kernel with the most time, ``traffic`` = HBM-side bytes
+                   per launch from the committed PMC table (profiles/r02_traffic.json),
   cpu_baseline  -- the oracle (CPU restatement of the reference step, kind "port") timed on the
-                   host cores of this box on a bounded sample of the same workload,
+                   host cores of this box on a bounded sample of the same workload; ``cores`` = intra-op
+                   threads used (fastest of a few counts), ``host`` = nproc + CPU model,
+                   ``cfg0_mnist_b128`` = BASELINE configs[0], ``elbo_delta`` = HIP vs oracle on one step,
+  dist          -- (N > 1 or --force-dp) world size, backend + RCCL version, an all-reduce-of-ones check,
+                   bucket sizes, ms/step of the same launch path with the collectives switched off and
+                   the difference (= exposed communication),
   also          -- (default invocation only) the CelebA B=256 step: images/sec and the fp32-MFMA
                    roofline of its conv kernels, the figure north_star's 40 % target is about.
+Flags beyond the contract: --no-extras (value only), --no-graph, --force-dp (world-1 run through the
+data-parallel launch path), --force-tiling wm,wn[,splits] (tuning build of the library).
 """
 import argparse
 import json
