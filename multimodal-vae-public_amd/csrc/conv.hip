@@ -33,19 +33,22 @@ struct LdIm2colT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int Mtot;
     int base, kq; unsigned vh, vwq;
-    int off[NV]; unsigned okfull;                     // full k-tiles: per-element offsets and validity are thread constants
+    BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
     __device__ void init(int tile0, int t, int) {
         const int m = tile0 + (t % TILE);
         kq = t / TILE;
         unsigned vw = 0;
         vh = 0; base = 0;
-        int ih0 = 0, iw0 = 0;
+        const int ohw = g.OH * g.OW, hw = g.H * g.W;
+        const int n0 = tile0 / ohw;                   // block-uniform
+        blk = buf_base(x + (size_t)n0 * g.Cin * hw);
+        int rel = 0;
         if (m < Mtot) {
-            const int ohw = g.OH * g.OW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            ih0 = oh * g.stride - g.pad; iw0 = ow * g.stride - g.pad;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
             base = (b * g.Cin * g.H + ih0) * g.W + iw0 + kq;      // kw = kq + (KSTEP*v & 3)
+            rel = ((b - n0) * g.Cin * g.H + ih0) * g.W + iw0 + kq;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (ih0 + q >= 0 && ih0 + q < g.H) vh |= 1u << q;
@@ -53,33 +56,24 @@ struct LdIm2colT {
             }
         }
         vwq = vw >> kq;
-        // a tap outside the image reads the (always inside) tap (kh, kw) = (pad, pad) of the same channel
-        // instead and is zeroed by its validity bit; a lane without an output position reads image 0's
-        const int hw = g.H * g.W;
-        const int inside = g.pad * g.W + g.pad - kq;  // relative to base: tap (kh, kw) = (pad, pad)
-        okfull = 0;
+        // element v of a full k-tile: channel (KSTEP*v >> 4) of the tile's channel group, tap (kh, kw); a tap
+        // outside the image (or a lane without an output position) reads as zero through BUF_OOB
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = KSTEP * v;
             const int kwl = c & 3, kh = (c >> 2) & 3, cil = c >> 4;
             const bool ok = ((vh >> kh) & 1u) && ((vwq >> kwl) & 1u);
-            off[v] = cil * hw + (ok ? kh * g.W + kwl : inside);
-            okfull |= (ok ? 1u : 0u) << v;
-        }
-        if (m >= Mtot) {                              // base = 0: keep every address inside the tensor
-#pragma unroll
-            for (int v = 0; v < NV; ++v) off[v] = ((KSTEP * v) >> 4) * hw;
+            voff[v] = ok ? (rel + cil * hw + kh * g.W + kwl) * 4 : BUF_OOB;
         }
     }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
-        const int hw = g.H * g.W;
-        const float *src = x + base + (k0 >> 4) * hw;
         if (k0 + BKV <= kend) {                       // block-uniform: the whole k-tile is inside the reduction
-#pragma unroll
-            for (int v = 0; v < NV; ++v) rg.v[v] = src[off[v]];
-            rg.ok = okfull;
+            load_part(k0, kend, t, rg, 0, 1);
+            rg.ok = 0xffffffffu;
             return;
         }
+        const int hw = g.H * g.W;
+        const float *src = x + base + (k0 >> 4) * hw;
         const int safe = (int)(x - src);              // offset of x[0]: always a legal address
         const int krem = kend - k0 - kq;              // element valid iff KSTEP*v < krem
         unsigned okbits = 0;
@@ -102,6 +96,20 @@ struct LdIm2colT {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
         for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+    // slices of a FULL k-tile (gemm_core.h, buffer loads): no vector-ALU work per element
+    static constexpr bool PARTS = true;
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> 4) * (g.H * g.W));
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load1(rs, voff[v]);
+    }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
+        const int m = t % TILE, kb = t / TILE;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) L[kb + v * KSTEP][m] = rg.v[v];
     }
 };
 
@@ -161,7 +169,7 @@ struct LdIm2colR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true;
+    static constexpr bool RMAJOR = true, PARTS = false;
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
@@ -201,7 +209,7 @@ struct LdDgradDyT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
-    int off[NV]; unsigned okfull;                     // full k-tiles: thread-constant offsets and validity
+    BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
     __device__ void init(int tile0, int t, int cls) {
         const int ph = cls / g.stride, pw = cls % g.stride;
         const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
@@ -210,49 +218,40 @@ struct LdDgradDyT {
         const int aq = (kq >> TLOG) & TMASK, bq = kq & TMASK;     // thread-constant tap fields
         unsigned vh = 0, vw = 0;
         base = 0;
-        int a_in = 0, b_in = 0;                       // a tap of this position that IS inside dy
+        const int hw2 = H2 * W2, ohw = g.OH * g.OW;
+        const int n0 = tile0 / hw2;                   // block-uniform
+        blk = buf_base(dy + (size_t)n0 * g.Cout * ohw);
+        int rel = 0;
         if (m < Mtot) {
-            const int hw2 = H2 * W2;
             const int n = m / hw2, rem = m - n * hw2;
             const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
             const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
             const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
             base = (n * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
+            rel = ((n - n0) * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
 #pragma unroll
             for (int a = 0; a <= TMASK; ++a) {
-                if (ohb - a >= 0 && ohb - a < g.OH) { vh |= 1u << a; a_in = a; }
-                if (owb - a >= 0 && owb - a < g.OW) { vw |= 1u << a; b_in = a; }
+                if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
+                if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
             }
         }
         vhq = vh >> aq; vwq = vw >> bq;
-        const int ohw = g.OH * g.OW;
-        const bool lane_ok = m < Mtot && vh != 0 && vw != 0;
-        // relative to base (which already holds -aq, -bq): the inside tap (a_in, b_in)
-        const int inside = -(a_in - aq) * g.OW - (b_in - bq);
-        okfull = 0;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = KSTEP * v;
             const int bl = c & TMASK, al = (c >> TLOG) & TMASK, col = c >> (2 * TLOG);
             const bool ok = ((vhq >> al) & 1u) && ((vwq >> bl) & 1u);
-            off[v] = col * ohw + (ok ? -al * g.OW - bl : inside);
-            okfull |= (ok ? 1u : 0u) << v;
-        }
-        if (!lane_ok) {                               // nothing of this lane is inside: read image 0, channel rows only
-            okfull = 0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) off[v] = ((KSTEP * v) >> (2 * TLOG)) * ohw - base;
+            voff[v] = ok ? (rel + col * ohw - al * g.OW - bl) * 4 : BUF_OOB;
         }
     }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
-        const int ohw = g.OH * g.OW;
-        const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
         if (k0 + BKV <= kend) {                       // block-uniform: the whole k-tile is inside the reduction
-#pragma unroll
-            for (int v = 0; v < NV; ++v) rg.v[v] = src[off[v]];
-            rg.ok = okfull;
+            load_part(k0, kend, t, rg, 0, 1);
+            rg.ok = 0xffffffffu;
             return;
         }
+        const int ohw = g.OH * g.OW;
+        const float *src = dy + base + (k0 >> (2 * TLOG)) * ohw;
         const int safe = (int)(dy - src);
         const int krem = kend - k0 - kq;
         unsigned okbits = 0;
@@ -275,6 +274,19 @@ struct LdDgradDyT {
         const int m = t % TILE, kb = t / TILE;
 #pragma unroll
         for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
+    static constexpr bool PARTS = true;               // slices of a FULL k-tile: buffer loads, nothing on the vector ALU
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> (2 * TLOG)) * (g.OH * g.OW));
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load1(rs, voff[v]);
+    }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
+        const int m = t % TILE, kb = t / TILE;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) L[kb + v * KSTEP][m] = rg.v[v];
     }
 };
 // Row-major staging of the same gather (see LdIm2colR): a 4-k group is the 2x2 taps of one output channel
@@ -333,7 +345,7 @@ struct LdDgradDyR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true;
+    static constexpr bool RMAJOR = true, PARTS = false;
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
@@ -378,30 +390,31 @@ struct LdWgradDy {
         ioff = ib * g.OH * g.OW;
         nvalid = (g.Cout - ib + ISTEP - 1) / ISTEP;     // rows ib + v*ISTEP < Cout  <=>  v < nvalid
     }
-    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+    __device__ void load(int k0, int kend, int t, Regs &rg) const { load_part(k0, kend, t, rg, 0, 1); }
+    static constexpr bool PARTS = true;
+    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
         const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
         const float *src = dy + (size_t)b * g.Cout * ohw + sp + ioff;
         const int safe = (int)(dy - src);
         const int nv = (k < kend) ? nvalid : 0;
-        unsigned okbits = 0;
+        if (part == 0) rg.ok = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);      // bit v set iff v < nv
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const float val = src[(v < nv) ? v * ISTEP * ohw : safe];
-            rg.v[v] = val;
-            okbits |= ((v < nv) ? 1u : 0u) << v;
-        }
-        rg.ok = okbits;
+        for (int v = 0; v < NV; ++v)
+            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts) rg.v[v] = src[(v < nv) ? v * ISTEP * ohw : safe];
     }
     static constexpr bool RMAJOR = false;
     static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
-    __device__ void store(Tile L, int t, const Regs &rg) const {
+    __device__ void store(Tile L, int t, const Regs &rg) const { store_part(L, t, rg, 0, 1); }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int kl = t % BK, ib = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+        for (int v = 0; v < NV; ++v)
+            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
+                L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 
@@ -419,7 +432,9 @@ struct LdWgradX {
         joff = (tile0 >> 4) * g.H * g.W + (jq >> 2) * g.W + (jq & 3);
         nvalid = (J - tile0 - jq + JSTEP - 1) / JSTEP;
     }
-    __device__ void load(int k0, int kend, int t, Regs &rg) const {
+    __device__ void load(int k0, int kend, int t, Regs &rg) const { load_part(k0, kend, t, rg, 0, 1); }
+    static constexpr bool PARTS = true;
+    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
         const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
@@ -436,20 +451,23 @@ struct LdWgradX {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const bool ok = ((v & 1) ? ok1 : ok0) && v < nvalid;
-            const float val = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
-            rg.v[v] = val;
+            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
+                rg.v[v] = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
             okbits |= (ok ? 1u : 0u) << v;
         }
-        rg.ok = okbits;
+        if (part == 0) rg.ok = okbits;
     }
     static constexpr bool RMAJOR = false;
     static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
-    __device__ void store(Tile L, int t, const Regs &rg) const {
+    __device__ void store(Tile L, int t, const Regs &rg) const { store_part(L, t, rg, 0, 1); }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int kl = t % BK, jb = t / BK;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+        for (int v = 0; v < NV; ++v)
+            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
+                L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
 };
 
@@ -686,28 +704,40 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             sc[row * TP + wj * 32 + lcol] = acc[x][r];
         }
     __syncthreads();
-    // ... and let every thread gather the <= 16 taps of its output pixels (image, channel, pixel)
+    // ... and let every thread gather the <= 16 taps of its output pixels (image, channel, pixel).  The reads are
+    // unconditional from clamped positions with a 0/1 factor (16 LDS reads in flight; a branch per tap made
+    // every read wait for the one before it).
     const int HW = g.H * g.W;
     const int per_img = 4 * HW;
+    const bool pow2 = (g.H == 8 && g.W == 8);
     for (int idx = t; idx < NI * per_img; idx += 256) {
-        const int img = idx / per_img, rem = idx - img * per_img;
-        const int cl = rem / HW, px = rem - cl * HW;
+        int img, cl, ih, iw;
+        if (pow2) { img = idx >> 8; cl = (idx >> 6) & 3; ih = (idx >> 3) & 7; iw = idx & 7; }
+        else {
+            img = idx / per_img;
+            const int rem = idx - img * per_img;
+            cl = rem / HW;
+            const int px = rem - cl * HW;
+            ih = px / g.W; iw = px - ih * g.W;
+        }
         const int n = n0 + img, ci = ci0 + cl;
         if (n >= g.B || ci >= g.Cin) continue;
-        const int ih = px / g.W, iw = px - ih * g.W;
+        const float *base = sc + (img * P) * TP + cl * 16;
         float v = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 4; ++kh) {
             const int oh = ih - kh;
-            if (oh < 0 || oh >= g.OH) continue;
+            const bool okh = oh >= 0 && oh < g.OH;
+            const int ohc = min(max(oh, 0), g.OH - 1);
 #pragma unroll
             for (int kw = 0; kw < 4; ++kw) {
                 const int ow = iw - kw;
-                if (ow < 0 || ow >= g.OW) continue;
-                v += sc[(img * P + oh * g.OW + ow) * TP + cl * 16 + kh * 4 + kw];
+                const bool ok = okh && ow >= 0 && ow < g.OW;
+                const int owc = min(max(ow, 0), g.OW - 1);
+                v += (ok ? 1.f : 0.f) * base[(ohc * g.OW + owc) * TP + kh * 4 + kw];
             }
         }
-        const size_t o = ((size_t)n * g.Cin + ci) * HW + px;
+        const size_t o = ((size_t)n * g.Cin + ci) * HW + ih * g.W + iw;
         if (dpre) v *= swish_grad_(dpre[o]);
         if (out) out[o] = v;
         if (act) act[o] = swishf_(v);

@@ -42,6 +42,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_STAGGER
 #define MVAE_STAGGER 0          // > 0: s_sleep units (64 cycles) per CU slot at kernel start (experiment)
 #endif
+#ifndef MVAE_INTERLEAVE
+#define MVAE_INTERLEAVE 1       // 1: next-tile loads / stores sliced into the MFMA groups' shadows (see igemm_kernel)
+#endif
+#ifndef MVAE_KO
+#define MVAE_KO 0               // knock-out experiments on the interleaved loop (results are wrong): 1 no global loads,
+#endif                          // 2 + no LDS stores, 3 + no barrier, 4 + no fragment reads (MFMAs only)
 #ifndef MVAE_SETPRIO
 #define MVAE_SETPRIO 0          // 1: raise the wave priority around each MFMA group (measured: see DESIGN.md)
 #endif
@@ -77,6 +83,46 @@ __device__ __forceinline__ float4 frag_kmajor(float (*L)[PITCH_], int k0, int ro
     return make_float4(L[k0][row], L[k0 + 1][row], L[k0 + 2][row], L[k0 + 3][row]);
 }
 
+// ---- buffer loads for the main loops ----
+// In an fp32-MFMA kernel every VALU instruction costs matrix throughput (the fp32 matrix instruction runs on the
+// same fp32 FMA lanes: tools/mfma_peak measures 145 -> 95 TFLOP/s with TWO VALU instructions per MFMA at one wave
+// per SIMD, ~4.5 cycles per VALU instruction at four).  The loaders therefore fetch FULL k-tiles with raw buffer
+// loads: the per-thread byte offsets are constants computed once in init(), the k-step moves the (scalar) base
+// of the buffer resource, and an element that must read as zero (a row beyond the matrix, a tap outside the
+// image) carries the offset BUF_OOB, which is beyond num_records -- the hardware returns 0.  No address
+// arithmetic, no bounds test and no mask multiply is left on the vector ALU.
+// (The loads are declared on the LLVM intrinsics: hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 emits a
+// ONE-dword load.  The block's base address is pinned to scalar registers with readfirstlane in init(); left to
+// itself the compiler kept it in vector registers and wrapped every load in a waterfall loop.)
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float llvm_raw_buffer_load_f32(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+constexpr int BUF_OOB = (int)0x80000000u;
+struct BufBase { unsigned lo, hi; };                  // a block-uniform address, held in scalar registers
+__device__ __forceinline__ BufBase buf_base(const float *p) {
+    const unsigned long long a = (unsigned long long)p;
+    BufBase b;
+    b.lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    b.hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return b;
+}
+// raw buffer (stride 0) at base + `floats`, num_records 2 GiB - 1: offsets are bytes relative to that address,
+// which every loader keeps within the current tile's neighbourhood
+__device__ __forceinline__ i32x4_t buf_rsrc(BufBase b, size_t floats) {
+    const unsigned long long a = (((unsigned long long)b.hi << 32) | b.lo) + (unsigned long long)floats * 4ull;
+    i32x4_t r;
+    r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xffffu); r.z = 0x7fffffff; r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ float buf_load1(i32x4_t r, int voff) { return llvm_raw_buffer_load_f32(r, voff, 0, 0); }
+__device__ __forceinline__ float4 buf_load4(i32x4_t r, int voff) {
+    const f32x4_t u = llvm_raw_buffer_load_f32x4(r, voff, 0, 0);
+    return make_float4(u.x, u.y, u.z, u.w);
+}
+// slice `part` of `nparts` of an NV-element per-thread transfer
+#define MVAE_IN_PART(v, NV_, part, nparts) ((v) >= (part) * (NV_) / (nparts) && (v) < ((part) + 1) * (NV_) / (nparts))
+
 // S[r * ld + k]: reduction axis contiguous (x and w of Linear fwd, dy of dgrad, conv weights).
 // VEC: base 16-byte aligned, ld % 4 == 0 and Klen % 4 == 0 (float4 loads never straddle the end).
 // BKV: k-tile depth (32 for the conv forms; the small Linear GEMMs use 64 -- half the barriers).
@@ -89,7 +135,21 @@ struct LdRowsKT {
     const float *src; int ld; int R; int Klen;
     size_t cls_stride = 0;                            // per-class (group) source offset
     int r0;
-    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
+    int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from row r0, k0 (or BUF_OOB)
+    BufBase blk;                                      //              address of (row r0, k = 0)
+    __device__ void init(int tile0, int t, int cls) {
+        r0 = tile0; src += (size_t)cls * cls_stride;
+        if (VEC) {
+            blk = buf_base(src + (size_t)r0 * ld);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int f = t + NTHREADS * v;
+                const int r = f / (BKV / 4), kc = (f % (BKV / 4)) * 4;
+                voff[v] = (r0 + r < R) ? (r * ld + kc) * 4 : BUF_OOB;
+            }
+        }
+    }
+    // general path (partial k-tiles, unaligned operands): clamped addresses + 0/1 masks
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -110,6 +170,14 @@ struct LdRowsKT {
             rg.v[v] = x;
         }
     }
+    // full k-tile, slice `part` of `nparts` (the interleaved main loop issues one slice per MFMA group)
+    static constexpr bool PARTS = VEC;
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)k0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load4(rs, voff[VEC ? v : 0]);
+    }
     // LDS image [TILE][BKV + 4]: the tile as it lies in memory (k contiguous), float4 stores, rows
     // 16-byte aligned.  The row pitch 4 * odd makes the ds_read_b128 fragment reads -- lane (row, 4 k's)
     // -- conflict-free (MI355X_MICROARCH.md, LDS: b128 lane groups of 16 rows on 64 banks).  The first
@@ -127,6 +195,14 @@ struct LdRowsKT {
             const float m2 = rg.m[VEC ? v : 4 * v + 2], m3 = rg.m[VEC ? v : 4 * v + 3];
             *reinterpret_cast<float4 *>(&L[r][kc]) =
                 make_float4(rg.v[v].x * m0, rg.v[v].y * m1, rg.v[v].z * m2, rg.v[v].w * m3);
+        }
+    }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!MVAE_IN_PART(v, NV, part, nparts)) continue;
+            const int f = t + NTHREADS * v;
+            *reinterpret_cast<float4 *>(&L[f / (BKV / 4)][(f % (BKV / 4)) * 4]) = rg.v[v];
         }
     }
     // the 4 consecutive k's starting at k0 of tile row `row`: one ds_read_b128
@@ -150,7 +226,20 @@ struct LdRowsMNT {
     struct Regs { float4 v[NV]; float m[VEC ? NV : 4 * NV]; };
     const float *src; int ld; int R; int Klen; size_t cls_stride;   // cls_stride: per-class source offset
     int r0;
-    __device__ void init(int tile0, int, int cls) { r0 = tile0; src += (size_t)cls * cls_stride; }
+    int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from (k0, r0) (or BUF_OOB)
+    BufBase blk;                                      //              address of (k = 0, r0)
+    __device__ void init(int tile0, int t, int cls) {
+        r0 = tile0; src += (size_t)cls * cls_stride;
+        if (VEC) {
+            blk = buf_base(src + r0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int f = t + NTHREADS * v;
+                const int kl = f / V4, r = (f % V4) * 4;
+                voff[v] = (r0 + r < R) ? (kl * ld + r) * 4 : BUF_OOB;
+            }
+        }
+    }
     __device__ void load(int k0, int kend, int t, Regs &rg) const {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -171,6 +260,13 @@ struct LdRowsMNT {
             rg.v[v] = x;
         }
     }
+    static constexpr bool PARTS = VEC;
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)k0 * ld);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load4(rs, voff[VEC ? v : 0]);
+    }
     // LDS image [BKV][TILE + 4] (k-major: the non-reduced axis contiguous, as in memory)
     static constexpr bool RMAJOR = false;
     static constexpr int ROWS = BKV, PITCH = TILE + LPAD;
@@ -183,6 +279,14 @@ struct LdRowsMNT {
             const float m0 = rg.m[VEC ? v : 4 * v], m1 = rg.m[VEC ? v : 4 * v + 1];
             const float m2 = rg.m[VEC ? v : 4 * v + 2], m3 = rg.m[VEC ? v : 4 * v + 3];
             *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = make_float4(x.x * m0, x.y * m1, x.z * m2, x.w * m3);
+        }
+    }
+    __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (!MVAE_IN_PART(v, NV, part, nparts)) continue;
+            const int f = t + NTHREADS * v;
+            *reinterpret_cast<float4 *>(&L[f / V4][(f % V4) * 4]) = rg.v[v];
         }
     }
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
@@ -356,7 +460,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     float rsum = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, auto &&hook) {
         if (ROWSUM) {
             if (rs_block && mover) {
 #pragma unroll
@@ -384,10 +488,16 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             if (Q::RMAJOR) qb[y] = Q::frag(Qs(buf), krow(0), (wj * WN + y) * 32 + lcol);
             else sb[y] = Qs(buf)[krow(0)][(wj * WN + y) * 32 + lcol];
         }
+#if MVAE_KO >= 4
+#pragma unroll
+        for (int x = 0; x < WM; ++x) { pa_n[x] = pa[x]; sa_n[x] = sa[x]; }
+#pragma unroll
+        for (int y = 0; y < WN; ++y) { qb_n[y] = qb[y]; sb_n[y] = sb[y]; }
+#endif
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             const int j = st & 3;
-            if (j == 0 && st + 4 < NS) {                // row-major operands: the next chunk, a chunk ahead
+            if (MVAE_KO < 4 && j == 0 && st + 4 < NS) { // row-major operands: the next chunk, a chunk ahead
 #pragma unroll
                 for (int x = 0; x < WM; ++x)
                     if (P::RMAJOR) pa_n[x] = P::frag(Ps(buf), krow(st + 4), (wi * WM + x) * 32 + lcol);
@@ -395,7 +505,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 for (int y = 0; y < WN; ++y)
                     if (Q::RMAJOR) qb_n[y] = Q::frag(Qs(buf), krow(st + 4), (wj * WN + y) * 32 + lcol);
             }
-            if (st + 1 < NS) {                          // k-major operands: the next step's values
+            if (MVAE_KO < 4 && st + 1 < NS) {           // k-major operands: the next step's values
 #pragma unroll
                 for (int x = 0; x < WM; ++x)
                     if (!P::RMAJOR) sa_n[x] = Ps(buf)[krow(st + 1)][(wi * WM + x) * 32 + lcol];
@@ -419,6 +529,8 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            hook(st, NS);                               // a slice of the next tile's loads / stores, in this group's shadow
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int x = 0; x < WM; ++x) {
                 if (!P::RMAJOR) sa[x] = sa_n[x];
@@ -436,14 +548,79 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // so ONE tile in flight in registers is enough -- the second register stage made the 128 x 128 kernels
     // spill (256 VGPRs)
     constexpr bool DEEP = WM * WN < 2;
-    if (!DEEP) {
+    auto no_hook = [](int, int) {};
+    // Interleaved main loop (every thread a mover, every k-tile full): the next tile's global loads are issued
+    // slice by slice right after the first MFMA groups of the current tile and its LDS stores after the last
+    // ones, so that address arithmetic, load issue, mask multiplies and ds_writes run in the shadow of the
+    // wave's OWN matrix instructions.  With load(); compute(); store() as three phases a wave issues no MFMA
+    // for a few hundred cycles per k-step and the pipe idles unless another block's wave happens to be in its
+    // MFMA phase (tools/mfma_peak: the pipe itself sustains 154.6 TFLOP/s from one wave per SIMD).
+    constexpr bool CAN_IL = (NT == NTHREADS) && P::PARTS && Q::PARTS && MVAE_INTERLEAVE;
+    const bool il = CAN_IL && nsteps > 0 && (kend - kbeg) % BKK == 0;
+    if (CAN_IL && il && !DEEP) {
+        p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
+        p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
+        __syncthreads();
+        for (int s = 0; s + 1 < nsteps; ++s) {
+            const int kn = kbeg + (s + 1) * BKK, nb = (s + 1) & 1;
+            compute(s & 1, [&](int st, int ns) {
+                const int nl = (WM * WN >= 4) ? ns / 4 : ns / 8;   // load slots at the head, store slots at the tail: >= 1500 MFMA cycles apart
+#if MVAE_KO < 1
+                if (st < nl) { p.load_part(kn, kend, t, pr0, st, nl); q.load_part(kn, kend, t, qr0, st, nl); }
+#endif
+#if MVAE_KO < 2
+                if (st >= ns - nl) { p.store_part(Ps(nb), t, pr0, st - (ns - nl), nl); q.store_part(Qs(nb), t, qr0, st - (ns - nl), nl); }
+#endif
+            });
+#if MVAE_KO < 3
+            __syncthreads();
+#endif
+        }
+        compute((nsteps - 1) & 1, no_hook);
+        __syncthreads();
+    } else if (CAN_IL && il && DEEP) {
+        // one tile per wave: 16 MFMAs per k-step do not cover a global-load latency, so two tiles are in flight
+        // in registers; tile s+2 is fetched in the first half of step s, tile s+1 staged in its second half
+        p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
+        if (nsteps > 1) { p.load_part(kbeg + BKK, kend, t, pr1, 0, 1); q.load_part(kbeg + BKK, kend, t, qr1, 0, 1); }
+        p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
+        __syncthreads();
+        int s = 0;
+        for (; s + 2 < nsteps; s += 2) {
+            const int k2 = kbeg + (s + 2) * BKK, k3 = kbeg + min(s + 3, nsteps - 1) * BKK;
+            compute(0, [&](int st, int ns) {
+                const int nl = ns / 2;
+                if (st < nl) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); }
+                else { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
+            });
+            __syncthreads();
+            compute(1, [&](int st, int ns) {
+                const int nl = ns / 2;
+                if (st < nl) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); }
+                else { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
+            });
+            __syncthreads();
+        }
+        // tail: tile s is staged in buffer 0; tile s+1 (if any) waits in register set 1
+        if (s + 1 < nsteps) {
+            compute(0, [&](int st, int ns) {
+                if (st >= ns / 2) { p.store_part(Ps(1), t, pr1, st - ns / 2, ns - ns / 2); q.store_part(Qs(1), t, qr1, st - ns / 2, ns - ns / 2); }
+            });
+            __syncthreads();
+            compute(1, no_hook);
+            __syncthreads();
+        } else if (s < nsteps) {
+            compute(0, no_hook);
+            __syncthreads();
+        }
+    } else if (!DEEP) {
         if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
         if (mover && nsteps > 0) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
             const bool more = s + 1 < nsteps;
             if (mover && more) { p.load(kbeg + (s + 1) * BKK, kend, t, pr0); q.load(kbeg + (s + 1) * BKK, kend, t, qr0); }
-            compute(s & 1);
+            compute(s & 1, no_hook);
             if (mover && more) { p.store(Ps((s + 1) & 1), t, pr0); q.store(Qs((s + 1) & 1), t, qr0); }
             __syncthreads();
         }
@@ -460,17 +637,17 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     for (; s + 1 < nsteps; s += 2) {
         // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
         if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BKK, kend, t, pr0); q.load(kbeg + (s + 2) * BKK, kend, t, qr0); }
-        compute(0);
+        compute(0, no_hook);
         if (mover) { p.store(Ps(1), t, pr1); q.store(Qs(1), t, qr1); }
         __syncthreads();
         // odd step
         if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BKK, kend, t, pr1); q.load(kbeg + (s + 3) * BKK, kend, t, qr1); }
-        compute(1);
+        compute(1, no_hook);
         if (mover && s + 2 < nsteps) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
         __syncthreads();
     }
     if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
-        compute(0);
+        compute(0, no_hook);
         __syncthreads();
     }
     }

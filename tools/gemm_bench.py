@@ -82,10 +82,21 @@ def lin_cases(M, N, Kd, tag):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv', 'knockout'])
+    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv', 'knockout', 'dec19'])
+    ap.add_argument('--auto-only', action='store_true', help='time only the automatic plan')
     args = ap.parse_args()
     conv, lin = [], []
     B = 256
+    if args.cases == 'dec19':
+        # the image decoder's forward over the rows of celeba19's 21 terms (the three largest kernels of that step)
+        rows = 21 * B
+        for name, fl, fn in (convT_cases(rows, 256, 5, 128, 1, 0, 'c19 dec1 256->128 5x5 s1')[:1] +
+                             convT_cases(rows, 128, 8, 64, 2, 1, 'c19 dec2 128->64 8x8')[:1] +
+                             convT_cases(rows, 64, 16, 32, 2, 1, 'c19 dec3 64->32 16x16')[:1] +
+                             convT_cases(rows, 32, 32, 3, 2, 1, 'c19 dec4 32->3 32x32')[:1]):
+            ms = timeit(fn, launches=4, replays=3)
+            print('%-34s %8.2f GFLOP %8.1f TFLOP/s %9.1f us' % (name, fl / 1e9, fl / (ms * 1e-3) / 1e12, ms * 1e3))
+        return
     conv += conv_cases(B, 3, 64, 32, 2, 1, 'enc1 3->32 64x64')
     conv += conv_cases(B, 32, 32, 64, 2, 1, 'enc2 32->64 32x32')
     conv += conv_cases(B, 64, 16, 128, 2, 1, 'enc3 64->128 16x16')
@@ -124,6 +135,8 @@ def main():
             lib.mvae_debug_set_knockout(0)
             print('%-34s %10.1f %10.1f %10.1f' % tuple([name] + row))
         return
+    if args.auto_only:
+        conv_cfg, lin_cfg = conv_cfg[:1], lin_cfg[:1]
     tot = {}
     for title, cases, configs in (('conv', conv, conv_cfg), ('lin', lin, lin_cfg)):
         if args.cases not in ('all', title):
