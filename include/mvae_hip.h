@@ -77,6 +77,23 @@ int mvae_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
                       float *dw, float *db, int M, int N, int K, int flags,
                       void *ws, size_t ws_bytes, mvae_stream_t stream);
 
+/* Several Linear weight gradients of DIFFERENT shapes in one launch: dw_q[N_q][K_q] (+)= dy_q^T x_q and, where
+ * db_q != NULL, db_q[N_q] (+)= column sums of dy_q -- the loss.backward() work of up to
+ * MVAE_WGRAD_BATCH_MAX nn.Linear layers (mnist/model.py:75-78,95-104,137-145) that nothing but the optimizer
+ * waits for.  Each item: N*K <= 2048 tiles of 32x32, M <= 4096, operands below 4 GiB; distinct dw / db per
+ * item (MVAE_ERR_ARG otherwise -- use mvae_linear_wgrad for those).  Same arithmetic as mvae_linear_wgrad's
+ * direct path: per output the batch rows are summed in a fixed order (deterministic). */
+#define MVAE_WGRAD_BATCH_MAX 16
+typedef struct {
+    const float *dy; int lddy;      /* [M, N] upstream gradient, row stride lddy */
+    const float *x; int ldx;        /* [M, K] layer input, row stride ldx */
+    float *dw;                      /* [N, K] contiguous */
+    float *db;                      /* [N] or NULL */
+    int M, N, K;
+    int flags;                      /* MVAE_ACCUMULATE: add to dw / db */
+} mvae_wgrad_item;
+int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_items, mvae_stream_t stream);
+
 /* Grouped forms: G independent Linear problems of ONE shape in one launch.  celeba19 builds 18
  * identical attribute encoders / decoders (celeba19/model.py:29-30, 173-196) and the reference runs
  * them one after another (celeba19/model.py:78-81, 53-54); here operand g of every array is at

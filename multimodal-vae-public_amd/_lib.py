@@ -35,6 +35,14 @@ class ElboPart(ctypes.Structure):
 ELBO_MAX_PARTS = 4
 
 
+class WgradItem(ctypes.Structure):          # mvae_wgrad_item
+    _fields_ = [('dy', c_void_p), ('lddy', c_int), ('x', c_void_p), ('ldx', c_int), ('dw', c_void_p),
+                ('db', c_void_p), ('M', c_int), ('N', c_int), ('K', c_int), ('flags', c_int)]
+
+
+WGRAD_BATCH_MAX = 16
+
+
 class ExpertGrads(ctypes.Structure):
     _fields_ = [('dmu', c_void_p * MAX_EXPERTS), ('dlogvar', c_void_p * MAX_EXPERTS)]
 
@@ -87,6 +95,7 @@ _SIGNATURES = {
     'mvae_ce_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_ce_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),
     'mvae_randn': (c_int, [P, c_size_t, c_uint64, P, P]),

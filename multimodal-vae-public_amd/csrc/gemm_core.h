@@ -26,12 +26,9 @@
 // Three shapes do not fit the template and have their own kernels below: the stride-1 transposed conv
 // (convT_s1_kernel: dense GEMM + col2im), the <= 4-output-channel transposed conv (convT_small_kernel)
 // and the weight gradient of the <= 4-input-channel conv (wgrad_smallcin_kernel).
-#include <cstdlib>
-
-#include "common.h"
-
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -613,43 +610,63 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             compute(0, no_hook);
             __syncthreads();
         }
-    } else if (!DEEP) {
-        if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
-        if (mover && nsteps > 0) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const bool more = s + 1 < nsteps;
-            if (mover && more) { p.load(kbeg + (s + 1) * BKK, kend, t, pr0); q.load(kbeg + (s + 1) * BKK, kend, t, qr0); }
-            compute(s & 1, no_hook);
-            if (mover && more) { p.store(Ps((s + 1) & 1), t, pr0); q.store(Qs((s + 1) & 1), t, qr0); }
-            __syncthreads();
-        }
     } else {
-    // prologue: tiles 0 and 1 in flight, tile 0 staged
-    if (mover && nsteps > 0) { p.load(kbeg, kend, t, pr0); q.load(kbeg, kend, t, qr0); }
-    if (mover && nsteps > 1) { p.load(kbeg + BKK, kend, t, pr1); q.load(kbeg + BKK, kend, t, qr1); }
-    if (mover && nsteps > 0) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
-    __syncthreads();
-    // two k-steps per trip (the register sets alternate); a lone last step is peeled off below so the
-    // loop has ONE exit -- with a break in the middle hipcc ping-ponged the accumulator between two
-    // register sets (16 v_mov + 17 wait states per k-step)
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
-        if (mover && s + 2 < nsteps) { p.load(kbeg + (s + 2) * BKK, kend, t, pr0); q.load(kbeg + (s + 2) * BKK, kend, t, qr0); }
-        compute(0, no_hook);
-        if (mover) { p.store(Ps(1), t, pr1); q.store(Qs(1), t, qr1); }
-        __syncthreads();
-        // odd step
-        if (mover && s + 3 < nsteps) { p.load(kbeg + (s + 3) * BKK, kend, t, pr1); q.load(kbeg + (s + 3) * BKK, kend, t, qr1); }
-        compute(1, no_hook);
-        if (mover && s + 2 < nsteps) { p.store(Ps(0), t, pr0); q.store(Qs(0), t, qr0); }
-        __syncthreads();
-    }
-    if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
-        compute(0, no_hook);
-        __syncthreads();
-    }
+        // phased loops (k-grouped blocks, whose extra waves only issue MFMAs; partial k-tiles; unaligned operands).
+        // With full k-tiles the movers still use the buffer loads / raw stores: `fullc` picks the version.
+        auto LOAD = [&](auto fullc, int k0, typename P::Regs &pr, typename Q::Regs &qr) {
+            if constexpr (decltype(fullc)::value) { p.load_part(k0, kend, t, pr, 0, 1); q.load_part(k0, kend, t, qr, 0, 1); }
+            else { p.load(k0, kend, t, pr); q.load(k0, kend, t, qr); }
+        };
+        auto STORE = [&](auto fullc, int b, const typename P::Regs &pr, const typename Q::Regs &qr) {
+            if constexpr (decltype(fullc)::value) { p.store_part(Ps(b), t, pr, 0, 1); q.store_part(Qs(b), t, qr, 0, 1); }
+            else { p.store(Ps(b), t, pr); q.store(Qs(b), t, qr); }
+        };
+        auto phased = [&](auto fullc) {
+            if (!DEEP) {
+                if (mover && nsteps > 0) LOAD(fullc, kbeg, pr0, qr0);
+                if (mover && nsteps > 0) STORE(fullc, 0, pr0, qr0);
+                __syncthreads();
+                for (int s = 0; s < nsteps; ++s) {
+                    const bool more = s + 1 < nsteps;
+                    if (mover && more) LOAD(fullc, kbeg + (s + 1) * BKK, pr0, qr0);
+                    compute(s & 1, no_hook);
+                    if (mover && more) STORE(fullc, (s + 1) & 1, pr0, qr0);
+                    __syncthreads();
+                }
+                return;
+            }
+            // one tile per wave -- prologue: tiles 0 and 1 in flight, tile 0 staged
+            if (mover && nsteps > 0) LOAD(fullc, kbeg, pr0, qr0);
+            if (mover && nsteps > 1) LOAD(fullc, kbeg + BKK, pr1, qr1);
+            if (mover && nsteps > 0) STORE(fullc, 0, pr0, qr0);
+            __syncthreads();
+            // two k-steps per trip (the register sets alternate); a lone last step is peeled off below so the
+            // loop has ONE exit -- with a break in the middle hipcc ping-ponged the accumulator between two
+            // register sets (16 v_mov + 17 wait states per k-step)
+            int s = 0;
+            for (; s + 1 < nsteps; s += 2) {
+                // even step: MFMA on buffer 0; register set 0 is free -> fetch tile s+2; stage tile s+1
+                if (mover && s + 2 < nsteps) LOAD(fullc, kbeg + (s + 2) * BKK, pr0, qr0);
+                compute(0, no_hook);
+                if (mover) STORE(fullc, 1, pr1, qr1);
+                __syncthreads();
+                // odd step
+                if (mover && s + 3 < nsteps) LOAD(fullc, kbeg + (s + 3) * BKK, pr1, qr1);
+                compute(1, no_hook);
+                if (mover && s + 2 < nsteps) STORE(fullc, 0, pr0, qr0);
+                __syncthreads();
+            }
+            if (s < nsteps) {       // odd number of k-steps: the last tile sits in buffer 0
+                compute(0, no_hook);
+                __syncthreads();
+            }
+        };
+        constexpr bool CAN_FULL = P::PARTS && Q::PARTS && MVAE_INTERLEAVE;
+        if (CAN_FULL && nsteps > 0 && (kend - kbeg) % BKK == 0) {
+            if constexpr (CAN_FULL) phased(std::true_type{});
+        } else {
+            phased(std::false_type{});
+        }
     }
     if (ROWSUM) {
         if (rs_block) {     // sum the RS_PARTS partial row sums in a fixed order (the tile buffers are free)

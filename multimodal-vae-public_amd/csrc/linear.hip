@@ -118,6 +118,28 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
                : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
 }
 
+MVAE_EXPORT int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_items, mvae_stream_t stream) {
+    if (n_items < 1 || n_items > WGRAD_BATCH_MAX || !items) return MVAE_ERR_ARG;
+    WgradBatchArgs a;
+    a.n = n_items;
+    int tiles = 0;
+    for (int q = 0; q < n_items; ++q) {
+        const mvae_wgrad_item &s = items[q];
+        if (!s.dy || !s.x || !s.dw || s.M < 1 || s.N < 1 || s.K < 1 || s.lddy < s.N || s.ldx < s.K) return MVAE_ERR_ARG;
+        if (!wgrad_batch_item_ok(s.N, s.K, s.M, s.lddy, s.ldx)) return MVAE_ERR_ARG;
+        for (int r = 0; r < q; ++r)
+            if (items[r].dw == s.dw || (s.db && items[r].db == s.db)) return MVAE_ERR_ARG;   // one writer per gradient
+        WgradBatchItem &w = a.it[q];
+        w.dy = s.dy; w.x = s.x; w.dw = s.dw; w.db = s.db;
+        w.lddy = s.lddy; w.ldx = s.ldx; w.M = s.M; w.I = s.N; w.J = s.K;
+        w.accumulate = (s.flags & MVAE_ACCUMULATE) ? 1 : 0;
+        w.tiles_j = cdiv(s.K, 32);
+        tiles += cdiv(s.N, 32) * w.tiles_j;
+        w.tile_end = tiles;
+    }
+    return wgrad_batched_launch(a, (hipStream_t)stream);
+}
+
 static const LinGroups kOneGroup = {1, 0, 0, 0, 0};
 
 MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const float *bias,

@@ -27,13 +27,13 @@ constexpr int WD_PD = 4;      // chunks (of 8 reduction rows) in flight per wave
 // MODE (tuning build only: mvae_debug_set_knockout): 0 = the kernel; 1 = loads without the MFMAs; 2 = MFMAs
 // without the loads -- where the time of a launch goes.
 template <bool ROWSUM, int KW, int MODE = 0>
-__global__ __launch_bounds__(64 * KW) void wgrad_direct_kernel(const float *dy, int lddy, const float *x, int ldx,
-                                                              EpRowMajor e, int I, int J, int M, float *db,
-                                                              int db_accumulate) {
+__device__ __forceinline__ void wgrad_direct_tile(const float *dy, int lddy, const float *x, int ldx,
+                                                  const EpRowMajor &e, int I, int J, int M, float *db,
+                                                  int db_accumulate, int tile_i, int tile_j) {
     extern __shared__ __attribute__((aligned(16))) float wd_lds[];
     const int t = threadIdx.x, lane = t & 63, kg = t >> 6;
     const int lcol = lane & 31, lrow = lane >> 5;
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int i0 = tile_i * 32, j0 = tile_j * 32;
     // 32-bit element offsets from the (wave-uniform) tensor bases: scalar base + vector offset addressing.
     // Columns beyond the operand are clamped (their products land in outputs the epilogue drops).
     const unsigned col_a = (unsigned)min(i0 + lcol, I - 1) * 4u, col_b = (unsigned)min(j0 + lcol, J - 1) * 4u;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * KW) void wgrad_direct_kernel(const float *dy, 
         if (e.col(j0 + jl)) e.put(i0 + il, j0 + jl, v);
     }
     if (ROWSUM) {
-        if (blockIdx.x == 0 && t < 32 && i0 + t < I) {
+        if (tile_j == 0 && t < 32 && i0 + t < I) {
             float s = 0.f;
 #pragma unroll
             for (int g2 = 0; g2 < 2 * KW; ++g2) s += rsl[g2 * 32 + t];
@@ -131,6 +131,71 @@ __global__ __launch_bounds__(64 * KW) void wgrad_direct_kernel(const float *dy, 
             db[i0 + t] = s;
         }
     }
+}
+
+template <bool ROWSUM, int KW, int MODE = 0>
+__global__ __launch_bounds__(64 * KW) void wgrad_direct_kernel(const float *dy, int lddy, const float *x, int ldx,
+                                                              EpRowMajor e, int I, int J, int M, float *db,
+                                                              int db_accumulate) {
+    wgrad_direct_tile<ROWSUM, KW, MODE>(dy, lddy, x, ldx, e, I, J, M, db, db_accumulate, blockIdx.y, blockIdx.x);
+}
+
+// ---- several Linear weight gradients in ONE launch (mvae_linear_wgrad_batched): the weight gradients of a
+//      stack are off the data-gradient chain -- nothing but the optimizer reads them -- so the backward pass
+//      queues them and issues them together: the 4 (decoder) + 3 (encoder) launches of an MNIST stack become
+//      one grid that fills the chip, instead of seven 10-us launches on the critical path of a 380-us step.
+//      A block looks its problem up in the table (block-uniform scan of <= 16 prefix counts) and runs the
+//      same tile code as the single-problem kernel.
+constexpr int WGRAD_BATCH_MAX = 16;
+struct WgradBatchItem {
+    const float *dy, *x; float *dw, *db;
+    int lddy, ldx, M, I, J, accumulate;
+    int tiles_j, tile_end;          // tiles along J; first tile index AFTER this problem in the launch
+};
+struct WgradBatchArgs { WgradBatchItem it[WGRAD_BATCH_MAX]; int n; };
+
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void wgrad_batched_kernel(WgradBatchArgs a) {
+    int p = 0, first = 0;
+    const int tile = blockIdx.x;
+#pragma unroll 1
+    for (int q = 0; q < a.n - 1; ++q) {
+        if (tile >= a.it[q].tile_end) { p = q + 1; first = a.it[q].tile_end; }
+    }
+    const WgradBatchItem &w = a.it[p];
+    const int local = tile - first;
+    const int tile_i = local / w.tiles_j, tile_j = local - tile_i * w.tiles_j;
+    EpRowMajor e;
+    e.out = w.dw; e.act = nullptr; e.ld = w.J; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
+    e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = w.I; e.J = w.J; e.accumulate = w.accumulate;
+    if (w.db) wgrad_direct_tile<true, KW>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, w.db, w.accumulate, tile_i, tile_j);
+    else wgrad_direct_tile<false, KW>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, nullptr, 0, tile_i, tile_j);
+}
+
+// shapes the direct tile code serves well on its own merits (32-bit byte offsets inside the operands included)
+inline bool wgrad_batch_item_ok(int I, int J, int M, int lddy, int ldx) {
+    const long tiles = cdiv(I, 32) * cdiv(J, 32);
+    return tiles <= 2048 && M <= 4096 && (long)M * lddy * 4 < (1L << 32) && (long)M * ldx * 4 < (1L << 32);
+}
+
+inline int wgrad_batched_launch(WgradBatchArgs &a, hipStream_t st) {
+    const int total = a.it[a.n - 1].tile_end;
+    // waves per tile: enough blocks x waves to put ~4 waves on every SIMD, a reduction slice of >= 4 chunks each
+    const int kw = total >= 768 ? 4 : (total >= 256 ? 8 : 16);
+#define MVAE_WB(KWV)                                                                                          \
+    {                                                                                                         \
+        constexpr size_t lds = ((size_t)KWV * 32 * 33 + (size_t)KWV * 64) * sizeof(float);                    \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_batched_kernel<KWV>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL(wgrad_batched_kernel<KWV>, dim3(total), dim3(64 * KWV), lds, st, a);               \
+    }
+    if (kw == 4) MVAE_WB(4) else if (kw == 8) MVAE_WB(8) else MVAE_WB(16)
+#undef MVAE_WB
+    return mvae_launch_status();
 }
 
 // one problem (no groups); returns false when the shape is better served by the tiled kernel

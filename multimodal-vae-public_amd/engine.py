@@ -141,6 +141,7 @@ class _StepBase(object):
         # MI355X: no gain (MNIST B=512 0.58-0.60 vs 0.56 ms/step, CelebA B=256 3.54-3.67 vs 3.58) --
         # with two branches in flight the kernels already fill the CUs; a fork per LAYER was 30 %
         # slower (every fork is a cross-queue signal).
+        self.batch_wgrad = os.environ.get('MVAE_BATCH_WGRAD', '1') != '0'
         self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 3 else None
         self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else self.wg_main
         self._wg_pending = []
@@ -159,14 +160,22 @@ class _StepBase(object):
             yield
 
     def _deferred(self):
-        """The list a backward chain queues its weight-gradient launches in (None: launch inline)."""
-        return [] if self.wg_main is not None else None
+        """The list a backward chain queues its weight-gradient launches in (None: launch inline).  Default:
+        a ``layers.WgradBatch`` -- the chain's Linear weight gradients leave as ONE launch when the chain is
+        done (MVAE_BATCH_WGRAD=0: inline, one launch per layer)."""
+        if self.wg_main is not None:
+            return []
+        return L.WgradBatch() if self.batch_wgrad else None
 
     def _launch_deferred(self, fns, stream):
         """Run the queued weight-gradient launches on ``stream``, ordered after everything the
         CURRENT stream has launched.  Joined by ``_join_wgrad`` -- directly into the origin stream:
         hipGraph capture (ROCm 7.0) crashes in EndCapture when a fork of a fork joins back into
-        its parent (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main')."""
+        its parent (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main').  A ``WgradBatch`` is
+        flushed on the current stream instead."""
+        if isinstance(fns, L.WgradBatch):
+            fns.flush()
+            return
         if not fns:
             return
         stream.wait_stream(torch.cuda.current_stream(self.dev))
@@ -576,6 +585,8 @@ class BimodalStep(_StepBase):
             wl, wi = self._deferred(), self._deferred()
             with self._branch():
                 L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
+                if isinstance(wl, L.WgradBatch):
+                    wl.flush()
             if self.has_dropout:
                 d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True, deferred=wi)
                 d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
@@ -583,6 +594,9 @@ class BimodalStep(_StepBase):
                 L.backward_tape(self.trunk, c['tape_trunk'], d_h, deferred=wi)
             else:
                 L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, deferred=wi)
+            if isinstance(wi, L.WgradBatch):
+                wi.flush()
+                wi = None
             self._join()
             if wi is not None:
                 fns = wi + wl

@@ -91,6 +91,32 @@ def linear_wgrad(dy, x, dw, db=None, accumulate=False):
           'mvae_linear_wgrad')
 
 
+def wgrad_batchable(dy, x):
+    """Whether mvae_linear_wgrad_batched takes this problem (see include/mvae_hip.h)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    tiles = ((N + 31) // 32) * ((K + 31) // 32)
+    return (tiles <= 2048 and M <= 4096 and M * dy.stride(0) * 4 < (1 << 32) and M * x.stride(0) * 4 < (1 << 32)
+            and dy.stride(1) == 1 and x.stride(1) == 1)
+
+
+def linear_wgrad_batched(items):
+    """items: [(dy[M,N], x[M,K], dw[N,K], db[N] or None, accumulate)] -- the weight gradients of several Linear
+    layers in ONE launch (mvae_linear_wgrad_batched); more than WGRAD_BATCH_MAX items go out in several."""
+    items = list(items)
+    for lo in range(0, len(items), _lib.WGRAD_BATCH_MAX):
+        chunk = items[lo:lo + _lib.WGRAD_BATCH_MAX]
+        arr = (_lib.WgradItem * len(chunk))()
+        for q, (dy, x, dw, db, acc) in enumerate(chunk):
+            _need_gpu(dy, x, dw, db); _f32c(dw, db)
+            M, N = dy.shape
+            if x.shape[0] != M or tuple(dw.shape) != (N, x.shape[1]):
+                raise RuntimeError('wgrad item %d: shapes %s %s %s' % (q, tuple(dy.shape), tuple(x.shape), tuple(dw.shape)))
+            arr[q] = _lib.WgradItem(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), _ptr(db), M, N,
+                                    x.shape[1], ACCUMULATE if acc else 0)
+        check(_lib.lib().mvae_linear_wgrad_batched(arr, len(chunk), _stream()), 'mvae_linear_wgrad_batched')
+
+
 # ---------------------------------------------------------------------------- grouped Linear
 # G problems of one shape per launch: activations are [G, rows, width] tensors, parameters are
 # (tensor of group 0, stride in floats to the same tensor of the next group) -- the experts' slices

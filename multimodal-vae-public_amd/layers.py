@@ -389,7 +389,10 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             g = g.reshape(x.shape[0], -1)
             if g.stride(1) != 1:
                 g = g.contiguous()
-            side(lambda op=op, g=g, x=x: _lin_wgrad(op, g, x))
+            if isinstance(deferred, WgradBatch):
+                deferred.add_linear(op, g, x)
+            else:
+                side(lambda op=op, g=g, x=x: _lin_wgrad(op, g, x))
             if defer_input_grad and i == first:
                 return g
             if want_dx:
@@ -458,7 +461,8 @@ def _conv_out_shape(op, x):
     return (Bn, m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4)
 
 
-def _lin_wgrad(op, g, x):
+def _lin_wgrad_targets(op):
+    """(dw, db, accumulate) of a Linear / paired-heads op; marks the gradients as written."""
     if op.kind == 'lin':
         m = op.mod
         dw, acc = grad_target(m.weight)
@@ -467,18 +471,59 @@ def _lin_wgrad(op, g, x):
             db, acc_b = grad_target(m.bias)
             if acc_b != acc:
                 raise RuntimeError('Linear weight/bias gradients out of sync')
-        K.linear_wgrad(g, x, dw, db, accumulate=acc)
-    else:
-        a, b = op.mod.heads
-        arena = a.weight._arena
-        acc = a.weight.grad is not None
-        for p in (a.weight, a.bias, b.weight, b.bias):
-            if (p.grad is not None) != acc:
-                raise RuntimeError('paired-head gradients out of sync')
-            grad_target(p)
-        _, dw = arena.joined(a.weight, b.weight)
-        _, db = arena.joined(a.bias, b.bias)
-        K.linear_wgrad(g, x, dw, db, accumulate=acc)
+        return dw, db, acc
+    a, b = op.mod.heads
+    arena = a.weight._arena
+    acc = a.weight.grad is not None
+    for p in (a.weight, a.bias, b.weight, b.bias):
+        if (p.grad is not None) != acc:
+            raise RuntimeError('paired-head gradients out of sync')
+        grad_target(p)
+    _, dw = arena.joined(a.weight, b.weight)
+    _, db = arena.joined(a.bias, b.bias)
+    return dw, db, acc
+
+
+def _lin_wgrad(op, g, x):
+    dw, db, acc = _lin_wgrad_targets(op)
+    K.linear_wgrad(g, x, dw, db, accumulate=acc)
+
+
+class WgradBatch(list):
+    """A ``deferred`` list for ``backward_tape`` that turns the Linear weight gradients of the chain into ONE
+    launch (``K.linear_wgrad_batched``): nothing on the data-gradient chain reads them, so they need not sit
+    between its launches.  ``flush()`` issues the batch (and any other queued closure) on the current stream;
+    the entries keep dy / x alive until then."""
+
+    def add_linear(self, op, g, x):
+        self.append(('lin', op, g, x))
+
+    def flush(self):
+        items, seen = [], set()
+
+        def issue():
+            if len(items) == 1:
+                K.linear_wgrad(*items[0][:4], accumulate=items[0][4])
+            elif items:
+                K.linear_wgrad_batched(items)
+            del items[:]
+            seen.clear()
+
+        for e in self:
+            if not isinstance(e, tuple):
+                e()
+                continue
+            _, op, g, x = e
+            dw, db, acc = _lin_wgrad_targets(op)
+            if dw.data_ptr() in seen:
+                issue()                     # a second contribution to the same gradient: keep the order
+            if K.wgrad_batchable(g, x):
+                seen.add(dw.data_ptr())
+                items.append((g, x, dw, db, acc))
+            else:
+                K.linear_wgrad(g, x, dw, db, accumulate=acc)
+        issue()
+        del self[:]
 
 
 # ----------------------------------------------------------------------------- grouped executor

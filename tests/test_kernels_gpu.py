@@ -93,6 +93,42 @@ def test_linear_wgrad(M, N, Kd):
     assert_close(dw2, dy.t() @ x, 'wgrad no bias')
 
 
+@pytest.mark.parametrize('shapes', [
+    [(1024, 512, 64), (1024, 512, 512), (1024, 512, 512), (1024, 784, 512)],       # MNIST image decoder
+    [(512, 128, 512), (512, 512, 512), (512, 512, 784)],                            # MNIST image encoder
+    [(100, 33, 70), (7, 40, 40), (257, 96, 32)],                                    # ragged everything
+    [(64, 32, 32)] * 17,                                                            # more than one launch's worth
+])
+def test_linear_wgrad_batched(shapes):
+    """Several Linear weight gradients in one launch == each one alone (same arithmetic: bit-equal)."""
+    items, refs = [], []
+    for q, (M, N, Kd) in enumerate(shapes):
+        dy, x = g(M, N, seed=100 + q), g(M, Kd, seed=200 + q)
+        dw = torch.full((N, Kd), 7.0, device=DEV)
+        db = torch.full((N,), 3.0, device=DEV) if q % 3 != 2 else None
+        acc = (q % 2 == 1)
+        items.append((dev(dy), dev(x), dw, db, acc))
+        refs.append((dy, x, acc))
+    assert all(K.wgrad_batchable(it[0], it[1]) for it in items)
+    K.linear_wgrad_batched(items)
+    for (dyd, xd, dw, db, acc), (dy, x, _) in zip(items, refs):
+        rw = dy.t() @ x + (7.0 if acc else 0.0)
+        assert_close(dw, rw, 'batched dw')
+        if db is not None:
+            assert_close(db, dy.sum(0) + (3.0 if acc else 0.0), 'batched db')
+        # the single-problem launch of the same problem gives the same bits (when it takes the direct path)
+        dw1 = torch.full_like(dw, 7.0); db1 = None if db is None else torch.full_like(db, 3.0)
+        K.linear_wgrad(dyd, xd, dw1, db1, accumulate=acc)
+        assert_close(dw, dw1.cpu(), 'batched vs single', tol=1e-6)
+
+
+def test_linear_wgrad_batched_rejects_shared_gradient():
+    dy, x = dev(g(64, 32, seed=1)), dev(g(64, 32, seed=2))
+    dw = torch.empty(32, 32, device=DEV)
+    with pytest.raises(RuntimeError):
+        K.linear_wgrad_batched([(dy, x, dw, None, False), (dy, x, dw, None, True)])
+
+
 def test_linear_strided_views():
     """Row-strided operands: column slices of a [B, 2D] head and a column of the [rows, 18] logits."""
     M, Kd = 96, 64
