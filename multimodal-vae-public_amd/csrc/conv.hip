@@ -34,6 +34,8 @@ struct LdIm2colT {
     const float *x; ConvGeom g; int Mtot;
     int base, kq; unsigned vh, vwq;
     BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
+    static constexpr bool fast = true;
+    __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int) {
         const int m = tile0 + (t % TILE);
         kq = t / TILE;
@@ -169,7 +171,8 @@ struct LdIm2colR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = false;
+    static constexpr bool RMAJOR = true, PARTS = false, fast = false;
+    __device__ void begin(int, int) {}
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
@@ -210,6 +213,8 @@ struct LdDgradDyT {
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
     BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
+    static constexpr bool fast = true;
+    __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
         const int ph = cls / g.stride, pw = cls % g.stride;
         const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
@@ -345,7 +350,8 @@ struct LdDgradDyR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = false;
+    static constexpr bool RMAJOR = true, PARTS = false, fast = false;
+    __device__ void begin(int, int) {}
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
@@ -376,6 +382,23 @@ template <int T> using LdRowsMNC = LdRowsMNT<T, true, MVAE_CONV_BK>;
 template <int T> using LdRowsMNSC = LdRowsMNT<T, false, MVAE_CONV_BK>;
 
 // wgrad operands: the reduction runs over k = (b,oh,ow); lanes along k (spatially contiguous).
+//
+// Full k-tiles take the buffer path (gemm_core.h): the address of an element is a PER-LANE part that depends on
+// the lane's reduction index k -- (image, output row, output column) -- plus a part that is the same for the
+// whole wave (which channel / tap row the element v belongs to), so the lane part goes into voffset and the
+// element part into the scalar soffset of the load: no per-element vector arithmetic.  The lane part is not
+// recomputed from k each k-step (two integer divisions by run-time values: ~100 VALU instructions, on an fp32-MFMA
+// kernel the whole story -- 6.6 VALU per MFMA, 60-80 TFLOP/s) but ADVANCED: k grows by 32 per k-step, i.e. by
+// q32 = 32 / OHW whole images and r32 = 32 % OHW positions, with at most one column wrap and one image wrap.
+struct KWalk {              // a lane's position on the k axis of a weight-gradient reduction
+    int sp, oh, ow;         // position inside the image, its row and column
+    __device__ void start(int k, int OH, int OW) {
+        const int ohw = OH * OW;
+        const int b = k / ohw;
+        sp = k - b * ohw; oh = sp / OW; ow = sp - oh * OW;
+    }
+};
+
 // P: element (i = co, k) = dy[b][co][oh][ow].
 template <int TILE_>
 struct LdWgradDy {
@@ -385,36 +408,65 @@ struct LdWgradDy {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g;
     int ioff, nvalid;       // ioff = i * OHW of element 0; nvalid = how many of the NV rows are < Cout
+    bool fast;              // buffer path usable: the tile is full along i and dy is below 2 GiB
+    BufBase blk; int voff, sp, k_pos;                 // buffer path: lane offset (bytes) of element 0, walk state
     __device__ void init(int tile0, int t, int) {
         const int ib = tile0 + t / BK;
         ioff = ib * g.OH * g.OW;
         nvalid = (g.Cout - ib + ISTEP - 1) / ISTEP;     // rows ib + v*ISTEP < Cout  <=>  v < nvalid
+        fast = tile0 + TILE <= g.Cout && (size_t)g.B * g.Cout * g.OH * g.OW * 4 < (1ull << 31);
+        blk = buf_base(dy);
     }
-    __device__ void load(int k0, int kend, int t, Regs &rg) const { load_part(k0, kend, t, rg, 0, 1); }
-    static constexpr bool PARTS = true;
-    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
+    __device__ void begin(int kbeg, int t) {
+        const int ohw = g.OH * g.OW;
+        const int k = kbeg + (t % BK);
+        const int b = k / ohw;
+        sp = k - b * ohw;
+        voff = (b * g.Cout * ohw + sp + ioff) * 4;
+        k_pos = kbeg;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
-        const int b = k / ohw, sp = k - b * ohw;
-        const float *src = dy + (size_t)b * g.Cout * ohw + sp + ioff;
+        const int b = k / ohw, spx = k - b * ohw;
+        const float *src = dy + (size_t)b * g.Cout * ohw + spx + ioff;
         const int safe = (int)(dy - src);
         const int nv = (k < kend) ? nvalid : 0;
-        if (part == 0) rg.ok = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);      // bit v set iff v < nv
+        rg.ok = nv >= 32 ? 0xffffffffu : ((1u << nv) - 1u);      // bit v set iff v < nv
+#pragma unroll
+        for (int v = 0; v < NV; ++v) rg.v[v] = src[(v < nv) ? v * ISTEP * ohw : safe];
+    }
+    static constexpr bool PARTS = true;
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) {
+        const int ohw = g.OH * g.OW;
+        if (part == 0) {
+            const bool adv = k0 != k_pos;             // block-uniform: the next k-tile (or the same one again)
+            const int q32 = BK / ohw, r32 = BK - q32 * ohw;
+            sp += adv ? r32 : 0;
+            const bool wrap = sp >= ohw;
+            sp -= wrap ? ohw : 0;
+            voff += (adv ? (r32 + q32 * g.Cout * ohw) * 4 : 0) + (wrap ? (g.Cout - 1) * ohw * 4 : 0);
+            k_pos = k0;
+        }
+        const i32x4_t rs = buf_rsrc(blk, 0);
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts) rg.v[v] = src[(v < nv) ? v * ISTEP * ohw : safe];
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = llvm_raw_buffer_load_f32(rs, voff, v * ISTEP * ohw * 4, 0);
     }
     static constexpr bool RMAJOR = false;
     static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
-    __device__ void store(Tile L, int t, const Regs &rg) const { store_part(L, t, rg, 0, 1); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int kl = t % BK, ib = t / BK;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
     __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int kl = t % BK, ib = t / BK;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
-                L[kl][ib + v * ISTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+            if (MVAE_IN_PART(v, NV, part, nparts)) L[kl][ib + v * ISTEP] = rg.v[v];
     }
 };
 
@@ -427,14 +479,26 @@ struct LdWgradX {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int J;
     int joff, jq, nvalid;
+    bool fast;              // buffer path usable: the tile is full along j and x is below 2 GiB
+    BufBase blk; int voff, k_pos; KWalk w;            // buffer path: lane offset (bytes) of tap (jq >> 2, jq & 3), walk state
     __device__ void init(int tile0, int t, int) {
         jq = t / BK;                                  // kw = jq & 3, kh = (jq >> 2) + 2*(v & 1), ci = j0/16 + (v >> 1)
         joff = (tile0 >> 4) * g.H * g.W + (jq >> 2) * g.W + (jq & 3);
         nvalid = (J - tile0 - jq + JSTEP - 1) / JSTEP;
+        fast = tile0 + TILE <= J && ((size_t)g.B * g.Cin * g.H * g.W + g.pad * g.W + g.pad) * 4 < (1ull << 31);
+        // voffset is UNSIGNED to the hardware: the base sits pad rows + pad columns before x, so that the offset
+        // of a lane whose own tap (jq >> 2, jq & 3) is above / left of the image but whose tap two rows down
+        // (soffset) is inside stays non-negative
+        blk = buf_base(x - (g.pad * g.W + g.pad));
     }
-    __device__ void load(int k0, int kend, int t, Regs &rg) const { load_part(k0, kend, t, rg, 0, 1); }
-    static constexpr bool PARTS = true;
-    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
+    __device__ void begin(int kbeg, int t) {
+        const int k = kbeg + (t % BK);
+        w.start(k, g.OH, g.OW);
+        const int b = k / (g.OH * g.OW);
+        voff = (b * g.Cin * g.H * g.W + w.oh * g.stride * g.W + w.ow * g.stride + joff) * 4;    // relative to blk
+        k_pos = kbeg;
+    }
+    __device__ void load(int k0, int kend, int t, Regs &rg) const {
         const int k = k0 + (t % BK);
         const int ohw = g.OH * g.OW;
         const int b = k / ohw, sp = k - b * ohw;
@@ -451,23 +515,53 @@ struct LdWgradX {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const bool ok = ((v & 1) ? ok1 : ok0) && v < nvalid;
-            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
-                rg.v[v] = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
+            rg.v[v] = src[ok ? (v >> 1) * hw + 2 * (v & 1) * g.W : safe];
             okbits |= (ok ? 1u : 0u) << v;
         }
-        if (part == 0) rg.ok = okbits;
+        rg.ok = okbits;
+    }
+    static constexpr bool PARTS = true;
+    int voff_a, voff_b;     // this k-step's offsets for the even / odd elements (tap rows jq>>2 and (jq>>2)+2), or BUF_OOB
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) {
+        const int hw = g.H * g.W;
+        if (part == 0) {
+            const int ohw = g.OH * g.OW, s = g.stride;
+            const bool adv = k0 != k_pos;             // block-uniform
+            const int q32 = BK / ohw, r32 = BK - q32 * ohw;
+            const int ra = r32 / g.OW, rc = r32 - ra * g.OW;            // r32 positions = ra rows + rc columns (uniform)
+            w.ow += adv ? rc : 0; w.oh += adv ? ra : 0;
+            const bool cw = w.ow >= g.OW;             // column wrap: next output row
+            w.ow -= cw ? g.OW : 0; w.oh += cw ? 1 : 0;
+            const bool iwrap = w.oh >= g.OH;          // image wrap
+            w.oh -= iwrap ? g.OH : 0;
+            voff += (adv ? (q32 * g.Cin * hw + ra * s * g.W + rc * s) * 4 : 0) + (cw ? (s * g.W - g.OW * s) * 4 : 0) +
+                    (iwrap ? (g.Cin * hw - g.OH * s * g.W) * 4 : 0);
+            k_pos = k0;
+            const int iw = w.ow * s - g.pad + (jq & 3), ihq = w.oh * s - g.pad + (jq >> 2);
+            const bool okw = iw >= 0 && iw < g.W;
+            voff_a = (okw && ihq >= 0 && ihq < g.H) ? voff : BUF_OOB;
+            voff_b = (okw && ihq + 2 >= 0 && ihq + 2 < g.H) ? voff : BUF_OOB;
+        }
+        const i32x4_t rs = buf_rsrc(blk, 0);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (MVAE_IN_PART(v, NV, part, nparts))
+                rg.v[v] = llvm_raw_buffer_load_f32(rs, (v & 1) ? voff_b : voff_a, ((v >> 1) * hw + 2 * (v & 1) * g.W) * 4, 0);
     }
     static constexpr bool RMAJOR = false;
     static constexpr int ROWS = BK, PITCH = TILE + 1;       // odd pitch: the lanes of a store run along k (one row each)
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) { return frag_kmajor(L, k0, row); }
-    __device__ void store(Tile L, int t, const Regs &rg) const { store_part(L, t, rg, 0, 1); }
+    __device__ void store(Tile L, int t, const Regs &rg) const {
+        const int kl = t % BK, jb = t / BK;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+    }
     __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int kl = t % BK, jb = t / BK;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (v >= part * NV / nparts && v < (part + 1) * NV / nparts)
-                L[kl][jb + v * JSTEP] = rg.v[v] * mask0((rg.ok >> v) & 1u);
+            if (MVAE_IN_PART(v, NV, part, nparts)) L[kl][jb + v * JSTEP] = rg.v[v];
     }
 };
 

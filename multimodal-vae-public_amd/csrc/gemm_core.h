@@ -134,6 +134,8 @@ struct LdRowsKT {
     int r0;
     int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from row r0, k0 (or BUF_OOB)
     BufBase blk;                                      //              address of (row r0, k = 0)
+    static constexpr bool fast = true;
+    __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
         r0 = tile0; src += (size_t)cls * cls_stride;
         if (VEC) {
@@ -225,6 +227,8 @@ struct LdRowsMNT {
     int r0;
     int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from (k0, r0) (or BUF_OOB)
     BufBase blk;                                      //              address of (k = 0, r0)
+    static constexpr bool fast = true;
+    __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
         r0 = tile0; src += (size_t)cls * cls_stride;
         if (VEC) {
@@ -553,7 +557,9 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // for a few hundred cycles per k-step and the pipe idles unless another block's wave happens to be in its
     // MFMA phase (tools/mfma_peak: the pipe itself sustains 154.6 TFLOP/s from one wave per SIMD).
     constexpr bool CAN_IL = (NT == NTHREADS) && P::PARTS && Q::PARTS && MVAE_INTERLEAVE;
-    const bool il = CAN_IL && nsteps > 0 && (kend - kbeg) % BKK == 0;
+    const bool full = nsteps > 0 && (kend - kbeg) % BKK == 0 && p.fast && q.fast;    // block-uniform
+    const bool il = CAN_IL && full;
+    p.begin(kbeg, t); q.begin(kbeg, t);
     if (CAN_IL && il && !DEEP) {
         p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
         p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
@@ -662,7 +668,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             }
         };
         constexpr bool CAN_FULL = P::PARTS && Q::PARTS && MVAE_INTERLEAVE;
-        if (CAN_FULL && nsteps > 0 && (kend - kbeg) % BKK == 0) {
+        if (CAN_FULL && full) {
             if constexpr (CAN_FULL) phased(std::true_type{});
         } else {
             phased(std::false_type{});

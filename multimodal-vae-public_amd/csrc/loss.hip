@@ -154,37 +154,43 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(ElboParts parts, floa
         for (size_t i = z4 * 4 + (size_t)blockIdx.x * 1024 + threadIdx.x; i < zero_n; i += zstride) zero[i] = 0.f;
     }
     if (blockIdx.x != 0) return;
-    __shared__ float red[16];
+    // every (part, group) sum is one wave's job (16 waves take them round-robin: lane-strided partial sums in a
+    // fixed order, then the wave reduction), parked in LDS; thread 0 then adds them up part by part, group by
+    // group -- one barrier instead of two per group (7 groups of 512 rows: 13 -> 4 us on the MNIST step's
+    // critical path)
+    __shared__ float gsum[MVAE_ELBO_MAX_PARTS * MVAE_ELBO_MAX_TERMS];
     __shared__ float acc[MVAE_ELBO_MAX_TERMS + 1];
-    for (int t = threadIdx.x; t <= T; t += 1024) acc[t] = 0.f;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int slot = 0;
     for (int q = 0; q < parts.n; ++q) {
         const mvae_elbo_part &p = parts.p[q];
-        float part_total = 0.f;
-        if (p.rows_per_group == 1) {        // a table of ready sums (celeba19's attribute terms): sequential, in order
-            if (threadIdx.x == 0) {
-                for (int g = 0; g < p.groups; ++g) {
-                    const float v = (p.coef ? p.coef[g] : 1.f) * p.rows[g];
-                    acc[p.term_of ? p.term_of[g] : p.first_term + g] += v;
-                    part_total += v;
-                }
-                acc[T] += part_total;
-            }
-            __syncthreads();
-            continue;
-        }
-        for (int g = 0; g < p.groups; ++g) {
+        if (p.rows_per_group == 1) continue;         // a table of ready sums: read directly below
+        for (int g = 0; g < p.groups; ++g, ++slot) {
+            if ((slot & 15) != wave) continue;
+            const float *r = p.rows + (size_t)g * p.rows_per_group;
             float s = 0.f;
-            for (int i = threadIdx.x; i < p.rows_per_group; i += 1024) s += p.rows[(size_t)g * p.rows_per_group + i];
-            s = block_sum(s, red) * (p.coef ? p.coef[g] : 1.f);
-            if (threadIdx.x == 0) acc[p.term_of ? p.term_of[g] : p.first_term + g] += s;
-            part_total += s;
+            for (int i = lane; i < p.rows_per_group; i += 64) s += r[i];
+            s = wave_sum(s);
+            if (lane == 0) gsum[slot] = s;
         }
-        if (threadIdx.x == 0) acc[T] += part_total;
-        __syncthreads();
     }
-    for (int t = threadIdx.x; t <= T; t += 1024) elbo[t] = acc[t];
-    if (threadIdx.x == 0 && counter) *counter += counter_inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 0; t <= T; ++t) acc[t] = 0.f;
+        slot = 0;
+        for (int q = 0; q < parts.n; ++q) {
+            const mvae_elbo_part &p = parts.p[q];
+            float part_total = 0.f;
+            for (int g = 0; g < p.groups; ++g) {
+                const float v = (p.rows_per_group == 1 ? p.rows[g] : gsum[slot++]) * (p.coef ? p.coef[g] : 1.f);
+                acc[p.term_of ? p.term_of[g] : p.first_term + g] += v;
+                part_total += v;
+            }
+            acc[T] += part_total;
+        }
+        for (int t = 0; t <= T; ++t) elbo[t] = acc[t];
+        if (counter) *counter += counter_inc;
+    }
 }
 
 int bce_launch(BceArgs a, hipStream_t st) {
@@ -253,6 +259,7 @@ MVAE_EXPORT int mvae_elbo_reduce(const mvae_elbo_part *parts, int n_parts, float
         ps.p[q] = parts[q];
         if (!ps.p[q].rows || ps.p[q].groups <= 0 || ps.p[q].rows_per_group <= 0) return MVAE_ERR_ARG;
         if (!ps.p[q].term_of && (ps.p[q].first_term < 0 || ps.p[q].first_term + ps.p[q].groups > T)) return MVAE_ERR_ARG;
+        if (ps.p[q].rows_per_group > 1 && ps.p[q].groups > MVAE_ELBO_MAX_TERMS) return MVAE_ERR_ARG;
     }
     size_t blocks = zero ? (zero_n / 4 + 1023) / 1024 : 1;
     if (blocks < 1) blocks = 1;
