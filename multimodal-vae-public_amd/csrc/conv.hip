@@ -721,38 +721,39 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     const int P = g.OH * g.OW;                      // positions per image (<= 32)
     const int n0 = blockIdx.y * NI, ci0 = blockIdx.x * 4;
     const int K = g.Cout, J = g.Cin * 16;
-    // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass
+    // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass.  Buffer loads
+    // (gemm_core.h): the lane part of the address -- image, position, k parity -- is a constant voffset (BUF_OOB
+    // for the 3 pad rows / images past the batch: zero fill), the k-step part rides the scalar soffset; nothing
+    // on the vector ALU (K % BK == 0 is a launch condition).
     const int pr_ = t & 127, pkq = t >> 7;
     const int pimg = pr_ / P, ppos = pr_ - pimg * P;
     const bool pok = pimg < NI && n0 + pimg < g.B;
-    const float *psrc = dy + ((size_t)(pok ? n0 + pimg : 0) * K) * P + (pok ? ppos : 0);
+    const int pvoff = pok ? ((pimg * K + pkq) * P + ppos) * 4 : BUF_OOB;
+    const BufBase pblk = buf_base(dy + (size_t)n0 * K * P);
     // Q loader: weight rows are contiguous in (ci, tap): 16 float4 per k row, 2 per thread
-    const float *qsrc = w + (size_t)ci0 * 16;
-    float pr[16], pm[16];
+    const BufBase qblk = buf_base(w + (size_t)ci0 * 16);
+    int qvoff[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int f = t + 256 * v;
+        qvoff[v] = ((f >> 4) * J + (f & 15) * 4) * 4;
+    }
+    float pr[16];
     float4 qr[2];
-    float qm[2];
     auto load = [&](int k0) {
+        const i32x4_t prs = buf_rsrc(pblk, 0), qrs = buf_rsrc(qblk, (size_t)k0 * J);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int k = k0 + pkq + 2 * v;
-            pm[v] = (pok && k < K) ? 1.f : 0.f;
-            pr[v] = psrc[(size_t)min(k, K - 1) * P];
-        }
+        for (int v = 0; v < 16; ++v) pr[v] = llvm_raw_buffer_load_f32(prs, pvoff, (k0 + 2 * v) * P * 4, 0);
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int f = t + 256 * v, k = k0 + (f >> 4), c4 = (f & 15) * 4;
-            qm[v] = (k < K) ? 1.f : 0.f;
-            qr[v] = *reinterpret_cast<const float4 *>(qsrc + (size_t)min(k, K - 1) * J + c4);
-        }
+        for (int v = 0; v < 2; ++v) qr[v] = buf_load4(qrs, qvoff[v]);
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) Ps(buf)[pkq + 2 * v][pr_] = pr[v] * pm[v];
+        for (int v = 0; v < 16; ++v) Ps(buf)[pkq + 2 * v][pr_] = pr[v];
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int f = t + 256 * v;
-            *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) =
-                make_float4(qr[v].x * qm[v], qr[v].y * qm[v], qr[v].z * qm[v], qr[v].w * qm[v]);
+            *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) = qr[v];
         }
     };
     f32x16 acc[2];
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load((s + 1) * BK);
+        load(min(s + 1, nsteps - 1) * BK);          // unconditional (the last trip re-reads its own tile): no branch
         float a0[2], b0;
         a0[0] = Ps(buf)[lrow][wi * 64 + lcol]; a0[1] = Ps(buf)[lrow][wi * 64 + 32 + lcol];
         b0 = Qs(buf)[lrow][wj * 32 + lcol];
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             __builtin_amdgcn_sched_barrier(0);
             a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
         }
-        if (s + 1 < nsteps) store(buf ^ 1);
+        store(buf ^ 1);
         __syncthreads();
     }
     // col2im: park the 128 (packed positions) x 64 (4 channels x 16 taps) tile in LDS ...
@@ -839,7 +840,8 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
 }
 
 inline bool conv_dgrad_s1_ok(const ConvGeom &g, const float *w) {
-    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && aligned16(w);
+    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && g.Cout % BK == 0 && aligned16(w) &&
+           (size_t)128 * g.Cout * g.OH * g.OW * 4 < (1ull << 31);
 }
 
 inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act, const float *dpre, ConvGeom g,
