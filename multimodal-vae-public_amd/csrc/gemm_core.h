@@ -56,6 +56,12 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #define MVAE_TUNE(f) 0
 #endif
 
+// raw buffer loads, declared on the LLVM intrinsics (see "buffer loads for the main loops" below)
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float llvm_raw_buffer_load_f32(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
 namespace {
 
 constexpr int BK = 32;
@@ -91,10 +97,6 @@ __device__ __forceinline__ float4 frag_kmajor(float (*L)[PITCH_], int k0, int ro
 // (The loads are declared on the LLVM intrinsics: hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 emits a
 // ONE-dword load.  The block's base address is pinned to scalar registers with readfirstlane in init(); left to
 // itself the compiler kept it in vector registers and wrapped every load in a waterfall loop.)
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float llvm_raw_buffer_load_f32(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 constexpr int BUF_OOB = (int)0x80000000u;
 struct BufBase { unsigned lo, hi; };                  // a block-uniform address, held in scalar registers
 __device__ __forceinline__ BufBase buf_base(const float *p) {
@@ -363,6 +365,7 @@ struct SplitSink {
     float *rowsum_final; int rowsum_final_accumulate;   // split launches: where the finish kernel puts the summed row sums
     size_t cls_region;                        // grouped + split: class c keeps its partials at ws + c * cls_region
     size_t rowsum_final_cls_stride;           //                  and its bias gradient at rowsum_final + c * this
+    int xcd_map;                              // 1: re-map the launch order to XCD-local output sub-grids (see igemm_kernel)
 };
 
 // finish kernels of a grouped launch: one grid slice per class
@@ -423,8 +426,19 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     const int wi = wq / WGN, wj = wq % WGN;
     const bool mover = (NT == NTHREADS) || t < NTHREADS;
     const int tiles_j = gridDim.x / sink.ncls;
-    const int cls = blockIdx.x / tiles_j;
-    const int i0 = blockIdx.y * BM, j0 = (blockIdx.x - cls * tiles_j) * BN, split = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (sink.xcd_map) {
+        // Workgroups go to the 8 XCDs round-robin in launch order, and each XCD has its own L2: with the j tile on
+        // blockIdx.x every XCD touches every row band of P (a 1024 x 512 x 512 Linear pulled 22 MB through the
+        // fabric for 5 MB of operands).  Re-map the launch order so that XCD x owns a (tiles_i / 4) x (tiles_j / 2)
+        // sub-grid of the output: P is fetched by 2 XCDs, Q by 4 (host checks divisibility, one class, no split).
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+        const unsigned sj = gridDim.x >> 1, si = gridDim.y >> 2;
+        const unsigned ti = slot / sj, tj = slot - ti * sj;
+        bx = (int)((xcd & 1u) * sj + tj); by = (int)((xcd >> 1) * si + ti);
+    }
+    const int cls = bx / tiles_j;
+    const int i0 = by * BM, j0 = (bx - cls * tiles_j) * BN, split = blockIdx.z;
     const int kbeg = split * klen;
     const int kend = min(K, kbeg + klen);
     const int nsteps = (kend - kbeg + BKK - 1) / BKK;
@@ -456,7 +470,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // db = sum over the reduction axis of P (dy^T): the bias gradient for free.  The 256 movers split the
     // tile: thread t owns row t % BM and every RS_PARTS-th k of it; parts are summed through LDS at the end.
     constexpr int RS_PARTS = NTHREADS / BM;
-    const bool rs_block = ROWSUM && blockIdx.x == cls * tiles_j;      // block-uniform
+    const bool rs_block = ROWSUM && bx == cls * tiles_j;              // block-uniform
     const int rs_row = t % BM, rs_part = t / BM;
     float rsum = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -866,7 +880,7 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; };
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; };   // xcd: XCD-local output sub-grids (Linear)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
@@ -969,6 +983,7 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         PLD<TM> p; make_p(p);                                                                    \
         QLD<TN> q; make_q(q);                                                                    \
         dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
+        sink.xcd_map = (pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
         constexpr size_t tile_b = 2 * (PLD<TM>::ROWS * PLD<TM>::PITCH + QLD<TN>::ROWS * QLD<TN>::PITCH) * sizeof(float); \
         constexpr size_t red_b = (WGM * WGN < 4 && KW > 1)                                       \
             ? (size_t)KW * TM * (TN + 1) * sizeof(float)              /* cooperative epilogue */ \
@@ -1039,6 +1054,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     s.stride = (size_t)I * J + (rowsum ? I : 0);
     s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
     s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0; s.cls_region = 0; s.rowsum_final_cls_stride = 0;
+    s.xcd_map = 0;
     return s;
 }
 

@@ -3,6 +3,10 @@
 #include "gemm_core.h"
 #include "linear_direct.h"
 
+#ifndef MVAE_XCD_MAP
+#define MVAE_XCD_MAP 1          // Linear launches: XCD-local output sub-grids (gemm_core.h, igemm_kernel)
+#endif
+
 
 // ==========================================================================================
 // C ABI
@@ -44,6 +48,7 @@ static int linear_fwd_impl(const float *x, int ldx, const float *w, const float 
     // gr: a = x stride, b = w stride, c = bias stride, d = pre/act stride
     const bool vec = aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 && gr.b % 4 == 0;
     Plan pl = make_plan(M, N, K, ws != nullptr, PLAN_FWD, gr.G, vec);
+    pl.xcd = MVAE_XCD_MAP;
     SplitSink sink = make_sink(ws, M, N, false);
     sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
     if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
@@ -65,6 +70,7 @@ static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *d
     const bool vec = aligned16(dy) && aligned16(w) && lddy % 4 == 0 && N % 4 == 0 && K % 4 == 0 && gr.a % 4 == 0 &&
                      gr.b % 4 == 0;
     Plan pl = make_plan(M, K, N, ws != nullptr, PLAN_FWD, gr.G, vec);
+    pl.xcd = MVAE_XCD_MAP;
     SplitSink sink = make_sink(ws, M, K, false);
     sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
     if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
@@ -86,6 +92,7 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
     const bool vec = aligned16(dy) && aligned16(x) && lddy % 4 == 0 && ldx % 4 == 0 && N % 4 == 0 && K % 4 == 0 &&
                      gr.a % 4 == 0 && gr.b % 4 == 0;
     Plan pl = make_plan(N, K, M, ws != nullptr, PLAN_LIN_WGRAD, gr.G, vec);
+    pl.xcd = MVAE_XCD_MAP;
     SplitSink sink = make_sink(ws, N, K, db != nullptr);
     sink.ncls = gr.G; sink.cls_region = (size_t)pl.splits * sink.stride;
     if (pl.splits > 1 && ws_bytes < gr.G * sink.cls_region * sizeof(float)) return MVAE_ERR_WS;
