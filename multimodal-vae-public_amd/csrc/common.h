@@ -12,6 +12,7 @@ static inline int mvae_launch_status() {
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 __device__ __forceinline__ bool aligned16_dev(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // sigmoid / swish as the reference composes them: x * (1 / (1 + exp(-x))) (mnist/model.py:166-169),

@@ -4,6 +4,9 @@
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
+#ifndef MVAE_CONVT_SMALL2
+#define MVAE_CONVT_SMALL2 1     // <= 4-channel transposed conv: two positions per thread, weights through scalar loads
+#endif
 #ifndef MVAE_CONV_BK
 #define MVAE_CONV_BK 32
 #endif
@@ -679,6 +682,89 @@ __global__ __launch_bounds__(256) void convT_small_kernel(const float *dy, const
     }
 }
 
+// The same, two horizontally adjacent positions per thread (even OW): the 3 x 4 neighbourhood is 9 loads
+// (a float2 and two scalars per row) for 96 FMAs per channel pair instead of 18, the outputs leave as float4 rows,
+// and the weights are read at block-uniform addresses straight from global memory -- scalar loads into SGPRs that
+// the FMAs take as operands -- instead of twelve LDS broadcasts per input channel (the LDS pipe was as busy as
+// the vector ALU: 28 TFLOP/s on ConvTranspose2d(32, 3), celeba/model.py:126).
+template <int C>
+__global__ __launch_bounds__(256) void convT_small2_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                           float *__restrict__ out, float *__restrict__ act,
+                                                           const float *__restrict__ dpre, ConvGeom g, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int OH = g.OH, OW = g.OW, OW2 = OW >> 1;  // dy is [B][Cout][OH][OW]; out [B][C][2*OH][2*OW]
+    const int b0 = (idx % OW2) * 2, a = (idx / OW2) % OH, n = idx / (OW2 * OH);
+    float acc[C][2][4];                             // [channel][output row parity][4 output columns 2*b0 .. 2*b0+3]
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q >> 2][q & 3] = 0.f;
+    const float rm = a > 0 ? 1.f : 0.f, rp = a + 1 < OH ? 1.f : 0.f, cm = b0 > 0 ? 1.f : 0.f, cp = b0 + 2 < OW ? 1.f : 0.f;
+    // clamped (always legal) addresses, 0/1 factors: no load under a branch
+    const int ra = a > 0 ? -OW : 0, rb = a + 1 < OH ? OW : 0, ca = b0 > 0 ? -1 : 0, cb = b0 + 2 < OW ? 2 : 1;
+    const float *src = dy + ((size_t)n * g.Cout * OH + a) * OW + b0;
+    const int plane = OH * OW;
+    // the next channel's neighbourhood is fetched while this one is multiplied (raw values; the 0/1 factors are
+    // applied when the registers are consumed)
+    float nx[3][4];
+    auto fetch = [&](const float *sp) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ro = r == 0 ? ra : (r == 2 ? rb : 0);
+            const float2 mid = *reinterpret_cast<const float2 *>(sp + ro);
+            nx[r][0] = sp[ro + ca]; nx[r][1] = mid.x; nx[r][2] = mid.y; nx[r][3] = sp[ro + cb];
+        }
+    };
+    fetch(src);
+    for (int co = 0; co < g.Cout; ++co) {
+        float d[3][4];                              // rows a-1, a, a+1; columns b0-1 .. b0+2
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float rf = r == 0 ? rm : (r == 2 ? rp : 1.f);
+            d[r][0] = nx[r][0] * (rf * cm); d[r][1] = nx[r][1] * rf; d[r][2] = nx[r][2] * rf; d[r][3] = nx[r][3] * (rf * cp);
+        }
+        src += (co + 1 < g.Cout) ? plane : 0;       // the last trip re-reads its own plane: no load under a branch
+        fetch(src);
+        const float *wc = w + (size_t)co * C * 16;  // block-uniform
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float *wp = wc + c * 16;          // [kh][kw]
+#pragma unroll
+            for (int pos = 0; pos < 2; ++pos) {     // input column b0 + pos -> output columns 2*(b0+pos), +1
+                const float (*e)[4] = d;
+                const int q = pos;                  // d[.][q] = column b-1, d[.][q+1] = b, d[.][q+2] = b+1
+                // chained FMAs into the accumulator (a sum of four products added afterwards costs a fifth instruction)
+                auto mac4 = [](float acc0, float w0, float x0, float w1, float x1, float w2, float x2, float w3, float x3) {
+                    return fmaf(w3, x3, fmaf(w2, x2, fmaf(w1, x1, fmaf(w0, x0, acc0))));
+                };
+                // output (row parity 0, col parity 0): kh in {1,3} <-> rows a, a-1 ; kw in {1,3} <-> cols b, b-1
+                acc[c][0][2 * pos] = mac4(acc[c][0][2 * pos], wp[5], e[1][q + 1], wp[7], e[1][q], wp[13], e[0][q + 1], wp[15], e[0][q]);
+                // (0,1): kw in {0,2} <-> cols b+1, b
+                acc[c][0][2 * pos + 1] = mac4(acc[c][0][2 * pos + 1], wp[4], e[1][q + 2], wp[6], e[1][q + 1], wp[12], e[0][q + 2], wp[14], e[0][q + 1]);
+                // (1,0): kh in {0,2} <-> rows a+1, a
+                acc[c][1][2 * pos] = mac4(acc[c][1][2 * pos], wp[1], e[2][q + 1], wp[3], e[2][q], wp[9], e[1][q + 1], wp[11], e[1][q]);
+                acc[c][1][2 * pos + 1] = mac4(acc[c][1][2 * pos + 1], wp[0], e[2][q + 2], wp[2], e[2][q + 1], wp[8], e[1][q + 2], wp[10], e[1][q + 1]);
+            }
+        }
+    }
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t o = (((size_t)n * C + c) * H + 2 * a + ph) * W + 2 * b0;     // 16-byte aligned: b0 even, W % 4 == 0
+            float4 v = make_float4(acc[c][ph][0], acc[c][ph][1], acc[c][ph][2], acc[c][ph][3]);
+            if (dpre) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(dpre + o);
+                v.x *= swish_grad_(p4.x); v.y *= swish_grad_(p4.y); v.z *= swish_grad_(p4.z); v.w *= swish_grad_(p4.w);
+            }
+            if (out) *reinterpret_cast<float4 *>(out + o) = v;
+            if (act) *reinterpret_cast<float4 *>(act + o) = make_float4(swishf_(v.x), swishf_(v.y), swishf_(v.z), swishf_(v.w));
+        }
+    }
+}
+
 inline bool conv_dgrad_small_ok(const ConvGeom &g) {
     return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && g.H == 2 * g.OH && g.W == 2 * g.OW &&
            (size_t)g.Cout * g.Cin * 16 * sizeof(float) <= 48 * 1024;
@@ -689,6 +775,18 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
     const int total = g.B * g.OH * g.OW;
     const size_t lds = (size_t)g.Cout * g.Cin * 16 * sizeof(float);
     const dim3 grid((total + 255) / 256), blk(256);
+    if (MVAE_CONVT_SMALL2 && g.OW % 2 == 0 && aligned16(dx ? dx : act) && (!dx || !act || aligned16(act)) && (!dpre || aligned16(dpre)) &&
+        aligned8(dy)) {
+        const int total2 = total / 2;
+        const dim3 grid2((total2 + 255) / 256);
+        switch (g.Cin) {
+            case 1: hipLaunchKernelGGL(convT_small2_kernel<1>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
+            case 2: hipLaunchKernelGGL(convT_small2_kernel<2>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
+            case 3: hipLaunchKernelGGL(convT_small2_kernel<3>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
+            default: hipLaunchKernelGGL(convT_small2_kernel<4>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
+        }
+        return mvae_launch_status();
+    }
     switch (g.Cin) {
         case 1: hipLaunchKernelGGL(convT_small_kernel<1>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
         case 2: hipLaunchKernelGGL(convT_small_kernel<2>, grid, blk, lds, st, dy, w, dx, act, dpre, g, total); break;
