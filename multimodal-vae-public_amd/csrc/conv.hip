@@ -134,20 +134,34 @@ struct LdIm2colR {
     struct Regs { float4 v[NV4]; unsigned ok; };      // raw data + 4 validity bits per group
     const float *x; ConvGeom g; int Mtot;
     int base, gq; unsigned vh, vw;
+    BufBase blk; int voff[NV4][4];                    // full k-tiles: buffer base (first image of the tile) + byte offsets
     __device__ void init(int tile0, int t, int) {
         const int m = tile0 + (t % TILE);
         gq = t / TILE;
         vh = 0; vw = 0; base = 0;
+        const int ohw = g.OH * g.OW, hw = g.H * g.W;
+        const int n0 = tile0 / ohw;                   // block-uniform
+        blk = buf_base(x + (size_t)n0 * g.Cin * hw);
+        int rel = 0;
         if (m < Mtot) {
-            const int ohw = g.OH * g.OW;
             const int b = m / ohw, rem = m - b * ohw;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
             base = (b * g.Cin * g.H + ih0) * g.W + iw0;
+            rel = ((b - n0) * g.Cin * g.H + ih0) * g.W + iw0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (ih0 + q >= 0 && ih0 + q < g.H) vh |= 1u << q;
                 if (iw0 + q >= 0 && iw0 + q < g.W) vw |= 1u << q;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const int gk = gq + GPT * v, kh = gk & 3, cil = gk >> 2;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const bool ok = ((vh >> kh) & 1u) && ((vw >> kw) & 1u);
+                voff[v][kw] = ok ? (rel + cil * hw + kh * g.W + kw) * 4 : BUF_OOB;
             }
         }
     }
@@ -174,8 +188,22 @@ struct LdIm2colR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = false, fast = false;
+    static constexpr bool RMAJOR = true, PARTS = true, fast = true;
     __device__ void begin(int, int) {}
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> 4) * (g.H * g.W));
+#pragma unroll
+        for (int v = 0; v < NV4; ++v)
+            if (MVAE_IN_PART(v, NV4, part, nparts))
+                rg.v[v] = make_float4(buf_load1(rs, voff[v][0]), buf_load1(rs, voff[v][1]), buf_load1(rs, voff[v][2]),
+                                      buf_load1(rs, voff[v][3]));
+    }
+    __device__ __forceinline__ void store_part(float (*L)[BKV_ + LPAD], int t, const Regs &rg, int part, int nparts) const {
+        const int m = t % TILE;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v)
+            if (MVAE_IN_PART(v, NV4, part, nparts)) *reinterpret_cast<float4 *>(&L[m][4 * (gq + GPT * v)]) = rg.v[v];
+    }
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
@@ -309,23 +337,39 @@ struct LdDgradDyR {
     struct Regs { float4 v[NV4]; unsigned ok; };
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, gq; unsigned vh, vw;
+    BufBase blk; int voff[NV4][4];                    // full k-tiles: buffer base (first image of the tile) + byte offsets
     __device__ void init(int tile0, int t, int cls) {
         const int ph = cls / g.stride, pw = cls % g.stride;
         const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
         const int m = tile0 + (t % TILE);
         gq = t / TILE;
         vh = 0; vw = 0; base = 0;
+        const int hw2 = H2 * W2, ohw = g.OH * g.OW;
+        const int n0 = tile0 / hw2;                   // block-uniform
+        blk = buf_base(dy + (size_t)n0 * g.Cout * ohw);
+        int rel = 0;
         if (m < Mtot) {
-            const int hw2 = H2 * W2;
             const int n = m / hw2, rem = m - n * hw2;
             const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
             const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
             const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
             base = (n * g.Cout * g.OH + ohb) * g.OW + owb;
+            rel = ((n - n0) * g.Cout * g.OH + ohb) * g.OW + owb;
 #pragma unroll
             for (int a = 0; a < (1 << TLOG); ++a) {
                 if (ohb - a >= 0 && ohb - a < g.OH) vh |= 1u << a;
                 if (owb - a >= 0 && owb - a < g.OW) vw |= 1u << a;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            const int gk = gq + GPT * v;
+            const int col = TLOG == 1 ? gk : gk >> 2, a_g = TLOG == 1 ? 0 : gk & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = TLOG == 1 ? (q >> 1) : a_g, b = TLOG == 1 ? (q & 1) : q;
+                const bool ok = ((vh >> a) & 1u) && ((vw >> b) & 1u);
+                voff[v][q] = ok ? (rel + col * ohw - a * g.OW - b) * 4 : BUF_OOB;
             }
         }
     }
@@ -353,8 +397,22 @@ struct LdDgradDyR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = false, fast = false;
+    static constexpr bool RMAJOR = true, PARTS = true, fast = true;
     __device__ void begin(int, int) {}
+    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+        const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> (2 * TLOG)) * (g.OH * g.OW));
+#pragma unroll
+        for (int v = 0; v < NV4; ++v)
+            if (MVAE_IN_PART(v, NV4, part, nparts))
+                rg.v[v] = make_float4(buf_load1(rs, voff[v][0]), buf_load1(rs, voff[v][1]), buf_load1(rs, voff[v][2]),
+                                      buf_load1(rs, voff[v][3]));
+    }
+    __device__ __forceinline__ void store_part(float (*L)[BKV_ + LPAD], int t, const Regs &rg, int part, int nparts) const {
+        const int m = t % TILE;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v)
+            if (MVAE_IN_PART(v, NV4, part, nparts)) *reinterpret_cast<float4 *>(&L[m][4 * (gq + GPT * v)]) = rg.v[v];
+    }
     static constexpr int ROWS = TILE, PITCH = BKV + LPAD;
     typedef float (*Tile)[PITCH];
     static __device__ __forceinline__ float4 frag(Tile L, int k0, int row) {
