@@ -172,12 +172,20 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
         eng.step(batches[0][0], batches[0][1], 0.5); opt.step()
         host_s = time.perf_counter() - t0                # host time to enqueue one eager step
         torch.cuda.synchronize()
-        spin = int(_spin_cycles_per_second() * (2.5 * host_s * n_steps + 0.005))
-        with KernelProfile() as prof:
-            torch.cuda._sleep(spin)
-            for i in range(n_steps):
-                eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
-                opt.step()
+        spin_s = 3.0 * host_s * n_steps + 0.010          # the event pairs make the enqueue ~1.5x slower
+        for attempt in range(4):
+            with KernelProfile() as prof:
+                torch.cuda._sleep(int(_spin_cycles_per_second() * spin_s))
+                spin_done = torch.cuda.Event()
+                spin_done.record()
+                for i in range(n_steps):
+                    eng.step(batches[i % 4][0], batches[i % 4][1], 0.5)
+                    opt.step()
+                queue_was_full = not spin_done.query()   # the spin kernel outlasted the whole enqueue
+            if queue_was_full:
+                break
+            torch.cuda.synchronize()
+            spin_s *= 2.0                                # a host stall (allocator, table ring) drained the queue: again
         rows = prof.summary()
         gemm = [r for r in rows if r['name'] in GEMM_COSTS]
         for r in gemm:
@@ -220,6 +228,7 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
     if top is not None:
         roof['top_hbm_kernel'] = {'kernel': top['name'], 'gbs': round(top['gbs'], 1),
                                   'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5)}
+    roof['queue_full_during_enqueue'] = bool(queue_was_full)
     roof['launches_per_step'] = sum(r['calls'] for r in rows) / n_steps
     roof['top_kernels'] = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_total'] / n_steps, 4),
                             'calls_per_step': r['calls'] / n_steps, 'tflops': round(r['tflops'], 2)} for r in gemm[:6]]

@@ -7,6 +7,12 @@
 #ifndef MVAE_CONVT_SMALL2
 #define MVAE_CONVT_SMALL2 1     // <= 4-channel transposed conv: two positions per thread, weights through scalar loads
 #endif
+#ifndef MVAE_MULTI_ITEMS
+#define MVAE_MULTI_ITEMS 4      // (class, j tile) items a block of the conv forward / dgrad forms walks (1: off)
+#endif
+#ifndef MVAE_MULTI_MAXK
+#define MVAE_MULTI_MAXK 256     // ... when the reduction is at most this long (measured: K = 512 tiles lose 2-3 %)
+#endif
 #ifndef MVAE_CONV_BK
 #define MVAE_CONV_BK 32
 #endif
@@ -673,6 +679,7 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     if (pl.wm == 1 && pl.wn == 1 && pl.kw == 1 && pl.wgn == 2 && I >= 128 && !MVAE_TUNE(wm) && !MVAE_TUNE(wn) &&
         cdiv(I, 128) * cdiv(J, 64) >= 384)
         pl.wm = 2;
+    if (K <= MVAE_MULTI_MAXK) pl.items = MVAE_MULTI_ITEMS;      // short reductions: pipeline across consecutive tiles
     EpNCHW e;
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
@@ -1028,6 +1035,7 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
         hipLaunchKernelGGL(repack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wr, g.Cout, g.Cin, s, g.pad);
     }
     Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
+    if (K <= MVAE_MULTI_MAXK) pl.items = MVAE_MULTI_ITEMS;      // short reductions: pipeline across consecutive tiles / classes
     const bool vec = (g.Cin % 4 == 0) && aligned16(wr);
     EpNCHW e;
     e.out = dx; e.act = act; e.dpre = dpre;

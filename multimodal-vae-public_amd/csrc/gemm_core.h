@@ -133,15 +133,16 @@ struct LdRowsKT {
     struct Regs { float4 v[NV]; float m[VEC ? NV : 4 * NV]; };   // raw data + 0/1 masks (applied when staged)
     const float *src; int ld; int R; int Klen;
     size_t cls_stride = 0;                            // per-class (group) source offset
+    size_t cls_off = 0;                               // = class * cls_stride, set by init()
     int r0;
     int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from row r0, k0 (or BUF_OOB)
     BufBase blk;                                      //              address of (row r0, k = 0)
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
-        r0 = tile0; src += (size_t)cls * cls_stride;
+        r0 = tile0; cls_off = (size_t)cls * cls_stride;
         if (VEC) {
-            blk = buf_base(src + (size_t)r0 * ld);
+            blk = buf_base(src + cls_off + (size_t)r0 * ld);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int f = t + NTHREADS * v;
@@ -156,7 +157,7 @@ struct LdRowsKT {
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
             const int r = r0 + f / (BKV / 4), k = k0 + (f % (BKV / 4)) * 4;
-            const float *row = src + (size_t)min(r, R - 1) * ld;
+            const float *row = src + cls_off + (size_t)min(r, R - 1) * ld;
             float4 x;
             if (VEC) {
                 x = *reinterpret_cast<const float4 *>(row + min(k, Klen - 4));
@@ -226,15 +227,16 @@ struct LdRowsMNT {
     static_assert(NV >= 1, "tile too small for 256 mover threads");
     struct Regs { float4 v[NV]; float m[VEC ? NV : 4 * NV]; };
     const float *src; int ld; int R; int Klen; size_t cls_stride;   // cls_stride: per-class source offset
+    size_t cls_off = 0;                               // = class * cls_stride, set by init()
     int r0;
     int voff[VEC ? NV : 1];                           // buffer path: byte offset of float4 v from (k0, r0) (or BUF_OOB)
     BufBase blk;                                      //              address of (k = 0, r0)
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
-        r0 = tile0; src += (size_t)cls * cls_stride;
+        r0 = tile0; cls_off = (size_t)cls * cls_stride;
         if (VEC) {
-            blk = buf_base(src + r0);
+            blk = buf_base(src + cls_off + r0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int f = t + NTHREADS * v;
@@ -248,7 +250,7 @@ struct LdRowsMNT {
         for (int v = 0; v < NV; ++v) {
             const int f = t + NTHREADS * v;
             const int k = k0 + f / V4, r = r0 + (f % V4) * 4;
-            const float *row = src + (size_t)min(k, Klen - 1) * ld;
+            const float *row = src + cls_off + (size_t)min(k, Klen - 1) * ld;
             float4 x;
             if (VEC) {
                 x = *reinterpret_cast<const float4 *>(row + min(r, R - 4));
@@ -305,6 +307,7 @@ template <int T> using LdRowsMNS64 = LdRowsMNT<T, false, 64>;
 
 // Row-major destination D[i * ld + j] with the Linear fusions.
 struct EpRowMajor {
+    static constexpr bool MULTI = false;      // multi-item blocks: conv forms only (set_class here is cumulative)
     float *out; float *act; int ld;           // out = raw / pre-activation result, act = swish(result)
     const float *bias;                        // per column j (Linear fwd)
     const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
@@ -334,6 +337,7 @@ struct EpRowMajor {
 // NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
+    static constexpr bool MULTI = true;
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
     int off;   // per-lane column offset, set by col()
@@ -366,6 +370,8 @@ struct SplitSink {
     size_t cls_region;                        // grouped + split: class c keeps its partials at ws + c * cls_region
     size_t rowsum_final_cls_stride;           //                  and its bias gradient at rowsum_final + c * this
     int xcd_map;                              // 1: re-map the launch order to XCD-local output sub-grids (see igemm_kernel)
+    int tiles_j;                              // j tiles per class (set by the launcher)
+    int items;                                // > 1: a block walks this many consecutive (class, j tile) items (see igemm_kernel)
 };
 
 // finish kernels of a grouped launch: one grid slice per class
@@ -425,7 +431,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     const int kg = wave / WPG, wq = wave % WPG;     // k-group of this wave, its slot inside the group
     const int wi = wq / WGN, wj = wq % WGN;
     const bool mover = (NT == NTHREADS) || t < NTHREADS;
-    const int tiles_j = gridDim.x / sink.ncls;
+    const int tiles_j = sink.tiles_j;
     int bx = blockIdx.x, by = blockIdx.y;
     if (sink.xcd_map) {
         // Workgroups go to the 8 XCDs round-robin in launch order, and each XCD has its own L2: with the j tile on
@@ -437,8 +443,17 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         const unsigned ti = slot / sj, tj = slot - ti * sj;
         bx = (int)((xcd & 1u) * sj + tj); by = (int)((xcd >> 1) * si + ti);
     }
+    // Multi-item blocks (sink.items > 1, conv forms with short reductions): the block owns `n_items` consecutive
+    // (class, j tile) items, and the software pipeline runs ACROSS them -- the first k-tiles of item w+1 are
+    // fetched and staged during the last k-steps of item w, its epilogue stores go out while the next item's
+    // MFMAs already run.  With K = 256 .. 512 a tile is 8 - 16 k-steps; paying the cold start (loader set-up,
+    // ~2 us of load latency, LDS staging) once per tile was 20-30 % of those kernels.
+    const int first_item = bx * sink.items;
+    const int n_items = min(sink.items, tiles_j * sink.ncls - first_item);
+    if (sink.items > 1) bx = first_item;
     const int cls = bx / tiles_j;
-    const int i0 = by * BM, j0 = (bx - cls * tiles_j) * BN, split = blockIdx.z;
+    const int i0 = by * BM, split = blockIdx.z;
+    int j0 = (bx - cls * tiles_j) * BN;
     const int kbeg = split * klen;
     const int kend = min(K, kbeg + klen);
     const int nsteps = (kend - kbeg + BKK - 1) / BKK;
@@ -574,6 +589,104 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     const bool full = nsteps > 0 && (kend - kbeg) % BKK == 0 && p.fast && q.fast;    // block-uniform
     const bool il = CAN_IL && full;
     p.begin(kbeg, t); q.begin(kbeg, t);
+    // ---- multi-item blocks: the pipeline of the interleaved loops, run across the block's items
+    constexpr bool CAN_MULTI = CAN_IL && KW == 1 && !ROWSUM && E::MULTI;      // conv forms only (EpNCHW)
+    if (CAN_MULTI && sink.items > 1) {
+        if constexpr (CAN_MULTI) {
+            if (!(il && nsteps >= 2 && gridDim.z == 1)) return;     // launch conditions (host): full k-tiles, >= 2 steps, no split
+            const int G = n_items * nsteps;             // k-steps of the whole block
+            auto item_tile = [&](int w, int &c, int &jt) { const int it = first_item + w; c = it / tiles_j; jt = (it - c * tiles_j) * BN; };
+            auto loaders_to = [&](int w) {              // point the loaders at item w (the load stream runs ahead)
+                int c, jt; item_tile(w, c, jt);
+                p.init(i0, t, c); q.init(jt, t, c);
+                p.begin(kbeg, t); q.begin(kbeg, t);
+            };
+            auto kof = [&](int g) { return kbeg + (g % nsteps) * BKK; };
+            auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
+                int c, jt; item_tile(w, c, jt);
+                e.set_class(c);
+#pragma unroll
+                for (int y = 0; y < WN; ++y) {
+                    const int j = jt + (wj * WN + y) * 32 + lcol;
+                    if (e.col(j)) {
+#pragma unroll
+                        for (int x = 0; x < WM; ++x) {
+                            const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) e.put(ib + (r & 3) + 8 * (r >> 2), j, acc[x][y][r]);
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < WM; ++x)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+                }
+            };
+            if (!DEEP) {
+                p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
+                p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
+                __syncthreads();
+                for (int g = 0; g + 1 < G; ++g) {
+                    const bool last = (g + 1) % nsteps == 0;      // step g ends its item; tile g+1 opens the next
+                    if (last) loaders_to((g + 1) / nsteps);
+                    const int kn = kof(g + 1), nb = (g + 1) & 1;
+                    compute(g & 1, [&](int st, int ns) {
+                        const int nl = (WM * WN >= 4) ? ns / 4 : ns / 8;
+                        if (st < nl) { p.load_part(kn, kend, t, pr0, st, nl); q.load_part(kn, kend, t, qr0, st, nl); }
+                        if (st >= ns - nl) { p.store_part(Ps(nb), t, pr0, st - (ns - nl), nl); q.store_part(Qs(nb), t, qr0, st - (ns - nl), nl); }
+                    });
+                    __syncthreads();
+                    if (last) finish_item(g / nsteps);
+                }
+                compute((G - 1) & 1, no_hook);
+                finish_item(n_items - 1);
+                return;
+            }
+            // one tile per wave: two tiles in flight in registers (see the single-item loop below)
+            p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
+            p.load_part(kbeg + BKK, kend, t, pr1, 0, 1); q.load_part(kbeg + BKK, kend, t, qr1, 0, 1);      // nsteps >= 2
+            p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
+            __syncthreads();
+            int g = 0;
+            for (; g + 2 < G; g += 2) {
+                // even step g on buffer 0: fetch tile g+2 into set 0, stage tile g+1 (set 1) in buffer 1
+                if ((g + 2) % nsteps == 0) loaders_to((g + 2) / nsteps);
+                const int k2 = kof(g + 2);
+                compute(0, [&](int st, int ns) {
+                    const int nl = ns / 2;
+                    if (st < nl) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); }
+                    else { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
+                });
+                __syncthreads();
+                if ((g + 1) % nsteps == 0) finish_item(g / nsteps);
+                // odd step g+1 on buffer 1: fetch tile g+3 into set 1 (the last tile again when there is none), stage
+                // tile g+2 (set 0) in buffer 0
+                const bool more3 = g + 3 < G;
+                if (more3 && (g + 3) % nsteps == 0) loaders_to((g + 3) / nsteps);
+                const int k3 = kof(more3 ? g + 3 : g + 2);
+                compute(1, [&](int st, int ns) {
+                    const int nl = ns / 2;
+                    if (st < nl) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); }
+                    else { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
+                });
+                __syncthreads();
+                if ((g + 2) % nsteps == 0) finish_item((g + 1) / nsteps);
+            }
+            // tail: tile g is staged in buffer 0; tile g+1 (if any) waits in register set 1
+            if (g + 1 < G) {
+                compute(0, [&](int st, int ns) {
+                    if (st >= ns / 2) { p.store_part(Ps(1), t, pr1, st - ns / 2, ns - ns / 2); q.store_part(Qs(1), t, qr1, st - ns / 2, ns - ns / 2); }
+                });
+                __syncthreads();
+                if ((g + 1) % nsteps == 0) finish_item(g / nsteps);
+                compute(1, no_hook);
+            } else {
+                compute(0, no_hook);
+            }
+            finish_item(n_items - 1);
+            return;
+        }
+    }
     if (CAN_IL && il && !DEEP) {
         p.load_part(kbeg, kend, t, pr0, 0, 1); q.load_part(kbeg, kend, t, qr0, 0, 1);
         p.store_part(Ps(0), t, pr0, 0, 1); q.store_part(Qs(0), t, qr0, 0, 1);
@@ -880,7 +993,7 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; };   // xcd: XCD-local output sub-grids (Linear)
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; };   // xcd: XCD-local output sub-grids (Linear); items: (class, j tile) items per block (conv forms)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
@@ -983,7 +1096,16 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         PLD<TM> p; make_p(p);                                                                    \
         QLD<TN> q; make_q(q);                                                                    \
         dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
+        sink.tiles_j = (J + TN - 1) / TN;                                                        \
         sink.xcd_map = (pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
+        sink.items = 1;                                                                          \
+        if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \
+            K >= 2 * PLD<TM>::BKV && PLD<TM>::PARTS && QLD<TN>::PARTS) {                         \
+            int items = pl.items;                      /* keep >= 1024 blocks: 4 per CU */       \
+            while (items > 1 && (int)grid.x / items < 1024) items >>= 1;                         \
+            sink.items = items;                                                                  \
+            grid.x = (grid.x + items - 1) / items;                                               \
+        }                                                                                        \
         constexpr size_t tile_b = 2 * (PLD<TM>::ROWS * PLD<TM>::PITCH + QLD<TN>::ROWS * QLD<TN>::PITCH) * sizeof(float); \
         constexpr size_t red_b = (WGM * WGN < 4 && KW > 1)                                       \
             ? (size_t)KW * TM * (TN + 1) * sizeof(float)              /* cooperative epilogue */ \
@@ -1054,7 +1176,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     s.stride = (size_t)I * J + (rowsum ? I : 0);
     s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
     s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0; s.cls_region = 0; s.rowsum_final_cls_stride = 0;
-    s.xcd_map = 0;
+    s.xcd_map = 0; s.tiles_j = 0; s.items = 1;
     return s;
 }
 

@@ -80,7 +80,13 @@ def _lin_grouped_cost(which):
     return cost
 
 
+def _wgrad_batched_cost(items, *a, **kw):
+    fl = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _, _ in items)
+    return fl, '%d layers' % len(items)
+
+
 GEMM_COSTS = {
+    'linear_wgrad_batched': _wgrad_batched_cost,
     'linear_fwd_grouped': _lin_grouped_cost('fwd'), 'linear_dgrad_grouped': _lin_grouped_cost('dgrad'),
     'linear_wgrad_grouped': _lin_grouped_cost('wgrad'),
     'linear_fwd': _lin_cost('fwd'), 'linear_dgrad': _lin_cost('dgrad'), 'linear_wgrad': _lin_cost('wgrad'),
