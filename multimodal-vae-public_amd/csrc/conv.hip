@@ -7,6 +7,9 @@
 #ifndef MVAE_CONVT_SMALL2
 #define MVAE_CONVT_SMALL2 1     // <= 4-channel transposed conv: two positions per thread, weights through scalar loads
 #endif
+#ifndef MVAE_CLS_MINOR
+#define MVAE_CLS_MINOR 1        // parity classes of one tile adjacent in launch order (see igemm_kernel)
+#endif
 #ifndef MVAE_MULTI_ITEMS
 #define MVAE_MULTI_ITEMS 4      // (class, j tile) items a block of the conv forward / dgrad forms walks (1: off)
 #endif
@@ -1047,6 +1050,7 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     auto mq = [&](auto &q) { q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; };
     SplitSink sink = make_sink(nullptr, I, J, false);
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
+    sink.cls_minor = MVAE_CLS_MINOR;
     if (vec) {
         if (s == 2) return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
         return launch_igemm<LdRowsMNC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);

@@ -372,6 +372,7 @@ struct SplitSink {
     int xcd_map;                              // 1: re-map the launch order to XCD-local output sub-grids (see igemm_kernel)
     int tiles_j;                              // j tiles per class (set by the launcher)
     int items;                                // > 1: a block walks this many consecutive (class, j tile) items (see igemm_kernel)
+    int cls_minor;                            // 1: launch order (j tile, class) instead of (class, j tile)
 };
 
 // finish kernels of a grouped launch: one grid slice per class
@@ -451,9 +452,17 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     const int first_item = bx * sink.items;
     const int n_items = min(sink.items, tiles_j * sink.ncls - first_item);
     if (sink.items > 1) bx = first_item;
-    const int cls = bx / tiles_j;
+    // class-minor order (transposed-conv parity classes): the s*s classes of one j tile are neighbours in launch
+    // order (and the items of one multi-item block), so the interleaved output lattice of a region is written --
+    // and the shared input neighbourhood read -- by blocks that run together, not a whole class sweep apart
+    auto item_of = [&](int it, int &c, int &jt) {
+        if (sink.cls_minor) { jt = it / sink.ncls; c = it - jt * sink.ncls; }
+        else { c = it / tiles_j; jt = it - c * tiles_j; }
+    };
+    int cls, jt0;
+    item_of(bx, cls, jt0);
     const int i0 = by * BM, split = blockIdx.z;
-    int j0 = (bx - cls * tiles_j) * BN;
+    int j0 = jt0 * BN;
     const int kbeg = split * klen;
     const int kend = min(K, kbeg + klen);
     const int nsteps = (kend - kbeg + BKK - 1) / BKK;
@@ -485,7 +494,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // db = sum over the reduction axis of P (dy^T): the bias gradient for free.  The 256 movers split the
     // tile: thread t owns row t % BM and every RS_PARTS-th k of it; parts are summed through LDS at the end.
     constexpr int RS_PARTS = NTHREADS / BM;
-    const bool rs_block = ROWSUM && bx == cls * tiles_j;              // block-uniform
+    const bool rs_block = ROWSUM && jt0 == 0;                         // block-uniform: the class's first j tile
     const int rs_row = t % BM, rs_part = t / BM;
     float rsum = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -595,7 +604,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         if constexpr (CAN_MULTI) {
             if (!(il && nsteps >= 2 && gridDim.z == 1)) return;     // launch conditions (host): full k-tiles, >= 2 steps, no split
             const int G = n_items * nsteps;             // k-steps of the whole block
-            auto item_tile = [&](int w, int &c, int &jt) { const int it = first_item + w; c = it / tiles_j; jt = (it - c * tiles_j) * BN; };
+            auto item_tile = [&](int w, int &c, int &jt) { item_of(first_item + w, c, jt); jt *= BN; };
             auto loaders_to = [&](int w) {              // point the loaders at item w (the load stream runs ahead)
                 int c, jt; item_tile(w, c, jt);
                 p.init(i0, t, c); q.init(jt, t, c);
@@ -720,16 +729,16 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             const int k2 = kbeg + (s + 2) * BKK, k3 = kbeg + min(s + 3, nsteps - 1) * BKK;
             compute(0, [&](int st, int ns) {
                 const int nl = ns / 2;
-                if (st < nl) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); }
-                else { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
+                if (st < nl) { if (MVAE_KO < 1) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); } }
+                else if (MVAE_KO < 2) { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
             });
-            __syncthreads();
+            if (MVAE_KO < 3) __syncthreads();
             compute(1, [&](int st, int ns) {
                 const int nl = ns / 2;
-                if (st < nl) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); }
-                else { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
+                if (st < nl) { if (MVAE_KO < 1) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); } }
+                else if (MVAE_KO < 2) { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
             });
-            __syncthreads();
+            if (MVAE_KO < 3) __syncthreads();
         }
         // tail: tile s is staged in buffer 0; tile s+1 (if any) waits in register set 1
         if (s + 1 < nsteps) {
@@ -1176,7 +1185,7 @@ inline SplitSink make_sink(void *ws, int I, int J, bool rowsum) {
     s.stride = (size_t)I * J + (rowsum ? I : 0);
     s.rowsum = nullptr; s.rowsum_stride = 0; s.rowsum_accumulate = 0; s.ncls = 1; s.rowsum_cls_stride = 0;
     s.rowsum_final = nullptr; s.rowsum_final_accumulate = 0; s.cls_region = 0; s.rowsum_final_cls_stride = 0;
-    s.xcd_map = 0; s.tiles_j = 0; s.items = 1;
+    s.xcd_map = 0; s.tiles_j = 0; s.items = 1; s.cls_minor = 0;
     return s;
 }
 
