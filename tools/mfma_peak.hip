@@ -1,7 +1,11 @@
-// Practical ceiling of v_mfma_f32_32x32x2_f32 on this GPU: a register-only MFMA loop (no memory traffic) for
-// 1 / 2 / 4 independent accumulators per wave and 1..4 waves per SIMD, short (~5 ms) and sustained (~300 ms,
-// where a power-limited clock shows), plus the same loop fed by two ds_read_b32 per MFMA (the igemm kernels'
-// fragment traffic).  Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/bin/mfma_peak
+// What v_mfma_f32_32x32x2_f32 sustains on this GPU, and what it costs to put other work next to it.
+//   1. register-only MFMA loop, 1 / 2 / 4 accumulators per wave, 1..4 waves per SIMD, 5 ms and 300 ms (a
+//      power-limited clock would show in the long run): 154 TFLOP/s, from ONE wave per SIMD.
+//   2. the loop as the igemm kernels issue it -- per MFMA a fragment pair from LDS, waited for one MFMA later --
+//      plus FILL independent VALU instructions per MFMA: the fp32 matrix instruction runs on the fp32 FMA lanes,
+//      so vector-ALU work is not hidden behind it: 2 VALU instructions per MFMA cost a third of the throughput
+//      at one wave per SIMD, ~4.5 cycles each at four.  (LDS reads alone are free: 144-152 TFLOP/s.)
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/bin/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -127,17 +131,11 @@ int main() {
     printf("device %s  CUs %d  clock %.0f MHz (reported max)\n", p.name, cus, p.clockRate / 1000.0);
     float *out;
     hipMalloc(&out, 4096);
-    printf("%-34s %10s %10s\n", "config (TFLOP/s)", "5 ms", "300 ms");
-    for (int bpc = 1; bpc <= 4; ++bpc) {
-        printf("acc1 regs  %d wave/SIMD              %10.1f %10.1f\n", bpc, run<1, false>(bpc, cus, 5, out), 0.0);
-        printf("acc2 regs  %d wave/SIMD              %10.1f %10.1f\n", bpc, run<2, false>(bpc, cus, 5, out), 0.0);
-        printf("acc4 regs  %d wave/SIMD              %10.1f %10.1f\n", bpc, run<4, false>(bpc, cus, 5, out), run<4, false>(bpc, cus, 300, out));
-    }
-    for (int bpc = 1; bpc <= 4; ++bpc) {
-        printf("acc1 +2 ds_read/mfma %d wave/SIMD    %10.1f %10.1f\n", bpc, run<1, true>(bpc, cus, 5, out), 0.0);
-        printf("acc2 +1 ds_read/mfma %d wave/SIMD    %10.1f %10.1f\n", bpc, run<2, true>(bpc, cus, 5, out), 0.0);
-        printf("acc4 +.5 ds_read/mfma %d wave/SIMD   %10.1f %10.1f\n", bpc, run<4, true>(bpc, cus, 5, out), 0.0);
-    }
+    printf("register-only MFMA loop (TFLOP/s)   %8s %8s %8s %8s\n", "1 w/SIMD", "2", "3", "4");
+    printf("1 accumulator, 5 ms                 %8.1f %8.1f %8.1f %8.1f\n", run<1, false>(1, cus, 5, out), run<1, false>(2, cus, 5, out), run<1, false>(3, cus, 5, out), run<1, false>(4, cus, 5, out));
+    printf("2 accumulators, 5 ms                %8.1f %8.1f %8.1f %8.1f\n", run<2, false>(1, cus, 5, out), run<2, false>(2, cus, 5, out), run<2, false>(3, cus, 5, out), run<2, false>(4, cus, 5, out));
+    printf("4 accumulators, 5 ms                %8.1f %8.1f %8.1f %8.1f\n", run<4, false>(1, cus, 5, out), run<4, false>(2, cus, 5, out), run<4, false>(3, cus, 5, out), run<4, false>(4, cus, 5, out));
+    printf("4 accumulators, 300 ms (sustained)  %8.1f %8.1f %8.1f %8.1f\n", run<4, false>(1, cus, 300, out), run<4, false>(2, cus, 300, out), run<4, false>(3, cus, 300, out), run<4, false>(4, cus, 300, out));
     printf("%-44s %8s %8s %8s %8s\n", "LDS-fed loop (TFLOP/s, 20 ms)", "1 w/SIMD", "2", "3", "4");
 #define ROW(A, F) printf("acc%d, %d VALU fillers per MFMA %16s %8.1f %8.1f %8.1f %8.1f\n", A, F, "", \
         run_fed<A, F>(1, cus, 20, out), run_fed<A, F>(2, cus, 20, out), run_fed<A, F>(3, cus, 20, out), run_fed<A, F>(4, cus, 20, out));
