@@ -236,6 +236,19 @@ int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E,
                  const mvae_expert_grads_t *grads, int ldg,
                  int B, int D, int variant, mvae_stream_t stream);
 
+/* mvae_poe_bwd with the latent gradient in TWO buffers: dz of term t = dz_a[slot_a[t]] + dz_b[slot_b[t]], each
+ * buffer [n_slots, B, D] holding only the terms its decoder saw (slot -1: the term is not in that buffer;
+ * slot_* are HOST arrays of T ints).  The fused step's two decoders run on two streams; with one buffer each,
+ * neither their first layers' data gradients nor a cleared shared dz sit on the joined chain.  The sum is taken
+ * a-then-b: same bits as accumulating b onto a. */
+int mvae_poe_bwd_split(const mvae_experts_t *experts, int ld, int E,
+                       const uint32_t *masks_dev, int T,
+                       const float *noise, const float *mu, const float *logvar,
+                       const float *dz_a, const int *slot_a, const float *dz_b, const int *slot_b,
+                       const float *dkl, int dkl_per_term,
+                       const mvae_expert_grads_t *grads, int ldg,
+                       int B, int D, int variant, mvae_stream_t stream);
+
 /* stand-alone reparameterised draw for the public MVAE.reparametrize (mnist/model.py:29-35):
  * z = eps * exp(0.5 * logvar) + mu */
 int mvae_reparam_fwd(const float *mu, const float *logvar, const float *eps, float *z, size_t n,

@@ -88,6 +88,9 @@ _SIGNATURES = {
                              c_int, c_int, c_int, P]),
     'mvae_poe_bwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P, P, P, c_int,
                              ctypes.POINTER(ExpertGrads), c_int, c_int, c_int, c_int, P]),
+    'mvae_poe_bwd_split': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P,
+                                   ctypes.POINTER(c_int), P, ctypes.POINTER(c_int), P, c_int,
+                                   ctypes.POINTER(ExpertGrads), c_int, c_int, c_int, c_int, P]),
     'mvae_kl_rows_fwd': (c_int, [P, P, P, c_int, c_int, P]),
     'mvae_kl_rows_bwd': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'mvae_bce_rowsum_fwd': (c_int, [P, P, P, P, P, P] + [c_int] * 7 + [P]),

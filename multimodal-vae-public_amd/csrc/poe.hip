@@ -81,9 +81,14 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
 // KL row and from direct consumers, folded into A_t = dmu_t / S_t, B_t = dlv_t * dlv/dS and the
 // fused mean; kept in LDS ([term][3][thread], conflict-free).  Phase 2 (per expert): T_e and
 // exp(lv_e) once, then a sweep over the terms that contain the expert.
+// dz of term t = dz[slot_a[t]] (+ dz_b[slot_b[t]]): the latent gradient may arrive in two buffers -- one per
+// decoder, each holding only the terms that decoder saw -- instead of one accumulated [T,B,D] tensor.
+struct PoeDzMap { signed char slot_a[MVAE_ELBO_MAX_TERMS], slot_b[MVAE_ELBO_MAX_TERMS]; };
+
 __global__ __launch_bounds__(POE_THREADS) void poe_bwd_kernel(PoeArgs a, const uint32_t *masks,
                                                               const float *noise, const float *mu,
                                                               const float *logvar, const float *dz,
+                                                              const float *dz_b, PoeDzMap dzm,
                                                               const float *dmu, const float *dlogvar,
                                                               const float *dkl, int dkl_stride,
                                                               mvae_expert_grads_t gr, int ldg) {
@@ -100,7 +105,14 @@ __global__ __launch_bounds__(POE_THREADS) void poe_bwd_kernel(PoeArgs a, const u
             float gmu = dmu ? dmu[o] : 0.f;
             float glv = dlogvar ? dlogvar[o] : 0.f;
             if (dz) {
-                const float g = dz[o];
+                float g;
+                if (dz_b) {
+                    const int sa = dzm.slot_a[t], sb = dzm.slot_b[t];       // block-uniform
+                    g = sa >= 0 ? dz[((size_t)sa * a.B + b) * a.D + d] : 0.f;
+                    if (sb >= 0) g += dz_b[((size_t)sb * a.B + b) * a.D + d];
+                } else {
+                    g = dz[o];
+                }
                 gmu += g;
                 if (noise) glv += g * noise[o] * 0.5f * expf(0.5f * plv);
             }
@@ -209,9 +221,36 @@ MVAE_EXPORT int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E, const
     a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
+    PoeDzMap none = {};
     hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,
-                       (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz, dmu, dlogvar, dkl, dkl_stride,
-                       *grads, ldg);
+                       (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz, (const float *)nullptr, none, dmu,
+                       dlogvar, dkl, dkl_stride, *grads, ldg);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_poe_bwd_split(const mvae_experts_t *experts, int ld, int E, const uint32_t *masks_dev, int T,
+                                   const float *noise, const float *mu, const float *logvar, const float *dz_a,
+                                   const int *slot_a, const float *dz_b, const int *slot_b, const float *dkl,
+                                   int dkl_per_term, const mvae_expert_grads_t *grads, int ldg, int B, int D,
+                                   int variant, mvae_stream_t stream) {
+    const int dkl_stride = dkl_per_term ? 0 : B;
+    if (!poe_args_ok(experts, ld, E, T, B, D, variant) || !masks_dev || !mu || !logvar || !grads || ldg < D ||
+        !dz_a || !dz_b || !slot_a || !slot_b || T > MVAE_ELBO_MAX_TERMS)
+        return MVAE_ERR_ARG;
+    for (int e = 0; e < E; ++e)
+        if (!grads->dmu[e] || !grads->dlogvar[e]) return MVAE_ERR_ARG;
+    PoeDzMap m;
+    for (int t = 0; t < T; ++t) {
+        if (slot_a[t] < -1 || slot_a[t] >= T || slot_b[t] < -1 || slot_b[t] >= T) return MVAE_ERR_ARG;
+        m.slot_a[t] = (signed char)slot_a[t]; m.slot_b[t] = (signed char)slot_b[t];
+    }
+    PoeArgs a;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    const int rows = POE_THREADS / 64;
+    const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,
+                       (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz_a, dz_b, m, (const float *)nullptr,
+                       (const float *)nullptr, dkl, dkl_stride, *grads, ldg);
     return mvae_launch_status();
 }
 

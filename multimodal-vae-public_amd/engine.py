@@ -346,6 +346,9 @@ class BimodalStep(_StepBase):
         # on MI355X: 17 % fewer graph nodes but no gain (MNIST B=512 0.508 vs 0.493 ms/step) -- the two
         # decoders already overlap on two streams and a paired launch serialises them.
         self.pair_dec = self._pairable_decoder_layers() if os.environ.get('MVAE_PAIR', '0') == '1' else 0
+        # each decoder's backward runs to the latent on its own stream into its own buffer (poe_bwd_split adds
+        # them); MVAE_SPLIT_DZ=0: one cleared dz both first layers accumulate into after the join
+        self.split_dz = os.environ.get('MVAE_SPLIT_DZ', '1') != '0' 
         # per-term loss coefficients lambda/B, beta/B: pinned host mirror -> device, so a captured
         # graph sees new annealing factors without re-capture
         self.tables = StepTables(3 * self.T, dev)
@@ -524,8 +527,15 @@ class BimodalStep(_StepBase):
                     K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
                                      dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
                 wl = self._deferred()
-                g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
-                                        defer_input_grad=True, deferred=wl)
+                if self.split_dz:
+                    # this decoder's latent gradient goes to its OWN buffer (terms l0 .. l0+nl-1), on this stream
+                    dz_lbl = torch.empty(nl * B, D, dtype=torch.float32, device=self.dev)
+                    L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl, need_input_grad=True,
+                                    input_grad_out=dz_lbl, deferred=wl)
+                    g_lbl = dz_lbl
+                else:
+                    g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
+                                            defer_input_grad=True, deferred=wl)
                 self._launch_deferred(wl, self.wg_side)
             # ---- image branch (this stream)
             zi = z[i0:i0 + ni].reshape(ni * B, D)
@@ -542,26 +552,49 @@ class BimodalStep(_StepBase):
             K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
                              rows_per_group=B, target_rows=B)
             wi = self._deferred()
-            g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
-                                    groups=ni, defer_input_grad=True, deferred=wi)
+            if self.split_dz:
+                dz_img = torch.empty(ni * B, D, dtype=torch.float32, device=self.dev)
+                L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape), groups=ni,
+                                need_input_grad=True, input_grad_out=dz_img, deferred=wi)
+                g_img = dz_img
+            else:
+                g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
+                                        groups=ni, defer_input_grad=True, deferred=wi)
             self._launch_deferred(wi, self.wg_main)     # decoder weight gradients run behind phase B
             self._join()
             keep_dec = (logits_lbl, tape_dl, dlog_lbl, logits_img, tape_di, dlog_img)
         # ---- ELBO per term and total (mnist/train.py:57-58,214), the cleared dz and the step's Philox counter
         #      advance: one bookkeeping launch
-        dz = torch.empty(T, B, D, dtype=torch.float32, device=self.dev)
-        K.elbo_reduce([(kl, self.coef[2], None, 0, T, B),
-                       (rows_img, self.coef[0, i0:i0 + ni], None, i0, ni, B),
-                       (rows_lbl, self.coef[1, l0:l0 + nl], None, l0, nl, B)], self.elbo, T, zero=dz,
-                      counter_dev=self.counter, counter_inc=2 if self.has_dropout else 1)
-        # ---- both decoders' first layers -> the shared dz
-        L.first_linear_dgrad(m.image_decoder.plan(), g_img, dz[i0:i0 + ni].reshape(ni * B, D), True)
-        L.first_linear_dgrad(m.label_decoder.plan(), g_lbl, dz[l0:l0 + nl].reshape(nl * B, D), True)
+        elbo_parts = [(kl, self.coef[2], None, 0, T, B),
+                      (rows_img, self.coef[0, i0:i0 + ni], None, i0, ni, B),
+                      (rows_lbl, self.coef[1, l0:l0 + nl], None, l0, nl, B)]
+        counter_inc = 2 if self.has_dropout else 1
+        if self.split_dz and not self.pair_dec:
+            # Each decoder's backward ran to its input on its own stream into its own latent-gradient buffer;
+            # poe_bwd adds the two per term (image first: the bits of accumulating into one cleared buffer).
+            # Nothing is left between the join and the PoE backward: the ELBO bookkeeping launch moves behind the
+            # image encoder's backward, where the main stream waits for the label side anyway.
+            dz = None
+            c['dz_split'] = (g_img, [t - i0 if i0 <= t < i0 + ni else -1 for t in range(T)],
+                             g_lbl, [t - l0 if l0 <= t < l0 + nl else -1 for t in range(T)])
+            c['elbo_late'] = (elbo_parts, counter_inc)
+        else:
+            dz = torch.empty(T, B, D, dtype=torch.float32, device=self.dev)
+            K.elbo_reduce(elbo_parts, self.elbo, T, zero=dz, counter_dev=self.counter, counter_inc=counter_inc)
+            # ---- both decoders' first layers -> the shared dz
+            L.first_linear_dgrad(m.image_decoder.plan(), g_img, dz[i0:i0 + ni].reshape(ni * B, D), True)
+            L.first_linear_dgrad(m.label_decoder.plan(), g_lbl, dz[l0:l0 + nl].reshape(nl * B, D), True)
         # everything a branch allocated stays referenced until the next step's first fork
         c.update(mus=mus, lvs=lvs, mu=mu, lv=lv, dz=dz, heads_img=heads_img, heads_lbl=heads_lbl,
                  keep=(z, kl, rows_lbl, g_lbl, rows_img, g_img, lbl_in, keep_dec))
         if self._comm is not None or self.on_bucket_ready is not None:
             self._join_wgrad()      # data parallel: the decoder bucket is all-reduced after phase A
+
+    def _late_elbo(self):
+        """The step's ELBO sums + Philox counter advance (split-dz mode): off the decoder -> PoE -> encoder chain."""
+        late = self._carry.pop('elbo_late', None)
+        if late is not None:
+            K.elbo_reduce(late[0], self.elbo, self.T, counter_dev=self.counter, counter_inc=late[1])
 
     def _phase_b(self, part='all'):
         """PoE backward + encoders backward.  ``part``: 'all', or for a data-parallel replica with three
@@ -575,9 +608,15 @@ class BimodalStep(_StepBase):
             g_heads_img = torch.empty_like(heads_img)
             g_heads_lbl = torch.empty_like(heads_lbl)
             g_list = ([g_heads_img[:B], g_heads_img[B:]] if self.has_dropout else [g_heads_img]) + [g_heads_lbl]
-            K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
-                      self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
-                      dkl_per_term=True)
+            if c.get('dz_split') is not None:
+                dza, sa, dzb, sb = c['dz_split']
+                K.poe_bwd_split(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], dza, sa, dzb, sb,
+                                self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list],
+                                m.POE_VARIANT, dkl_per_term=True)
+            else:
+                K.poe_bwd(c['mus'], c['lvs'], self.masks_dev, self.noise, c['mu'], c['lv'], c['dz'], None, None,
+                          self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
+                          dkl_per_term=True)
             c['keep_b'] = (g_heads_img, g_heads_lbl)
         if part == 'all':
             # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
@@ -597,6 +636,7 @@ class BimodalStep(_StepBase):
             if isinstance(wi, L.WgradBatch):
                 wi.flush()
                 wi = None
+            self._late_elbo()
             self._join()
             if wi is not None:
                 fns = wi + wl
@@ -621,6 +661,7 @@ class BimodalStep(_StepBase):
                 K.dropout_fanin_bwd(d_hd, self.drop_masks, g, 1.0 / KEEP)
                 c['keep_b'] += (d_hd,)
             c['g_cut'] = L.backward_tape(plan[cut:], tape[cut:], g, need_input_grad=True)
+            self._late_elbo()
             self._join()
         else:
             L.backward_tape(plan[:cut], tape[:cut], c['g_cut'])

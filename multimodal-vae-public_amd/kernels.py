@@ -490,6 +490,33 @@ def poe_bwd(mus, lvs, masks_dev, noise, mu, logvar, dz, dmu, dlogvar, dkl, g_mus
           'mvae_poe_bwd')
 
 
+def poe_bwd_split(mus, lvs, masks_dev, noise, mu, logvar, dz_a, slots_a, dz_b, slots_b, dkl, g_mus, g_lvs, variant,
+                  dkl_per_term=False):
+    """poe_bwd with the latent gradient in two buffers: dz of term t = dz_a[slots_a[t]] + dz_b[slots_b[t]]
+    (slot -1: not in that buffer); dz_* are [n_slots, B, D]."""
+    ld = _expert_ld(mus, lvs)
+    ldg = _expert_ld(g_mus, g_lvs)
+    _need_gpu(masks_dev, noise, mu, logvar, dz_a, dz_b, dkl)
+    _f32c(noise, mu, logvar, dz_a, dz_b, dkl)
+    T, B, D = mu.shape
+    if len(slots_a) != T or len(slots_b) != T:
+        raise RuntimeError('one slot per term')
+    for dz, slots in ((dz_a, slots_a), (dz_b, slots_b)):
+        if dz.numel() != (max(slots) + 1) * B * D:
+            raise RuntimeError('latent-gradient buffer does not match its slots')
+    ex = _experts(mus, lvs)
+    gr = _lib.ExpertGrads()
+    for i, (m, v) in enumerate(zip(g_mus, g_lvs)):
+        gr.dmu[i] = m.data_ptr()
+        gr.dlogvar[i] = v.data_ptr()
+    sa = (ctypes.c_int * T)(*[int(x) for x in slots_a])
+    sb = (ctypes.c_int * T)(*[int(x) for x in slots_b])
+    check(_lib.lib().mvae_poe_bwd_split(ctypes.byref(ex), ld, len(mus), _ptr(masks_dev), T, _ptr(noise), _ptr(mu),
+                                        _ptr(logvar), _ptr(dz_a), sa, _ptr(dz_b), sb, _ptr(dkl),
+                                        1 if dkl_per_term else 0, ctypes.byref(gr), ldg, B, D,
+                                        _lib.POE_VARIANT[variant], _stream()), 'mvae_poe_bwd_split')
+
+
 def kl_rows_fwd(mu, logvar, kl):
     _need_gpu(mu, logvar, kl); _f32c(mu, logvar, kl)
     check(_lib.lib().mvae_kl_rows_fwd(_ptr(mu), _ptr(logvar), _ptr(kl), mu.shape[0], mu.shape[1], _stream()),

@@ -445,6 +445,36 @@ def test_poe_per_term_kl_scale():
         assert_close(gh[e], heads[e].grad, 'kl-only grad expert %d' % e)
 
 
+def test_poe_bwd_split_equals_accumulated_dz():
+    """The latent gradient in two per-decoder buffers (terms {0,1} and {1,2}) gives the bits of one dz they were
+    accumulated into, image first."""
+    B, D, T, E = 40, 64, 3, 2
+    masks = [1, 3, 2]
+    hd = [dev(g(B, 2 * D, seed=170 + e, scale=0.7)) for e in range(E)]
+    mus = [h[:, :D] for h in hd]; lvs = [h[:, D:] for h in hd]
+    md = torch.tensor(masks, dtype=torch.int32, device=DEV)
+    noise = dev(g(T, B, D, seed=172))
+    mu = torch.empty(T, B, D, device=DEV); lv = torch.empty_like(mu); z = torch.empty_like(mu)
+    kl = torch.empty(T, B, device=DEV)
+    K.poe_fwd(mus, lvs, md, noise, mu, lv, z, kl, 'A')
+    dz_a, dz_b = dev(g(2, B, D, seed=173)), dev(g(2, B, D, seed=174))     # a: terms 0,1; b: terms 1,2
+    dz = torch.zeros(T, B, D, device=DEV)
+    dz[0:2] += dz_a
+    dz[1:3] += dz_b
+    coef = dev(torch.tensor([0.1, 0.2, 0.3]))
+    ref = [torch.empty_like(h) for h in hd]
+    K.poe_bwd(mus, lvs, md, noise, mu, lv, dz, None, None, coef, [x[:, :D] for x in ref], [x[:, D:] for x in ref], 'A',
+              dkl_per_term=True)
+    out = [torch.empty_like(h) for h in hd]
+    K.poe_bwd_split(mus, lvs, md, noise, mu, lv, dz_a, [0, 1, -1], dz_b, [-1, 0, 1], coef,
+                    [x[:, :D] for x in out], [x[:, D:] for x in out], 'A', dkl_per_term=True)
+    for e in range(E):
+        assert torch.equal(out[e], ref[e])
+    with pytest.raises(RuntimeError):
+        K.poe_bwd_split(mus, lvs, md, noise, mu, lv, dz_a, [0, 1], dz_b, [-1, 0, 1], coef,
+                        [x[:, :D] for x in out], [x[:, D:] for x in out], 'A', dkl_per_term=True)
+
+
 def test_kl_and_reparam_standalone():
     from mvae_amd.functional import ReparamFn, _KlRowsFn
     mu, lv, eps = (g(33, 100, seed=s).requires_grad_(s < 98) for s in (96, 97, 98))
