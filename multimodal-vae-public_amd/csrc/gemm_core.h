@@ -10,12 +10,14 @@
 // The j axis is the lane axis of the MFMA result (32 consecutive j per store instruction),
 // so each op maps its memory-contiguous output axis to j.
 //
-// Tiling: 256 threads = 4 waves (2 x 2), each wave WM x WN MFMA tiles of 32x32
-// (block tile 64*WM x 64*WN), BK = 32.  Software pipeline: global -> registers two k-tiles
-// ahead (two register sets), registers -> LDS one tile ahead (two LDS buffers), ONE barrier per
-// k-step; the fp32 MFMA (64 cycles each) of tile t hides the HBM/L2 latency of tile t+2.
-// LDS tiles are [BK][tile + 4]: fragment reads are bank-conflict free (ds_read_b32, lanes
-// 0..31 consecutive), float4 tile rows stay 16-byte aligned.
+// Tiling: see igemm_kernel (k-groups of WGM x WGN waves, WM x WN MFMA tiles of 32x32 each; BK = 32 or 64).
+// Main loops issue MFMAs and memory instructions only: on fp32 MFMA a vector-ALU instruction costs matrix
+// throughput (tools/mfma_peak.hip), so full k-tiles are fetched with raw buffer loads at per-thread CONSTANT
+// offsets (an out-of-range offset zero-fills what must read as zero), the k-step moves the scalar base, and the
+// next tile's loads / LDS stores are sliced into the shadows of the current tile's MFMA groups ("buffer loads for
+// the main loops" and the interleaved loops below).  Register staging: one tile ahead for 2- and 4-tile waves,
+// two for 1-tile waves; two LDS buffers; ONE barrier per k-step.  Row operands with k contiguous are staged
+// row-major ([row][k + 4], ds_read_b128 fragments), the others k-major ([k][tile + 4], ds_read_b32).
 //
 // Long reductions with a small output (weight gradients over the batch; Linear layers with
 // 6400 inputs or outputs) are split across blockIdx.z into a caller-provided workspace and
