@@ -4,6 +4,9 @@
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
+#ifndef MVAE_CONV_SMALL_FWD
+#define MVAE_CONV_SMALL_FWD 1   // <= 4-input-channel stride-2 conv forward: direct VALU kernel instead of a K <= 48 GEMM
+#endif
 #ifndef MVAE_CONVT_SMALL2
 #define MVAE_CONVT_SMALL2 1     // <= 4-channel transposed conv: two positions per thread, weights through scalar loads
 #endif
@@ -671,10 +674,104 @@ inline bool conv_args_ok(int B, int Cin, int H, int W, int Cout, int stride, int
     return true;
 }
 
+// ---- direct forward conv for <= 4 INPUT channels, stride 2, pad 1 (Conv2d(3,32) of CelebA and the data gradient
+//      of ConvTranspose2d(32,3), celeba/model.py:77,126; Conv2d(1,64) / ConvTranspose2d(64,1) of FashionMNIST).
+//      As a GEMM the reduction is 16 .. 48 long -- one or two k-tiles, the second partial -- and the launch is all
+//      prologue (28 TFLOP/s).  It is a streaming VALU kernel instead: a thread owns two adjacent output columns
+//      of a 32-channel group (64 accumulators); per (input channel, tap row) it loads the 6 input columns both
+//      outputs touch (two float2 + two scalars, clamped addresses and 0/1 factors: no load under a branch) and
+//      per tap reads the 32 weights of the group from LDS (transposed there once per block: [ci][tap][co], eight
+//      broadcast ds_read_b128 per 64 FMAs).  Outputs leave as float2 per channel. ----
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             float *__restrict__ out, float *__restrict__ act,
+                                                             const float *__restrict__ dpre, ConvGeom g, int total) {
+    __shared__ __attribute__((aligned(16))) float wl[CIN * 16 * 32];
+    const int cg = blockIdx.y * 32;
+    for (int j = threadIdx.x; j < CIN * 16 * 32; j += 256) {        // coalesced read of the group's rows, transposing store
+        const int col = j / (CIN * 16), rem = j - col * (CIN * 16);  // rem = ci * 16 + tap
+        wl[rem * 32 + col] = (cg + col < g.Cout) ? w[(size_t)cg * CIN * 16 + j] : 0.f;
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int OW2 = g.OW >> 1;
+    const int ow0 = (idx % OW2) * 2, oh = (idx / OW2) % g.OH, n = idx / (OW2 * g.OH);
+    float acc[2][32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { acc[0][c] = 0.f; acc[1][c] = 0.f; }
+    const float lm = ow0 > 0 ? 1.f : 0.f, rm = ow0 + 2 < g.OW ? 1.f : 0.f;     // columns 2*ow0-1 and 2*ow0+4 inside?
+    const int lo = ow0 > 0 ? -1 : 0, ro = ow0 + 2 < g.OW ? 4 : 3;              // clamped (always legal) offsets
+    const float *img = x + (size_t)n * CIN * g.H * g.W + 2 * ow0;
+    // One rolled loop over (input channel, tap row) -- unrolled, hipcc hoists all 48 taps' loads and weight reads
+    // and spills -- with the NEXT row's six values in flight while this one is multiplied.
+    float2 n0, n1; float nl, nr;
+    auto fetch = [&](int it) {
+        const int ci = it >> 2, ih = 2 * oh - 1 + (it & 3);
+        const float *row = img + ((size_t)ci * g.H + min(max(ih, 0), g.H - 1)) * g.W;
+        n0 = *reinterpret_cast<const float2 *>(row); n1 = *reinterpret_cast<const float2 *>(row + 2);
+        nl = row[lo]; nr = row[ro];
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int it = 0; it < CIN * 4; ++it) {
+        const int ih = 2 * oh - 1 + (it & 3);
+        const float rok = (ih >= 0 && ih < g.H) ? 1.f : 0.f;
+        float v[6];
+        v[0] = nl * (rok * lm); v[1] = n0.x * rok; v[2] = n0.y * rok; v[3] = n1.x * rok; v[4] = n1.y * rok;
+        v[5] = nr * (rok * rm);
+        fetch(min(it + 1, CIN * 4 - 1));              // the last trip re-reads its own row: no load under a branch
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const float4 *wp = reinterpret_cast<const float4 *>(wl + (it * 4 + kw) * 32);     // it * 4 = ci * 16 + kh * 4
+            const float x0 = v[kw], x1 = v[kw + 2];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 ww = wp[q];
+                acc[0][4 * q + 0] = fmaf(ww.x, x0, acc[0][4 * q + 0]); acc[1][4 * q + 0] = fmaf(ww.x, x1, acc[1][4 * q + 0]);
+                acc[0][4 * q + 1] = fmaf(ww.y, x0, acc[0][4 * q + 1]); acc[1][4 * q + 1] = fmaf(ww.y, x1, acc[1][4 * q + 1]);
+                acc[0][4 * q + 2] = fmaf(ww.z, x0, acc[0][4 * q + 2]); acc[1][4 * q + 2] = fmaf(ww.z, x1, acc[1][4 * q + 2]);
+                acc[0][4 * q + 3] = fmaf(ww.w, x0, acc[0][4 * q + 3]); acc[1][4 * q + 3] = fmaf(ww.w, x1, acc[1][4 * q + 3]);
+            }
+        }
+    }
+    const int ohw = g.OH * g.OW;
+    const size_t o0 = ((size_t)n * g.Cout + cg) * ohw + (size_t)oh * g.OW + ow0;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (cg + c < g.Cout) {                      // (no break: the accumulators must stay statically indexed)
+            const size_t o = o0 + (size_t)c * ohw;
+            float v0 = acc[0][c], v1 = acc[1][c];
+            if (dpre) { const float2 p2 = *reinterpret_cast<const float2 *>(dpre + o); v0 *= swish_grad_(p2.x); v1 *= swish_grad_(p2.y); }
+            if (out) *reinterpret_cast<float2 *>(out + o) = make_float2(v0, v1);
+            if (act) *reinterpret_cast<float2 *>(act + o) = make_float2(swishf_(v0), swishf_(v1));
+        }
+    }
+}
+
+inline bool conv_fwd_small_ok(const ConvGeom &g, const float *x, const float *pre, const float *act, const float *dpre) {
+    return MVAE_CONV_SMALL_FWD && g.Cin <= 4 && g.stride == 2 && g.pad == 1 && g.H == 2 * g.OH && g.W == 2 * g.OW &&
+           g.OW % 2 == 0 && aligned8(x) && (!pre || aligned8(pre)) && (!act || aligned8(act)) && (!dpre || aligned8(dpre));
+}
+
+inline int conv_fwd_small(const float *x, const float *w, float *pre, float *act, const float *dpre, ConvGeom g,
+                          hipStream_t st) {
+    const int total = g.B * g.OH * (g.OW / 2);
+    const dim3 grid((total + 255) / 256, (g.Cout + 31) / 32), blk(256);
+    switch (g.Cin) {
+        case 1: hipLaunchKernelGGL(conv_small_fwd_kernel<1>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
+        case 2: hipLaunchKernelGGL(conv_small_fwd_kernel<2>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
+        case 3: hipLaunchKernelGGL(conv_small_fwd_kernel<3>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
+        default: hipLaunchKernelGGL(conv_small_fwd_kernel<4>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
+    }
+    return mvae_launch_status();
+}
+
 // ---- conv forward form: y[n][co][oh][ow] = sum_k w[co][k] * im2col(x)[k][(n,oh,ow)] ----
 int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const float *dpre,
                   ConvGeom g, hipStream_t st) {
     const int I = g.Cout, J = g.B * g.OH * g.OW, K = g.Cin * 16;
+    if (conv_fwd_small_ok(g, x, pre, act, dpre) && !MVAE_TUNE(wm)) return conv_fwd_small(x, w, pre, act, dpre, g, st);
     Plan pl = make_plan(I, J, K, false);
     // >= 128 output channels and enough columns for >= 384 blocks of 128 x 64: two accumulators per wave share
     // every gathered fragment (dec2 / dec1 dgrad at 512 images: 91 -> 99 and 77 -> 80 TFLOP/s; at 256 images the
