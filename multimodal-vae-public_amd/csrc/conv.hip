@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(64 * SC_WAVES) void wgrad_smallcin_kernel(const flo
         __builtin_amdgcn_wave_barrier();
         if (u + nwaves < units) fetch(u + nwaves);
         // ---- k = ow in pairs
+#pragma unroll 4
         for (int q = 0; q < (OW >> 1); ++q) {
             const int k = 2 * q + lk;
             float af[MT], bf[NT];

@@ -938,6 +938,8 @@ __global__ __launch_bounds__(256) void finish_kernel(SplitSink sink, int splits,
     float s = 0.f;
     if (j < sink.J) {
         const float *src = sink.ws + (size_t)i * sink.J + j;
+        // unrolled: eight loads in flight, added in the same order (a rolled loop waits a memory latency per split)
+#pragma unroll 8
         for (int z = grp; z < splits; z += 8) s += src[(size_t)z * sink.stride];
     }
     part[grp][o] = s;
@@ -973,6 +975,7 @@ __global__ __launch_bounds__(256) void finish_few_kernel(SplitSink sink, int spl
     if (sink.rowsum_final && j == 0) finish_rowsum(sink, splits, i);
     if (j >= sink.J || !e.col(j)) return;
     float s = 0.f;
+#pragma unroll 4
     for (int z = 0; z < splits; ++z) s += sink.ws[(size_t)z * sink.stride + (size_t)i * sink.J + j];
     e.put(i, j, s);
 }
@@ -991,7 +994,8 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
     const int i = (int)(idx / jq), j = (int)(idx - (size_t)i * jq) * 4;
     const float *src = sink.ws + (size_t)i * sink.J + j;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < splits; ++z) {
+#pragma unroll 4
+    for (int z = 0; z < splits; ++z) {       // four loads in flight, added in split order
         const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)z * sink.stride);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
