@@ -4,6 +4,9 @@
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
+#ifndef MVAE_SC_BLOCKS
+#define MVAE_SC_BLOCKS 256      // blocks (8 waves each) of the small-Cin conv weight gradient: one per CU
+#endif
 #ifndef MVAE_CONV_SMALL_FWD
 #define MVAE_CONV_SMALL_FWD 1   // <= 4-input-channel stride-2 conv forward: direct VALU kernel instead of a K <= 48 GEMM
 #endif
@@ -1306,7 +1309,7 @@ inline bool wgrad_smallcin_ok(const ConvGeom &g) {
 inline int wgrad_smallcin_blocks(const ConvGeom &g) {
     const int units = g.B * g.OH;
     int blocks = (units + SC_WAVES - 1) / SC_WAVES;
-    return blocks > 256 ? 256 : blocks;      // one 8-wave block per CU; more partials only slow the finish
+    return blocks > MVAE_SC_BLOCKS ? MVAE_SC_BLOCKS : blocks;
 }
 
 // ---- conv wgrad form: dw[co][(ci,kh,kw)] = sum_(n,oh,ow) dy[n][co][oh][ow] * x[n][ci][ih][iw] ----

@@ -76,10 +76,14 @@ __global__ __launch_bounds__(64 * EMB_LANES) void embedding_swish_bwd_kernel(con
     float s = 0.f;
     if (j < width) {
         const int per = (R + EMB_LANES - 1) / EMB_LANES, r0 = ty * per, r1 = min(R, r0 + per);
+        // unconditional loads, eight rows in flight, rows of other classes added as +0 in the same order (the
+        // rolled loop with a load under `if (class matches)` waited a memory latency per row: 15 us for 512 rows)
+#pragma unroll 8
         for (int r = r0; r < r1; ++r) {
             int cr = read_index(idx, is_float, r);
             cr = min(max(cr, 0), n_classes - 1);
-            if (cr == c) s += dact[(size_t)r * width + j];
+            const float v = dact[(size_t)r * width + j];
+            s += (cr == c) ? v : 0.f;
         }
     }
     part[ty][tx] = s;
