@@ -118,7 +118,7 @@ struct LdIm2colT {
         for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
     // slices of a FULL k-tile (gemm_core.h, buffer loads): no vector-ALU work per element
-    static constexpr bool PARTS = true;
+    static constexpr bool PARTS = true, TAIL = false;
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> 4) * (g.H * g.W));
 #pragma unroll
@@ -203,7 +203,7 @@ struct LdIm2colR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = true, fast = true;
+    static constexpr bool RMAJOR = true, PARTS = true, TAIL = false, fast = true;
     __device__ void begin(int, int) {}
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> 4) * (g.H * g.W));
@@ -326,7 +326,7 @@ struct LdDgradDyT {
 #pragma unroll
         for (int v = 0; v < NV; ++v) L[kb + v * KSTEP][m] = rg.v[v] * mask0((rg.ok >> v) & 1u);
     }
-    static constexpr bool PARTS = true;               // slices of a FULL k-tile: buffer loads, nothing on the vector ALU
+    static constexpr bool PARTS = true, TAIL = false;               // slices of a FULL k-tile: buffer loads, nothing on the vector ALU
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> (2 * TLOG)) * (g.OH * g.OW));
 #pragma unroll
@@ -412,7 +412,7 @@ struct LdDgradDyR {
         }
         rg.ok = okbits;
     }
-    static constexpr bool RMAJOR = true, PARTS = true, fast = true;
+    static constexpr bool RMAJOR = true, PARTS = true, TAIL = false, fast = true;
     __device__ void begin(int, int) {}
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> (2 * TLOG)) * (g.OH * g.OW));
@@ -512,7 +512,7 @@ struct LdWgradDy {
 #pragma unroll
         for (int v = 0; v < NV; ++v) rg.v[v] = src[(v < nv) ? v * ISTEP * ohw : safe];
     }
-    static constexpr bool PARTS = true;
+    static constexpr bool PARTS = true, TAIL = false;
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) {
         const int ohw = g.OH * g.OW;
         if (part == 0) {
@@ -596,7 +596,7 @@ struct LdWgradX {
         }
         rg.ok = okbits;
     }
-    static constexpr bool PARTS = true;
+    static constexpr bool PARTS = true, TAIL = false;
     int voff_a, voff_b;     // this k-step's offsets for the even / odd elements (tap rows jq>>2 and (jq>>2)+2), or BUF_OOB
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) {
         const int hw = g.H * g.W;

@@ -175,12 +175,15 @@ struct LdRowsKT {
         }
     }
     // full k-tile, slice `part` of `nparts` (the interleaved main loop issues one slice per MFMA group)
-    static constexpr bool PARTS = VEC;
-    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+    // A partial LAST k-tile is covered too (TAIL): the float4s at or beyond kend take the out-of-range offset
+    // (one compare + NV selects per k-step; a thread's k column is the same for all its float4s).
+    static constexpr bool PARTS = VEC, TAIL = VEC;
+    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)k0);
+        const bool cut = (t % (BKV / 4)) * 4 >= kend - k0;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load4(rs, voff[VEC ? v : 0]);
+            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load4(rs, cut ? BUF_OOB : voff[VEC ? v : 0]);
     }
     // LDS image [TILE][BKV + 4]: the tile as it lies in memory (k contiguous), float4 stores, rows
     // 16-byte aligned.  The row pitch 4 * odd makes the ds_read_b128 fragment reads -- lane (row, 4 k's)
@@ -267,12 +270,14 @@ struct LdRowsMNT {
             rg.v[v] = x;
         }
     }
-    static constexpr bool PARTS = VEC;
-    __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
+    static constexpr bool PARTS = VEC, TAIL = VEC;    // partial last k-tile: rows k >= kend read as zero
+    __device__ __forceinline__ void load_part(int k0, int kend, int t, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)k0 * ld);
+        const int left = kend - k0 - t / V4;          // float4 v sits in tile row t / V4 + v * (NTHREADS / V4)
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load4(rs, voff[VEC ? v : 0]);
+            if (MVAE_IN_PART(v, NV, part, nparts))
+                rg.v[v] = buf_load4(rs, (v * (NTHREADS / V4) >= left) ? BUF_OOB : voff[VEC ? v : 0]);
     }
     // LDS image [BKV][TILE + 4] (k-major: the non-reduced axis contiguous, as in memory)
     static constexpr bool RMAJOR = false;
@@ -597,7 +602,8 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // for a few hundred cycles per k-step and the pipe idles unless another block's wave happens to be in its
     // MFMA phase (tools/mfma_peak: the pipe itself sustains 154.6 TFLOP/s from one wave per SIMD).
     constexpr bool CAN_IL = (NT == NTHREADS) && P::PARTS && Q::PARTS && MVAE_INTERLEAVE;
-    const bool full = nsteps > 0 && (kend - kbeg) % BKK == 0 && p.fast && q.fast;    // block-uniform
+    // block-uniform: the buffer path covers the block's k range (row loaders also take a partial last tile)
+    const bool full = nsteps > 0 && ((kend - kbeg) % BKK == 0 || (P::TAIL && Q::TAIL)) && p.fast && q.fast;
     const bool il = CAN_IL && full;
     p.begin(kbeg, t); q.begin(kbeg, t);
     // ---- multi-item blocks: the pipeline of the interleaved loops, run across the block's items
