@@ -144,6 +144,24 @@ int mvae_convT2d_k4_wgrad(const float *dy, const float *x, float *dw,
                           int B, int Cin, int H, int W, int Cout, int stride, int pad,
                           int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
 
+/* The two dgrad-form launches -- mvae_conv2d_k4_dgrad and mvae_convT2d_k4_fwd -- read the weights from a
+ * repacked copy (parity-class major, input channel contiguous) in `ws`.  With `w` given they make that copy
+ * themselves, a small launch in front of every call.  A caller that runs many steps can make the copies of all
+ * its layers in ONE launch per step instead (the weights only change in the optimizer) and pass w = NULL with
+ * ws = the layer's copy:
+ *   mvae_conv_k4_repack_floats   floats of the copy this launch would read, or 0 if it reads `w` directly (the
+ *                                <= 4-channel and stride-1 5x5 shapes have their own kernels) -- then w = NULL is
+ *                                MVAE_ERR_ARG.  transposed: 0 = Conv2d data gradient, 1 = ConvTranspose2d forward;
+ *                                B, Cin, H, W, Cout, stride, pad exactly as in that call.
+ *   mvae_conv_k4_repack_batched  up to 16 copies in one launch (Cin, Cout: the module's own). */
+typedef struct {
+    const float *w; float *wr;
+    int transposed, Cin, Cout, stride, pad;
+} mvae_repack_item;
+size_t mvae_conv_k4_repack_floats(int transposed, const float *w, int B, int Cin, int H, int W, int Cout,
+                                  int stride, int pad);
+int mvae_conv_k4_repack_batched(const mvae_repack_item *items, int n_items, mvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K4  BatchNorm2d / BatchNorm1d (training mode, eps 1e-5, momentum 0.1) + fused Swish:
  *     celeba/model.py:80,83,86,118,121,124,149,152,176,179,182; celeba19/model.py:106,109,

@@ -43,6 +43,14 @@ class WgradItem(ctypes.Structure):          # mvae_wgrad_item
 WGRAD_BATCH_MAX = 16
 
 
+class RepackItem(ctypes.Structure):         # mvae_repack_item
+    _fields_ = [('w', c_void_p), ('wr', c_void_p), ('transposed', c_int), ('Cin', c_int), ('Cout', c_int),
+                ('stride', c_int), ('pad', c_int)]
+
+
+REPACK_MAX = 16
+
+
 class ExpertGrads(ctypes.Structure):
     _fields_ = [('dmu', c_void_p * MAX_EXPERTS), ('dlogvar', c_void_p * MAX_EXPERTS)]
 
@@ -98,6 +106,8 @@ _SIGNATURES = {
     'mvae_ce_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_ce_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    'mvae_conv_k4_repack_floats': (c_size_t, [c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'mvae_conv_k4_repack_batched': (c_int, [ctypes.POINTER(RepackItem), c_int, P]),
     'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),

@@ -1127,11 +1127,13 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     const int s = g.stride, tlog = (s == 2) ? 1 : 2;
     const int H2 = g.H / s, W2 = g.W / s;
     const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << (2 * tlog);
-    if (conv_dgrad_small_ok(g) && !MVAE_TUNE(wm)) return conv_dgrad_small(dy, w, dx, act, dpre, g, st);
-    if (conv_dgrad_s1_ok(g, w) && !MVAE_TUNE(wm)) return conv_dgrad_s1(dy, w, dx, act, dpre, g, st);
+    // w == NULL: `ws` already holds the repacked weights (mvae_conv_k4_repack_batched) -- only valid for launches
+    // that read them (mvae_conv_k4_repack_floats != 0)
+    if (conv_dgrad_small_ok(g) && !MVAE_TUNE(wm)) return w ? conv_dgrad_small(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
+    if (conv_dgrad_s1_ok(g, w) && !MVAE_TUNE(wm)) return w ? conv_dgrad_s1(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
     if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
     float *wr = (float *)ws;
-    {
+    if (w) {
         const int total = s * s * K * g.Cin;
         int blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
@@ -1373,7 +1375,7 @@ MVAE_EXPORT int mvae_conv2d_k4_fwd(const float *x, const float *w, float *pre, f
 MVAE_EXPORT int mvae_conv2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,
                                      int Cin, int H, int W, int Cout, int stride, int pad, void *ws,
                                      size_t ws_bytes, mvae_stream_t stream) {
-    if (!dy || !w || !dx || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
+    if (!dy || (!w && !ws) || !dx || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
     return conv_dgrad_impl(dy, w, dx, nullptr, pre_in, make_geom(B, Cin, H, W, Cout, stride, pad), ws, ws_bytes,
                            (hipStream_t)stream);
 }
@@ -1395,11 +1397,78 @@ static inline bool convT_geom(int B, int Cin, int H, int W, int Cout, int stride
     return g->OH == H && g->OW == W;
 }
 
+// ---- the repacked weight copies of several layers in ONE launch, ahead of the step: the dgrad-form launches
+//      (Conv2d data gradient, ConvTranspose2d forward) read the weights class-major / channel-contiguous;
+//      repacking inside every launch put a 5-us kernel on the chain in front of each of them ----
+constexpr int REPACK_MAX = 16;
+struct RepackArgs { const float *w[REPACK_MAX]; float *wr[REPACK_MAX]; int Cout[REPACK_MAX], Cin[REPACK_MAX], stride[REPACK_MAX], pad[REPACK_MAX], end[REPACK_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void repack_batched_kernel(RepackArgs a) {
+    const int total = a.end[a.n - 1];
+    for (int gidx = blockIdx.x * 256 + threadIdx.x; gidx < total; gidx += gridDim.x * 256) {
+        int q = 0;
+        while (gidx >= a.end[q]) ++q;
+        const int idx = gidx - (q ? a.end[q - 1] : 0);
+        const int Cout = a.Cout[q], Cin = a.Cin[q], stride = a.stride[q], pad = a.pad[q];
+        const int tlog = (stride == 2) ? 1 : 2, tpd = 1 << tlog;
+        const int kc = Cout * tpd * tpd;
+        const int ci = idx % Cin;
+        const int rest = idx / Cin;
+        const int k = rest % kc, cls = rest / kc;
+        const int ph = cls / stride, pw = cls % stride;
+        const int kh0 = (ph + pad) % stride, kw0 = (pw + pad) % stride;
+        const int co = k >> (2 * tlog), aa = (k >> tlog) & (tpd - 1), bb = k & (tpd - 1);
+        a.wr[q][idx] = a.w[q][((co * Cin + ci) * 4 + kh0 + stride * aa) * 4 + kw0 + stride * bb];
+    }
+}
+
+// geometry of the dgrad-form launch behind a Conv2d data gradient (transposed = 0) or a ConvTranspose2d forward (1)
+static inline bool repack_geom(int transposed, int B, int Cin, int H, int W, int Cout, int stride, int pad, ConvGeom *g) {
+    if (transposed) {
+        const int OH = (H - 1) * stride - 2 * pad + 4, OW = (W - 1) * stride - 2 * pad + 4;
+        if (!conv_args_ok(B, Cout, OH, OW, Cin, stride, pad)) return false;
+        *g = make_geom(B, Cout, OH, OW, Cin, stride, pad);
+        return g->OH == H && g->OW == W;
+    }
+    if (!conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return false;
+    *g = make_geom(B, Cin, H, W, Cout, stride, pad);
+    return true;
+}
+
+MVAE_EXPORT size_t mvae_conv_k4_repack_floats(int transposed, const float *w, int B, int Cin, int H, int W, int Cout,
+                                              int stride, int pad) {
+    ConvGeom g;
+    if (!w || B <= 0 || !repack_geom(transposed, B, Cin, H, W, Cout, stride, pad, &g)) return 0;
+    if (conv_dgrad_small_ok(g) || conv_dgrad_s1_ok(g, w)) return 0;       // direct kernels read w itself
+    return dgrad_ws_floats(g);
+}
+
+MVAE_EXPORT int mvae_conv_k4_repack_batched(const mvae_repack_item *items, int n_items, mvae_stream_t stream) {
+    if (!items || n_items < 1 || n_items > REPACK_MAX) return MVAE_ERR_ARG;
+    RepackArgs a;
+    a.n = n_items;
+    int total = 0;
+    for (int q = 0; q < n_items; ++q) {
+        const mvae_repack_item &s = items[q];
+        if (!s.w || !s.wr || s.Cin < 1 || s.Cout < 1 || (s.stride != 1 && s.stride != 2) || s.pad < 0) return MVAE_ERR_ARG;
+        a.w[q] = s.w; a.wr[q] = s.wr;
+        a.Cout[q] = s.transposed ? s.Cin : s.Cout;      // of the underlying w[co][ci][4][4] view
+        a.Cin[q] = s.transposed ? s.Cout : s.Cin;
+        a.stride[q] = s.stride; a.pad[q] = s.pad;
+        total += s.Cin * s.Cout * 16;
+        a.end[q] = total;
+    }
+    int blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(repack_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, float *act, int B, int Cin,
                                     int H, int W, int Cout, int stride, int pad, void *ws, size_t ws_bytes,
                                     mvae_stream_t stream) {
     ConvGeom g;
-    if (!x || !w || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
+    if (!x || (!w && !ws) || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
     return conv_dgrad_impl(x, w, pre, act, nullptr, g, ws, ws_bytes, (hipStream_t)stream);
 }
 

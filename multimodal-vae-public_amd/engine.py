@@ -142,6 +142,8 @@ class _StepBase(object):
         # with two branches in flight the kernels already fill the CUs; a fork per LAYER was 30 %
         # slower (every fork is a cross-queue signal).
         self.batch_wgrad = os.environ.get('MVAE_BATCH_WGRAD', '1') != '0'
+        self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
+        self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
         self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 3 else None
         self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else self.wg_main
         self._wg_pending = []
@@ -217,6 +219,7 @@ class _StepBase(object):
     def forward_backward(self, image, label):
         """Launch the whole forward + backward.  Gradients go to ``p.grad`` (the arena); returns
         the device tensor ``elbo[T+1]`` = per-term ELBOs (engine order) and their sum."""
+        self._step_begin()
         self._phase_a(image, label)
         if self.on_bucket_ready is not None and self.n_buckets > 1:
             self.on_bucket_ready(0)      # decoder gradients are final
@@ -224,7 +227,18 @@ class _StepBase(object):
             part()
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(k + 1 if self.n_buckets > 1 else 0)   # this group of encoder gradients is final
+        self._step_end()
         return self.elbo
+
+    def _step_begin(self):
+        """Ahead of the step: the repacked weight copies of all dgrad-form conv launches in ONE launch (the
+        launches otherwise each make their own, a 5-us kernel in front of every one of them on the chain)."""
+        if self.batch_repack:
+            L.repack_weights(self._conv_mods)
+
+    def _step_end(self):
+        if self.batch_repack:
+            L.repack_done(self._conv_mods)      # the optimizer changes the weights next
 
     def step(self, image, label, annealing_factor, noise=None):
         """One eager step (no optimizer): zero_grad -> forward/backward.  Returns elbo[T+1]."""
@@ -255,7 +269,7 @@ class _StepBase(object):
         with torch.cuda.stream(side):
             for it in range(warmup):
                 before = [m._nbt_pending for m in bns]
-                self._body_a(); self._phase_b('all'); optimizer.step()
+                self._body_a(); self._phase_b('all'); self._step_end(); optimizer.step()
                 # graph replays skip the host code that counts BatchNorm calls: remember the
                 # per-step increments of num_batches_tracked and re-apply them in replay()
                 self._bn_inc = [(m, m._nbt_pending - b) for m, b in zip(bns, before)]
@@ -264,7 +278,7 @@ class _StepBase(object):
         if comm is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._body_a(); self._phase_b('all'); optimizer.step()
+                self._body_a(); self._phase_b('all'); self._step_end(); optimizer.step()
             self._graphs = (g,)
         else:
             # data parallel: one graph per gradient bucket (A = forward + decoder backward, then one or two
@@ -280,6 +294,7 @@ class _StepBase(object):
                 with torch.cuda.graph(g, pool=pool):
                     part()
                 graphs.append(g)
+            self._step_end()
             self._graphs = tuple(graphs)
             self._optimizer = optimizer
         _restore(self.model, optimizer, self.counter, snap)   # warm-up steps must leave no trace
@@ -289,6 +304,7 @@ class _StepBase(object):
 
     def _body_a(self):
         self.model.zero_grad(set_to_none=True)
+        self._step_begin()
         self.draw_noise()
         self._phase_a(self.static_image, self.static_label)
 

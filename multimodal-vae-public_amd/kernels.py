@@ -258,8 +258,12 @@ def embedding_swish_bwd_grouped(idx, w0, w_gs, dact, dw0, accumulate=False):
 
 
 # ---------------------------------------------------------------------------- Conv 4x4
-def _conv_call(name, a, b, c, d, B, Cin, H, W, Cout, stride, pad, repack=False):
-    if repack:      # dgrad-form launches repack the weights (Cout*Cin*16 floats) into scratch first
+def _conv_call(name, a, b, c, d, B, Cin, H, W, Cout, stride, pad, repack=False, wr=None):
+    if repack and wr is not None:       # the caller made the repacked copy already (conv_repack_batched): w = NULL
+        _need_gpu(wr); _f32c(wr)
+        check(getattr(_lib.lib(), name)(_ptr(a), None, _ptr(c), _ptr(d), B, Cin, H, W, Cout, stride, pad,
+                                        _ptr(wr), wr.numel() * 4, _stream()), name)
+    elif repack:    # dgrad-form launches repack the weights (Cout*Cin*16 floats) into scratch first
         ws, wsb = _ws_args(Cout * Cin * 16 * 4, a.device)
         check(getattr(_lib.lib(), name)(_ptr(a), _ptr(b), _ptr(c), _ptr(d), B, Cin, H, W, Cout, stride, pad,
                                         ws, wsb, _stream()), name)
@@ -274,10 +278,30 @@ def conv2d_fwd(x, w, pre, act, stride, pad):
     _conv_call('mvae_conv2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[0], stride, pad)
 
 
-def conv2d_dgrad(dy, w, dx, pre_in, stride, pad):
+def conv2d_dgrad(dy, w, dx, pre_in, stride, pad, wr=None):
     _need_gpu(dy, w, dx, pre_in); _f32c(dy, w, dx, pre_in)
     B, Cin, H, W = dx.shape
-    _conv_call('mvae_conv2d_k4_dgrad', dy, w, dx, pre_in, B, Cin, H, W, w.shape[0], stride, pad, repack=True)
+    _conv_call('mvae_conv2d_k4_dgrad', dy, w, dx, pre_in, B, Cin, H, W, w.shape[0], stride, pad, repack=True, wr=wr)
+
+
+def conv_repack_floats(transposed, w, B, Cin, H, W, Cout, stride, pad):
+    """Floats of the repacked weight copy a Conv2d data gradient (transposed False) / ConvTranspose2d forward
+    (True) of this geometry reads, or 0 when that launch reads ``w`` itself (include/mvae_hip.h)."""
+    return int(_lib.lib().mvae_conv_k4_repack_floats(1 if transposed else 0, _ptr(w), B, Cin, H, W, Cout, stride, pad))
+
+
+def conv_repack_batched(items):
+    """items: [(w, wr, transposed, Cin, Cout, stride, pad)] -- all repacked copies in one launch (16 per launch)."""
+    items = list(items)
+    for lo in range(0, len(items), _lib.REPACK_MAX):
+        chunk = items[lo:lo + _lib.REPACK_MAX]
+        arr = (_lib.RepackItem * len(chunk))()
+        for q, (w, wr, tr, Cin, Cout, s, p) in enumerate(chunk):
+            _need_gpu(w, wr); _f32c(w, wr)
+            if wr.numel() < Cin * Cout * 16:
+                raise RuntimeError('repack buffer too small')
+            arr[q] = _lib.RepackItem(_ptr(w), _ptr(wr), 1 if tr else 0, Cin, Cout, s, p)
+        check(_lib.lib().mvae_conv_k4_repack_batched(arr, len(chunk), _stream()), 'mvae_conv_k4_repack_batched')
 
 
 def conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False):
@@ -291,11 +315,11 @@ def conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False):
           'mvae_conv2d_k4_wgrad')
 
 
-def convT2d_fwd(x, w, pre, act, stride, pad):
+def convT2d_fwd(x, w, pre, act, stride, pad, wr=None):
     """x[B,Cin,H,W], w[Cin,Cout,4,4] -> [B,Cout,(H-1)s-2p+4, ...]"""
     _need_gpu(x, w, pre, act); _f32c(x, w, pre, act)
     B, Cin, H, W = x.shape
-    _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad, repack=True)
+    _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad, repack=True, wr=wr)
 
 
 def convT2d_dgrad(dy, w, dx, pre_in, stride, pad):

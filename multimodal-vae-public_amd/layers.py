@@ -301,7 +301,12 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
                 pre = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
             if op.act:
                 act = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
-            (K.conv2d_fwd if op.kind == 'conv' else K.convT2d_fwd)(h, m.weight.detach(), pre, act, s, p)
+            if op.kind == 'conv':
+                K.conv2d_fwd(h, m.weight.detach(), pre, act, s, p)
+            else:
+                if training:
+                    _probe_repack(m, True, Bn, h.shape[1], H, W, Cout, s, p)
+                K.convT2d_fwd(h, m.weight.detach(), pre, act, s, p, wr=_fresh_repack(m))
             saved = (h, pre if op.act else None, None)
             h = act if op.act else pre
         elif op.kind == 'bn':
@@ -417,8 +422,12 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             side(conv_wgrad)
             if want_dx:
                 dx = torch.empty_like(x)
-                (K.conv2d_dgrad if op.kind == 'conv' else K.convT2d_dgrad)(
-                    g, m.weight.detach(), dx, None if pre_in is None else pre_in.reshape(x.shape), s, p)
+                pin = None if pre_in is None else pre_in.reshape(x.shape)
+                if op.kind == 'conv':
+                    _probe_repack(m, False, x.shape[0], x.shape[1], x.shape[2], x.shape[3], m.out_channels, s, p)
+                    K.conv2d_dgrad(g, m.weight.detach(), dx, pin, s, p, wr=_fresh_repack(m))
+                else:
+                    K.convT2d_dgrad(g, m.weight.detach(), dx, pin, s, p)
                 g = dx
         elif op.kind == 'bn':
             m = op.mod
@@ -459,6 +468,42 @@ def _conv_out_shape(op, x):
     if op.kind == 'conv':
         return (Bn, m.out_channels, (H + 2 * p - 4) // s + 1, (W + 2 * p - 4) // s + 1)
     return (Bn, m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4)
+
+
+# ---- repacked weight copies of the dgrad-form conv launches (Conv2d data gradient, ConvTranspose2d forward).
+# The launches make the copy themselves unless handed one; a step engine makes all of them in ONE launch at the
+# start of its step (``repack_weights``) and withdraws them at its end (``repack_done``) -- between steps the
+# optimizer changes the weights, and anything run outside an engine step takes the self-contained path.
+def _probe_repack(m, transposed, B, Cin, H, W, Cout, s, p):
+    if getattr(m, '_wr_item', None) is None:
+        n = K.conv_repack_floats(transposed, m.weight.detach(), B, Cin, H, W, Cout, s, p)
+        m._wr = torch.empty(n, dtype=torch.float32, device=m.weight.device) if n else None
+        m._wr_item = (bool(transposed), Cin, Cout, s, p)
+        m._wr_fresh = False
+
+
+def _fresh_repack(m):
+    return m._wr if getattr(m, '_wr_fresh', False) else None
+
+
+def repack_weights(mods):
+    """One launch for the repacked copies of every probed conv module in ``mods``; marks them usable."""
+    items = []
+    for m in mods:
+        if getattr(m, '_wr', None) is not None:
+            tr, Cin, Cout, s, p = m._wr_item
+            items.append((m.weight.detach(), m._wr, tr, Cin, Cout, s, p))
+    if items:
+        K.conv_repack_batched(items)
+        for m in mods:
+            if getattr(m, '_wr', None) is not None:
+                m._wr_fresh = True
+
+
+def repack_done(mods):
+    for m in mods:
+        if getattr(m, '_wr_fresh', False):
+            m._wr_fresh = False
 
 
 def _lin_wgrad_targets(op):

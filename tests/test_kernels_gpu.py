@@ -122,6 +122,35 @@ def test_linear_wgrad_batched(shapes):
         assert_close(dw, dw1.cpu(), 'batched vs single', tol=1e-6)
 
 
+def test_conv_repack_batched_equals_in_launch_repack():
+    """Repacked weight copies made ahead in one launch (w = NULL to the compute launch) == the copies the launches
+    make themselves; shapes with their own kernels report 0 floats and refuse w = NULL."""
+    B = 3
+    conv_w = dev(g(64, 32, 4, 4, seed=300, scale=0.05))          # Conv2d(32, 64), 32x32 input, stride 2
+    convT_w = dev(g(128, 64, 4, 4, seed=301, scale=0.05))        # ConvTranspose2d(128, 64), 8x8 input
+    n1 = K.conv_repack_floats(False, conv_w, B, 32, 32, 32, 64, 2, 1)
+    n2 = K.conv_repack_floats(True, convT_w, B, 128, 8, 8, 64, 2, 1)
+    assert n1 == 64 * 32 * 16 and n2 == 128 * 64 * 16
+    wr1, wr2 = torch.empty(n1, device=DEV), torch.empty(n2, device=DEV)
+    K.conv_repack_batched([(conv_w, wr1, False, 32, 64, 2, 1), (convT_w, wr2, True, 128, 64, 2, 1)])
+    dy = dev(g(B, 64, 16, 16, seed=302)); dx_a = torch.empty(B, 32, 32, 32, device=DEV); dx_b = torch.empty_like(dx_a)
+    K.conv2d_dgrad(dy, conv_w, dx_a, None, 2, 1)
+    K.conv2d_dgrad(dy, conv_w, dx_b, None, 2, 1, wr=wr1)
+    assert torch.equal(dx_a, dx_b)
+    x = dev(g(B, 128, 8, 8, seed=303)); y_a = torch.empty(B, 64, 16, 16, device=DEV); y_b = torch.empty_like(y_a)
+    K.convT2d_fwd(x, convT_w, y_a, None, 2, 1)
+    K.convT2d_fwd(x, convT_w, y_b, None, 2, 1, wr=wr2)
+    assert torch.equal(y_a, y_b)
+    # direct-kernel shapes: the 5x5 stride-1 transposed conv and the 3-channel output
+    s1_w = dev(g(256, 128, 4, 4, seed=304, scale=0.05))
+    assert K.conv_repack_floats(True, s1_w, B, 256, 5, 5, 128, 1, 0) == 0
+    small_w = dev(g(32, 3, 4, 4, seed=305, scale=0.05))
+    assert K.conv_repack_floats(True, small_w, B, 32, 32, 32, 3, 2, 1) == 0
+    with pytest.raises(RuntimeError):
+        K.convT2d_fwd(dev(g(B, 32, 32, 32, seed=306)), small_w, torch.empty(B, 3, 64, 64, device=DEV), None, 2, 1,
+                      wr=torch.empty(32 * 3 * 16, device=DEV))
+
+
 def test_linear_wgrad_batched_rejects_shared_gradient():
     dy, x = dev(g(64, 32, seed=1)), dev(g(64, 32, seed=2))
     dw = torch.empty(32, 32, device=DEV)
