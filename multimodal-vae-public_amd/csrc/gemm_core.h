@@ -1034,7 +1034,7 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
     const bool forced = MVAE_TUNE(wm) || MVAE_TUNE(wn) || MVAE_TUNE(kw);
     if (small_ok && !forced && !MVAE_TUNE(small_off)) {
         const long t64 = cdiv(I, 64) * cdiv(J, 64) * ncls, t32 = cdiv(I, 32) * cdiv(J, 32) * ncls;
-        if (t64 < 256 && (t32 >= 192 || K <= 1024)) {
+        if (t64 < 256 && (t32 >= 192 || K <= 1024) && K < 4096) {
             // largest tile that still gives (nearly) every CU a block; between the two 2-tile shapes the one
             // that pads less (ties: 32x64 -- the j axis is the contiguous store axis)
             const long b_tall = cdiv(I, 64) * cdiv(J, 32) * ncls, b_wide = cdiv(I, 32) * cdiv(J, 64) * ncls;
@@ -1063,6 +1063,11 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
         if (J >= 128) p.wn = 2;
         if (I >= 128 && J >= 128) p.wm = 2;
     }
+    // long reductions into a small output (FashionMNIST's 6272-wide layers: 1024 x 512 over K = 6272): 64 x 128
+    // tiles, split over K, beat the k-grouped small layouts (86 -> 101, 91 -> 100 TFLOP/s)
+    if (kind == PLAN_FWD && allow_split && !narrow && !forced && K >= 4096 && J >= 128 &&
+        cdiv(I, 64) * cdiv(J, 64) * ncls <= 256 && cdiv(I, 64) * cdiv(J, 64) * ncls >= 64)
+        p.wn = 2;
     if (MVAE_TUNE(wm)) p.wm = MVAE_TUNE(wm);
     if (MVAE_TUNE(wn)) p.wn = MVAE_TUNE(wn);
     const long tiles = narrow ? cdiv(J, 128) * ncls : cdiv(I, 64 * p.wm) * cdiv(J, 64 * p.wn) * ncls;

@@ -55,13 +55,21 @@ class Linear(nn.Linear):
         return run_stack([self], x)
 
 
-class Conv2d(nn.Conv2d):
+class _RepackMixin(object):
+    """Conv modules may carry a repacked weight copy (``_probe_repack``); moving the module drops it."""
+    def _apply(self, fn, *a, **kw):
+        for name in ('_wr', '_wr_item', '_wr_fresh'):
+            self.__dict__.pop(name, None)
+        return super()._apply(fn, *a, **kw)
+
+
+class Conv2d(_RepackMixin, nn.Conv2d):
     """4x4, bias=False, (stride, pad) in {(2,1), (1,0)} -- the only shapes on the hot path."""
     def forward(self, x):
         return run_stack([self], x)
 
 
-class ConvTranspose2d(nn.ConvTranspose2d):
+class ConvTranspose2d(_RepackMixin, nn.ConvTranspose2d):
     def forward(self, x):
         return run_stack([self], x)
 
