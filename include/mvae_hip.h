@@ -353,6 +353,11 @@ int mvae_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
 int mvae_adam_apply(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                     const int64_t *step_dev, mvae_stream_t stream);
+/* mvae_adam_apply at step t = *step_dev + step_add (step_add = 0: the caller advanced the counter earlier in
+ * the step, off the critical chain, and needs no counter launch behind the update) */
+int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                       size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
+                       const int64_t *step_dev, int64_t step_add, mvae_stream_t stream);
 int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
 int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
 

@@ -115,6 +115,8 @@ _SIGNATURES = {
     'mvae_bernoulli': (c_int, [P, c_size_t, c_float, c_uint64, P, P]),
     'mvae_adam_step': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P, P]),
     'mvae_adam_apply': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P, P]),
+    'mvae_adam_apply_at': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P,
+                                   ctypes.c_int64, P]),
     'mvae_counter_add': (c_int, [P, ctypes.c_int64, P]),
     'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
     'mvae_reparam_fwd': (c_int, [P, P, P, P, c_size_t, P]),

@@ -154,12 +154,12 @@ __global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
                                                    double lr, double b1d, double b2d, double epsd, float gscale,
-                                                   const int64_t *step_dev) {
+                                                   const int64_t *step_dev, int64_t step_add) {
     // hyper-parameters arrive as doubles and are rounded the way torch rounds python floats into
     // fp32 tensor ops: beta and (1 - beta) separately (1 - 0.999 != 1 - float(0.999))
     const float b1 = (float)b1d, b2 = (float)b2d, eps = (float)epsd;
     const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const double t = (double)(*step_dev + 1);
+    const double t = (double)(*step_dev + step_add);
     const float step_size = (float)(lr / (1.0 - pow(b1d, t)));
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(b2d, t)));
     const size_t n4 = n / 4;
@@ -316,7 +316,7 @@ MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, 
     if (n == 0) return MVAE_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev, (int64_t)1);
     hipLaunchKernelGGL(bump_i64_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return mvae_launch_status();
 }
@@ -330,7 +330,19 @@ MVAE_EXPORT int mvae_adam_apply(float *param, const float *grad, float *exp_avg,
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev);
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, (int64_t)1);
+    return mvae_launch_status();
+}
+
+// The same at step t = *step_dev + step_add: a caller that advanced the counter earlier in the step (off the
+// critical chain) passes step_add = 0 and needs no counter launch behind the update.
+MVAE_EXPORT int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                   double lr, double beta1, double beta2, double eps, float grad_scale,
+                                   const int64_t *step_dev, int64_t step_add, mvae_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, step_add);
     return mvae_launch_status();
 }
 

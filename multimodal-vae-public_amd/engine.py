@@ -269,7 +269,7 @@ class _StepBase(object):
         with torch.cuda.stream(side):
             for it in range(warmup):
                 before = [m._nbt_pending for m in bns]
-                self._body_a(); self._phase_b('all'); self._step_end(); optimizer.step()
+                self._single_gpu_step(optimizer)
                 # graph replays skip the host code that counts BatchNorm calls: remember the
                 # per-step increments of num_batches_tracked and re-apply them in replay()
                 self._bn_inc = [(m, m._nbt_pending - b) for m, b in zip(bns, before)]
@@ -278,7 +278,7 @@ class _StepBase(object):
         if comm is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._body_a(); self._phase_b('all'); self._step_end(); optimizer.step()
+                self._single_gpu_step(optimizer)
             self._graphs = (g,)
         else:
             # data parallel: one graph per gradient bucket (A = forward + decoder backward, then one or two
@@ -301,6 +301,27 @@ class _StepBase(object):
         torch.cuda.synchronize(dev)
         self.on_bucket_ready = hook
         return self._graphs
+
+    def _single_gpu_step(self, optimizer):
+        """The captured single-GPU step.  With the fused optimizer the step counter is advanced on the side stream behind
+        the label / attribute encoders' forward -- the shorter encoder branch; a one-thread launch, nothing waits for it -- and the update at the end of the chain
+        is ONE launch at t = counter (MVAE_EARLY_COUNTER=0: update + counter launch at the end)."""
+        early = (os.environ.get('MVAE_EARLY_COUNTER', '1') != '0' and self.side is not None
+                 and hasattr(optimizer, 'step_counted'))
+        self._adam_counter = optimizer.step_counter() if early else None
+        self._body_a()
+        self._phase_b('all')
+        self._step_end()
+        if early:
+            optimizer.step_counted()
+        else:
+            optimizer.step()
+        self._adam_counter = None
+
+    def _early_counter(self):
+        """Called at the end of the side stream's encoder forward (the shorter of the two encoder branches)."""
+        if getattr(self, '_adam_counter', None) is not None:
+            K.counter_add(self._adam_counter, 1)
 
     def _body_a(self):
         self.model.zero_grad(set_to_none=True)
@@ -505,6 +526,7 @@ class BimodalStep(_StepBase):
         lbl_in = label if m.LABEL_KIND == 'class' else label.float().contiguous()
         with self._branch():
             heads_lbl, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
+            self._early_counter()
         if self.has_dropout:
             h, c['tape_trunk'] = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
             hd = torch.empty(2 * B, h.shape[1], dtype=torch.float32, device=self.dev)
@@ -891,6 +913,7 @@ class Celeba19Step(_StepBase):
                 for i in range(N_ATTRS):
                     ha, tp = L.forward_tape(self.enc_plans[i], attrs[:, i])
                     heads_attr.append(ha); c['tape_enc'].append(tp)
+            self._early_counter()
         # ---- image encoder: trunk once, n_img Dropout draws, head on n_img*B rows
         h, c['tape_trunk'] = L.forward_tape(self.trunk, image, bn_updates=self.n_img_present,
                                             bn_updates_dev=self.nimg_dev)

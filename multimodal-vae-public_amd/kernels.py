@@ -656,6 +656,15 @@ def adam_apply(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=
           'mvae_adam_apply')
 
 
+def adam_apply_at(param, grad, exp_avg, exp_avg_sq, step_dev, step_add, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+                  grad_scale=1.0):
+    """Adam at step *step_dev + step_add, counter untouched (step_add 0: it was advanced earlier in the step)."""
+    _need_gpu(param, grad, exp_avg, exp_avg_sq, step_dev); _f32c(param, grad, exp_avg, exp_avg_sq)
+    check(_lib.lib().mvae_adam_apply_at(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                        lr, beta1, beta2, eps, grad_scale, _ptr(step_dev), int(step_add), _stream()),
+          'mvae_adam_apply_at')
+
+
 def counter_add(counter_dev, delta):
     _need_gpu(counter_dev)
     check(_lib.lib().mvae_counter_add(_ptr(counter_dev), int(delta), _stream()), 'mvae_counter_add')

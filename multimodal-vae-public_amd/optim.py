@@ -63,6 +63,26 @@ class FusedAdam(torch.optim.Optimizer):
                     g['betas'][1], g['eps'], self.grad_scale)
         self._host_step += 1
 
+    def step_counter(self):
+        """The device step counter (binding the arena if needed): a fused step engine advances it itself early
+        in the step, off the critical chain, and then calls ``step_counted()`` instead of ``step()``."""
+        arena = self._arena
+        if arena is None or arena is not getattr(self.param_groups[0]['params'][0], '_arena', None):
+            self._bind()
+        return self._step_dev
+
+    @torch.no_grad()
+    def step_counted(self):
+        """``step()`` for a caller that already advanced ``step_counter()`` by one this step: one launch."""
+        arena = self._arena
+        for p in arena.params:
+            if p.grad is None:
+                raise RuntimeError('a parameter received no gradient this step')
+        g = self.param_groups[0]
+        K.adam_apply_at(arena.flat, arena.grad, self._m, self._v, self._step_dev, 0, g['lr'], g['betas'][0],
+                        g['betas'][1], g['eps'], self.grad_scale)
+        self._host_step += 1
+
     @torch.no_grad()
     def step_range(self, lo, hi):
         """Adam on arena elements [lo, hi) at the CURRENT step (counter not advanced): data-parallel

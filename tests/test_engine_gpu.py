@@ -271,3 +271,26 @@ def test_training_trajectory_with_fused_adam_and_graph():
     assert all(np.isfinite(losses)) and len(set(losses)) == 4
     assert not torch.equal(before, model.arena.flat)
     assert opt._step_dev.item() == 5 + 4
+
+
+def test_captured_step_with_early_counter_equals_update_plus_counter_launch(monkeypatch):
+    """The captured single-GPU step advances Adam's step counter at the start of the step on the side stream and
+    updates in one launch; MVAE_EARLY_COUNTER=0 is the update + counter launch at the end.  Same parameters, bit
+    for bit, and the same counter."""
+    kind, batch = 'mnist', 32
+    finals = []
+    for early in ('1', '0'):
+        monkeypatch.setenv('MVAE_EARLY_COUNTER', early)
+        _, model, _ = build_pair(kind, weight_seed=23)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        eng = BimodalStep(model, batch, 1.0, 50.0)
+        image, label = OS.synthetic_batch(kind, batch, seed=600)
+        eng.capture(opt, image.shape[1:], label)
+        for step in range(3):
+            image, label = OS.synthetic_batch(kind, batch, seed=610 + step)
+            eng.replay(image.to(DEV), label.to(DEV), 0.5)
+        torch.cuda.synchronize()
+        assert opt._step_dev.item() == 3
+        finals.append(model.arena.flat.clone())
+    assert torch.equal(finals[0], finals[1])
+

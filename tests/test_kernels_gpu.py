@@ -628,6 +628,25 @@ def test_adam_apply_over_ranges_equals_one_step():
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
 
 
+def test_adam_apply_at_with_the_counter_advanced_first_equals_one_step():
+    """The captured single-GPU step advances the counter early (off the critical chain) and updates with
+    mvae_adam_apply_at(step_add=0): identical to mvae_adam_step, counter included."""
+    n = 10009
+    p0, m0, v0, gr = g(n, seed=124), g(n, seed=125).abs() * 0.1, g(n, seed=126).abs() * 0.1, g(n, seed=127)
+    step_a = torch.full((1,), 6, dtype=torch.int64, device=DEV); step_b = step_a.clone()
+    pa, ma, va = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    pb, mb, vb = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    K.adam_step(pa, dev(gr), ma, va, step_a, 1e-3, grad_scale=0.5)
+    K.counter_add(step_b, 1)
+    K.adam_apply_at(pb, dev(gr), mb, vb, step_b, 0, 1e-3, grad_scale=0.5)
+    assert step_b.item() == step_a.item() == 7
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    pc, mc, vc = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+    step_c = torch.full((1,), 6, dtype=torch.int64, device=DEV)
+    K.adam_apply_at(pc, dev(gr), mc, vc, step_c, 1, 1e-3, grad_scale=0.5)        # step_add = 1: mvae_adam_apply
+    assert step_c.item() == 6 and torch.equal(pa, pc)
+
+
 def test_philox_fill_matches_the_bumping_entry_points():
     ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
     a = torch.empty(4099, device=DEV); m = torch.empty(4099, device=DEV)
