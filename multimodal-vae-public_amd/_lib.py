@@ -51,6 +51,13 @@ class RepackItem(ctypes.Structure):         # mvae_repack_item
 REPACK_MAX = 16
 
 
+class StatsLayout(ctypes.Structure):        # mvae_stats_layout
+    _fields_ = [('ncls', c_int), ('tiles_j', c_int), ('ppt', c_int), ('cols', c_int)]
+
+    def parts(self):
+        return self.ncls * self.tiles_j * self.ppt
+
+
 class ExpertGrads(ctypes.Structure):
     _fields_ = [('dmu', c_void_p * MAX_EXPERTS), ('dlogvar', c_void_p * MAX_EXPERTS)]
 
@@ -108,6 +115,12 @@ _SIGNATURES = {
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'mvae_conv_k4_repack_floats': (c_size_t, [c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'mvae_conv_k4_repack_batched': (c_int, [ctypes.POINTER(RepackItem), c_int, P]),
+    'mvae_conv_k4_stats_layout': (c_int, [c_int] * 8 + [ctypes.POINTER(StatsLayout)]),
+    'mvae_conv2d_k4_fwd_stats': (c_int, [P, P, P] + [c_int] * 7 + [P, c_size_t, ctypes.POINTER(StatsLayout), P]),
+    'mvae_convT2d_k4_fwd_stats': (c_int, [P, P, P] + [c_int] * 7 + [P, c_size_t, P, c_size_t,
+                                                                    ctypes.POINTER(StatsLayout), P]),
+    'mvae_bn_train_fwd_parts': (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, P, c_int, P,
+                                                                 ctypes.POINTER(StatsLayout), P, c_size_t, P]),
     'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),

@@ -135,3 +135,51 @@ def test_arena_layout_on_cpu_tensors():
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     assert enc.fc1.weight.data_ptr() == arena.flat.data_ptr() + 4 * enc.fc1.weight._arena_off
+
+
+# ---- statistics launches (conv epilogue -> BatchNorm): the layout query and the argument checks are host logic ----
+CELEBA_STATS_SHAPES = [
+    # transposed, B, Cin, H, W, Cout, stride, pad, has_layout       (celeba/model.py:79-86,117-126 at B = 256, 3 decodes)
+    (0, 256, 3, 64, 64, 32, 2, 1, False),        # first conv: direct small-channel kernel (and no BatchNorm behind it)
+    (0, 256, 32, 32, 32, 64, 2, 1, True),
+    (0, 256, 64, 16, 16, 128, 2, 1, True),
+    (0, 256, 128, 8, 8, 256, 1, 0, True),
+    (1, 768, 256, 1, 1, 128, 1, 0, False),       # 1x1 -> 4x4 transposed conv: its own stride-1 kernel
+    (1, 768, 128, 4, 4, 64, 2, 1, True),
+    (1, 768, 64, 8, 8, 32, 2, 1, True),
+    (1, 768, 32, 16, 16, 3, 2, 1, False),        # last layer: direct kernel
+    (1, 19 * 256, 64, 8, 8, 32, 2, 1, True),     # celeba19: 19 decodes in one launch
+    (0, 7, 128, 8, 8, 256, 1, 0, False),         # 7 * 25 positions: a ragged last tile
+]
+
+
+@pytest.mark.parametrize('tr,B,Cin,H,W,Cout,s,p,has', CELEBA_STATS_SHAPES)
+def test_stats_layout_covers_every_output_position_once(tr, B, Cin, H, W, Cout, s, p, has):
+    from mvae_amd import kernels as K
+    lay = K.conv_stats_layout(tr, B, Cin, H, W, Cout, s, p)
+    assert (lay is not None) == has
+    if lay is None:
+        return
+    OH = (H - 1) * s - 2 * p + 4 if tr else (H + 2 * p - 4) // s + 1
+    OW = (W - 1) * s - 2 * p + 4 if tr else (W + 2 * p - 4) // s + 1
+    assert lay.ncls == (s * s if tr else 1)
+    assert lay.parts() * lay.cols == B * OH * OW
+    assert lay.cols in (32, 64) and lay.ppt in (1, 2, 4)
+
+
+def test_bn_from_parts_rejects_layouts_that_do_not_match_the_tensor():
+    lib = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    G, B, C, HW = 3, 256, 64, 256
+
+    def call(lay, x=p, y=p):
+        return lib.mvae_bn_train_fwd_parts(x, p, p, y, p, p, None, None, G, B, C, HW, 1e-5, 0.1, 1, None, 0, p,
+                                           ctypes.byref(lay), p, 1 << 30, None)
+    ERR_ARG = -1
+    assert _lib.StatsLayout(4, 768, 2, 32).parts() * 32 == G * B * HW       # the layout that WOULD be accepted
+    assert call(_lib.StatsLayout(4, 768, 2, 32), x=None, y=p) == ERR_ARG    # an output needs x
+    assert call(_lib.StatsLayout(4, 192, 2, 32)) == ERR_ARG                 # covers a quarter of the tensor
+    assert call(_lib.StatsLayout(4, 767, 2, 32)) == ERR_ARG                 # wrong count
+    assert call(_lib.StatsLayout(2, 1024, 3, 32)) == ERR_ARG                # right count, tiles straddle groups
+    assert call(_lib.StatsLayout(0, 0, 0, 0)) == ERR_ARG
