@@ -110,3 +110,47 @@ def test_loss_helpers_error_behaviour():
         OF.binary_cross_entropy_with_logits(torch.zeros(4, 3), torch.zeros(4, 2))
     with pytest.raises(ValueError, match='Target size'):
         OF.cross_entropy(torch.zeros(4, 10), torch.zeros(3, dtype=torch.long))
+
+
+# ----------------------------------------------------------------------------------------------------
+# the reference's test(epoch) body in eval mode (tests/golden/make_eval_golden.py): reparametrize returns mu,
+# Dropout off, BatchNorm on running statistics, elbo_loss at its default weights
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('exp', ['mnist', 'fashionmnist', 'celeba', 'celeba19'])
+def test_eval_pass_matches_reference(golden_dir, exp):
+    from oracle import functional as OF
+    torch.set_num_threads(4)
+    fx, meta = load_golden(golden_dir, 'eval_' + exp)
+    model = _build(exp, meta)
+    sd = model.state_dict()
+    moved = 0
+    for k in list(sd):
+        if 'running_' in k or 'num_batches' in k:
+            sd[k] = torch.from_numpy(np.asarray(fx['bn/' + k])).to(sd[k].dtype)
+            moved += 1
+    model.load_state_dict(sd)
+    assert (moved > 0) == (exp in ('celeba', 'celeba19'))
+    model.eval()
+    image, label = OS.synthetic_batch(exp, meta['batch'], meta['input_seed'])
+    assert np.array_equal(label.numpy(), fx['label'])
+    with torch.no_grad():
+        if exp == 'celeba19':
+            attrs = [label[:, i] for i in range(label.shape[1])]
+            ri, ra, mu, lv, z = model(image, attrs)
+            calls = [(ri, torch.stack(ra, dim=1), mu, lv, z)]
+            terms = [OF.elbo_loss_multi([ri] + ra, [image] + attrs, mu, lv)]
+        else:
+            elbo = OF.elbo_loss_attrs if exp == 'celeba' else OF.elbo_loss_label
+            lam = (meta['lambda_image'], meta['lambda_label'])      # celeba/train.py:238-243 passes the CLI's; 1, 1 elsewhere
+            calls = [model(image, label), model(image, None), model(None, label)]
+            terms = [elbo(calls[0][0], image, calls[0][1], label, calls[0][2], calls[0][3], *lam),
+                     elbo(calls[1][0], image, None, None, calls[1][2], calls[1][3], *lam),
+                     elbo(None, None, calls[2][1], label, calls[2][2], calls[2][3], *lam)]
+    assert_close([t.item() for t in terms], fx['terms'], 'eval terms', tol=2e-6)
+    assert_close(sum(t.item() for t in terms), fx['total'], 'eval total', tol=2e-6)
+    for c, (ri, rl, mu, lv, z) in enumerate(calls):
+        assert_close(mu, fx['mu%d' % c], 'eval mu%d' % c, tol=1e-5)
+        assert_close(lv, fx['logvar%d' % c], 'eval logvar%d' % c, tol=1e-5)
+        assert torch.equal(z, mu), 'eval-mode reparametrize returns mu'
+        assert_close(ri[0].reshape(-1)[:256], fx['logits_image_0_%d' % c], 'eval image logits %d' % c, tol=1e-5)
+        assert_close(rl, fx['logits_label_%d' % c], 'eval label logits %d' % c, tol=1e-5)
