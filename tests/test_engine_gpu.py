@@ -311,8 +311,9 @@ def test_eval_pass_matches_reference_golden(golden_dir, kind):
             sd[k] = torch.from_numpy(np.asarray(fx['bn/' + k])).to(sd[k].dtype)
     model = getattr(mvae_amd, kind).model.MVAE(d)
     model.load_state_dict(sd)
-    model.to(DEV).eval()
+    model.to(DEV).train()
     model.finalize()
+    model.eval()
     image, label = OS.synthetic_batch(kind, meta['batch'], meta['input_seed'])
     img, lbl = image.to(DEV), label.to(DEV)
     args = argparse.Namespace(lambda_image=meta['lambda_image'], lambda_attrs=meta['lambda_label'],
