@@ -68,6 +68,18 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert lib.mvae_linear_fwd(None, 4, None, None, None, None, 4, None, 1.0, 4, 4, 4, None, 0, None) == -1
     assert lib.mvae_conv2d_k4_fwd(None, None, None, None, 1, 1, 8, 8, 1, 3, 1, None) == -1
     assert lib.mvae_fill(None, 4, 0.0, None) == -1
+    # the entry points added in round 2: null pointers / bad item lists are refused before anything is launched
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mvae_adam_apply_at(None, p, p, p, 16, 1e-3, 0.9, 0.999, 1e-8, 1.0, p, 0, None) == -1
+    assert lib.mvae_adam_apply_at(p, p, p, p, 16, 1e-3, 0.9, 0.999, 1e-8, 1.0, None, 0, None) == -1
+    assert lib.mvae_adam_apply_at(p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, p, 0, None) == 0        # nothing to do
+    assert lib.mvae_linear_wgrad_batched(None, 1, None) == -1
+    assert lib.mvae_conv_k4_repack_batched(None, 1, None) == -1
+    assert lib.mvae_conv2d_k4_fwd_stats(p, p, p, 8, 32, 32, 32, 64, 2, 1, None, 0, None, None) == -1   # no record buffer
+    lay = _lib.StatsLayout()
+    assert lib.mvae_conv_k4_stats_layout(0, 8, 32, 32, 32, 64, 3, 1, ctypes.byref(lay)) == -1           # stride 3
+    assert lib.mvae_conv_k4_stats_layout(0, 8, 32, 32, 32, 64, 2, 1, None) == -1
 
 
 def test_no_cpu_fallback():
