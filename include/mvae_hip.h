@@ -41,6 +41,9 @@ extern "C" {
 
 #define MVAE_POE_VARIANT_A 0   /* mnist/model.py:156-163, fashionmnist/model.py:175-182 */
 #define MVAE_POE_VARIANT_B 1   /* celeba/model.py:200-207, celeba19/model.py:219-226 */
+#define MVAE_POE_NO_PRIOR  4   /* OR-ed into `variant`: no built-in N(0,1) prior -- the caller's stack carries every expert,
+                                  as when ProductOfExperts.forward is called on a [M,B,D] stack whose row 0 is what
+                                  prior_expert returned (mnist/model.py:50-63,156-163,172-185) */
 #define MVAE_MAX_EXPERTS  32
 
 typedef void *mvae_stream_t;   /* hipStream_t */
@@ -162,31 +165,6 @@ size_t mvae_conv_k4_repack_floats(int transposed, const float *w, int B, int Cin
                                   int stride, int pad);
 int mvae_conv_k4_repack_batched(const mvae_repack_item *items, int n_items, mvae_stream_t stream);
 
-/* Forward launches that leave the per-channel batch statistics of their output for the BatchNorm behind them
- * (celeba/model.py:79-86,117-124: every Conv2d / ConvTranspose2d but the first and last is followed by one), so
- * that BatchNorm does not read the tensor a second time for them.  EXPERIMENTAL in round 2: written and compiled,
- * not yet run on hardware; the engine only uses it under MVAE_FUSED_BN_STATS=1.
- *   Every wave of the tiled kernel writes one record per channel -- (mean, M2) of `cols` consecutive output
- *   positions -- to fixed places of `stats` (no atomics, deterministic):
- *     stats[(part * 2 + {0, 1}) * Cout + c],  part = (class * tiles_j + tile) * ppt + wave,   ncls * tiles_j * ppt parts.
- *   mvae_bn_train_fwd_parts merges them.  `pre` may be NULL: statistics only, nothing stored (the decoder passes
- *   of celeba19/train.py:277-283 whose output nobody reads).
- *   mvae_conv_k4_stats_layout   MVAE_OK and the layout this shape's launch would leave, or MVAE_ERR_ARG when the
- *                               shape has no such launch (the direct <= 4-channel and stride-1 kernels, ragged
- *                               tiles, split reductions) -- then use the ordinary forward + mvae_bn_train_fwd.
- *                               transposed: 0 = Conv2d, 1 = ConvTranspose2d; shape as in that forward call. */
-typedef struct { int ncls, tiles_j, ppt, cols; } mvae_stats_layout;
-int mvae_conv_k4_stats_layout(int transposed, int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                              mvae_stats_layout *lay);
-int mvae_conv2d_k4_fwd_stats(const float *x, const float *w, float *pre /* nullable */,
-                             int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                             float *stats, size_t stats_floats, mvae_stats_layout *lay /* out, nullable */,
-                             mvae_stream_t stream);
-int mvae_convT2d_k4_fwd_stats(const float *x, const float *w, float *pre /* nullable */,
-                              int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                              void *ws, size_t ws_bytes, float *stats, size_t stats_floats,
-                              mvae_stats_layout *lay /* out, nullable */, mvae_stream_t stream);
-
 /* ------------------------------------------------------------------------------------
  * K4  BatchNorm2d / BatchNorm1d (training mode, eps 1e-5, momentum 0.1) + fused Swish:
  *     celeba/model.py:80,83,86,118,121,124,149,152,176,179,182; celeba19/model.py:106,109,
@@ -207,16 +185,6 @@ int mvae_bn_train_fwd(const float *x, const float *gamma, const float *beta, flo
                       int G, int B, int C, int HW, float eps, float momentum,
                       int n_updates, const int *n_updates_dev /* nullable: overrides n_updates */,
                       int flags, void *ws, size_t ws_bytes, mvae_stream_t stream);
-/* mvae_bn_train_fwd on the statistics a mvae_conv*_k4_fwd_stats launch left (`stats`, `lay`): no statistics pass
- * over x.  x may be NULL when y is NULL.  The records must cover the G*B*HW positions exactly once and no tile may
- * straddle two groups (lay->tiles_j % G == 0), else MVAE_ERR_ARG.  EXPERIMENTAL, see above. */
-int mvae_bn_train_fwd_parts(const float *x, const float *gamma, const float *beta, float *y,
-                            float *save_mean, float *save_invstd,
-                            float *running_mean, float *running_var,
-                            int G, int B, int C, int HW, float eps, float momentum,
-                            int n_updates, const int *n_updates_dev,
-                            int flags, const float *stats, const mvae_stats_layout *lay,
-                            void *ws, size_t ws_bytes, mvae_stream_t stream);
 int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
                       const float *save_mean, const float *save_invstd,
                       float *dx, float *dgamma, float *dbeta,

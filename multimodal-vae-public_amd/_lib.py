@@ -18,7 +18,8 @@ ERRORS = {-1: 'MVAE_ERR_ARG (bad shape / null pointer / unsupported stride)',
           -3: 'MVAE_ERR_WS (workspace too small)'}
 ACT_SWISH = 1
 ACCUMULATE = 2
-POE_VARIANT = {'A': 0, 'B': 1}
+POE_NO_PRIOR = 4     # MVAE_POE_NO_PRIOR
+POE_VARIANT = {'A': 0, 'B': 1, 'A-noprior': 0 | POE_NO_PRIOR, 'B-noprior': 1 | POE_NO_PRIOR}
 MAX_EXPERTS = 32
 MAX_TERMS = 40
 
@@ -49,13 +50,6 @@ class RepackItem(ctypes.Structure):         # mvae_repack_item
 
 
 REPACK_MAX = 16
-
-
-class StatsLayout(ctypes.Structure):        # mvae_stats_layout
-    _fields_ = [('ncls', c_int), ('tiles_j', c_int), ('ppt', c_int), ('cols', c_int)]
-
-    def parts(self):
-        return self.ncls * self.tiles_j * self.ppt
 
 
 class ExpertGrads(ctypes.Structure):
@@ -115,12 +109,6 @@ _SIGNATURES = {
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'mvae_conv_k4_repack_floats': (c_size_t, [c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'mvae_conv_k4_repack_batched': (c_int, [ctypes.POINTER(RepackItem), c_int, P]),
-    'mvae_conv_k4_stats_layout': (c_int, [c_int] * 8 + [ctypes.POINTER(StatsLayout)]),
-    'mvae_conv2d_k4_fwd_stats': (c_int, [P, P, P] + [c_int] * 7 + [P, c_size_t, ctypes.POINTER(StatsLayout), P]),
-    'mvae_convT2d_k4_fwd_stats': (c_int, [P, P, P] + [c_int] * 7 + [P, c_size_t, P, c_size_t,
-                                                                    ctypes.POINTER(StatsLayout), P]),
-    'mvae_bn_train_fwd_parts': (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, c_int, P, c_int, P,
-                                                                 ctypes.POINTER(StatsLayout), P, c_size_t, P]),
     'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),

@@ -12,7 +12,7 @@ import torch.nn as nn
 from . import kernels as K
 from . import layers as L
 from .arena import ParamArena
-from .functional import PoEFn, ReparamFn
+from .functional import PoEFn, PoEStackFn, ReparamFn
 
 
 class Stack(nn.Module):
@@ -33,12 +33,53 @@ class Stack(nn.Module):
                           training=self.training)
 
 
+class ProductOfExperts(nn.Module):
+    """The reference's module of the same name (mnist/model.py:149-163; celeba/model.py:193-207): parameters of
+    the product of independent Gaussian experts, called on STACKED experts -- ``mu``, ``logvar`` of shape
+    [M, B, D] (or [M, D]), row 0 being the prior expert in the reference's ``infer`` -- and returning
+    ``(pd_mu, pd_logvar)`` of shape [B, D].  One HIP launch (``mvae_poe_fwd`` with MVAE_POE_NO_PRIOR), with a
+    backward, so code written against ``model.experts(mu, logvar)`` keeps working.  ``MVAE.forward`` / ``infer``
+    themselves never build the stack (the prior is a constant inside the fused launch).
+    ``VARIANT``: 'A' = eps added twice and inside the log (mnist, fashionmnist), 'B' = once (celeba, celeba19)."""
+    VARIANT = 'A'
+
+    def forward(self, mu, logvar, eps=1e-8):
+        if eps != 1e-8:
+            raise ValueError('ProductOfExperts: eps is fixed at the reference default 1e-8 (got %r)' % (eps,))
+        if mu.shape != logvar.shape or mu.dim() not in (2, 3):
+            raise ValueError('ProductOfExperts: mu and logvar must both be [M, B, D] (or [M, D]); got %s and %s'
+                             % (tuple(mu.shape), tuple(logvar.shape)))
+        if not (mu.is_cuda and logvar.is_cuda):
+            raise RuntimeError('multimodal-vae-public_amd: ProductOfExperts runs on the GPU only; there is no CPU '
+                               'fallback')
+        flat = mu.dim() == 2
+        if flat:
+            mu, logvar = mu.unsqueeze(1), logvar.unsqueeze(1)
+        pd_mu, pd_logvar = PoEStackFn.apply(mu.float(), logvar.float(), self.VARIANT)
+        return (pd_mu[0], pd_logvar[0]) if flat else (pd_mu, pd_logvar)
+
+
+class ProductOfExpertsB(ProductOfExperts):
+    VARIANT = 'B'
+
+
+def prior_expert(size, use_cuda=False):
+    """Universal prior expert N(0, 1): ``(mu, logvar)`` of zeros of shape ``size`` (mnist/model.py:172-185;
+    celeba/model.py:216-229 writes log(ones) -- the same zeros)."""
+    device = 'cuda' if use_cuda else 'cpu'
+    return (torch.zeros(size, dtype=torch.float32, device=device),
+            torch.zeros(size, dtype=torch.float32, device=device))
+
+
 class MVAEBase(nn.Module):
     POE_VARIANT = 'A'
 
     def __init__(self, n_latents):
         super().__init__()
         self.n_latents = n_latents
+        # the reference's ``self.experts = ProductOfExperts()`` (mnist/model.py:26): parameter-free, callable on a
+        # stacked [M, B, D] pair; forward() / infer() use the fused launch instead
+        self.experts = ProductOfExperts() if self.POE_VARIANT == 'A' else ProductOfExpertsB()
         self.__dict__['_arena'] = None
         self.__dict__['_rng'] = None
 

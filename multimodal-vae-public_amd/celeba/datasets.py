@@ -125,7 +125,8 @@ class CelebaLoader(object):
         self.data = CelebAttributes(partition, data_dir)
         self.batch_size, self.shuffle, self.device = int(batch_size), bool(shuffle), device
         self.rank, self.world = int(rank), int(world)
-        self.dataset = range(rank, len(self.data), world)
+        from ..train_common import shard_len
+        self.dataset = range(shard_len(len(self.data), self.world))        # samples per rank, equal on all ranks
         self._gen = torch.Generator().manual_seed(seed)
         self._transform = ResizeCenterCropToTensor(size)
         self._threads = max(1, int(decode_threads))
@@ -140,7 +141,8 @@ class CelebaLoader(object):
         from concurrent.futures import ThreadPoolExecutor
         n_total = len(self.data)
         order = torch.randperm(n_total, generator=self._gen) if self.shuffle else torch.arange(n_total)
-        order = order[self.rank::self.world].tolist()
+        from ..train_common import shard_order
+        order = shard_order(order, self.rank, self.world).tolist()
         with ThreadPoolExecutor(self._threads) as pool:
             for i in range(0, len(order), self.batch_size):
                 idx = order[i:i + self.batch_size]

@@ -13,6 +13,10 @@ import torch.nn as nn
 
 from .. import layers as L
 from ..base import MVAEBase, Stack
+# module-level names of the reference's model.py (``from model import ProductOfExperts, Swish, prior_expert``):
+# ProductOfExperts here is variant B -- celeba/model.py:193-207
+from ..base import ProductOfExpertsB as ProductOfExperts, prior_expert  # noqa: F401
+from ..layers import Swish  # noqa: F401
 
 N_ATTRS = 18  # celeba/datasets.py:34
 

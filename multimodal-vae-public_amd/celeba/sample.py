@@ -16,6 +16,7 @@ import torch  # noqa: E402
 from ..sample_common import (add_common_flags, generate, load_image, need_cuda, posterior,  # noqa: E402
                              save_image)
 from .train import load_checkpoint  # noqa: E402
+from .. import kernels as K  # noqa: E402
 
 from ..sample_common import CELEBA_ATTRS  # noqa: E402
 
@@ -62,7 +63,10 @@ if __name__ == "__main__":
     mu, std = posterior(model, image, attrs)
     _, image_recon, attr_logits = generate(model, args.n_samples, mu, std)
     save_image(image_recon.reshape(args.n_samples, 3, 64, 64), os.path.join(args.out_dir, 'sample_image.png'))
-    attrs_recon = torch.sigmoid(attr_logits).cpu()
+    attr_logits = attr_logits.contiguous()
+    attrs_prob = torch.empty_like(attr_logits)
+    K.sigmoid_fwd(attr_logits, attrs_prob)                    # F.sigmoid of celeba/sample.py:127 as a HIP launch
+    attrs_recon = attrs_prob.cpu()
     with open(os.path.join(args.out_dir, 'sample_attrs.txt'), 'w') as fp:
         for i in range(attrs_recon.size(0)):
             fp.write('%s\n' % ','.join(tensor_to_attributes(attrs_recon[i])))

@@ -13,6 +13,10 @@ import torch.nn as nn
 
 from .. import layers as L
 from ..base import MVAEBase, Stack
+# module-level names of the reference's model.py (``from model import ProductOfExperts, Swish, prior_expert``):
+# ProductOfExperts here is variant B -- celeba19/model.py:212-226
+from ..base import ProductOfExpertsB as ProductOfExperts, prior_expert  # noqa: F401
+from ..layers import Swish  # noqa: F401
 from ..celeba.model import ImageDecoder, ImageEncoder, N_ATTRS  # noqa: F401  (identical stacks)
 
 

@@ -771,37 +771,10 @@ inline int conv_fwd_small(const float *x, const float *w, float *pre, float *act
 }
 
 // ---- conv forward form: y[n][co][oh][ow] = sum_k w[co][k] * im2col(x)[k][(n,oh,ow)] ----
-// A launch that also leaves the per-channel statistics of its output for the BatchNorm behind it (EpNCHWStats):
-// `rec` gets the records, `lay` says how they are laid out; dry = fill `lay` only (what mvae_conv_k4_stats_layout
-// answers).  Only the tiled kernels have that epilogue: the direct small-channel / stride-1 kernels and launches
-// with ragged tiles answer MVAE_ERR_ARG, and the caller runs the ordinary launch + bn_partial_stats_kernel.
-struct StatsReq { float *rec; size_t rec_floats; StatsLayout lay; bool dry; };
-
-inline size_t stats_floats(const StatsLayout &l, int C) { return (size_t)l.ncls * l.tiles_j * l.ppt * 2 * C; }
-
-inline EpNCHWStats with_stats(const EpNCHW &e, const StatsReq &sr) {
-    EpNCHWStats es;
-    static_cast<EpNCHW &>(es) = e;
-    es.st = sr.rec; es.st_C = e.C;
-    return es;
-}
-
-// layout first (dry), then the size check, then the launch
-template <class F>
-inline int launch_with_stats(Plan pl, StatsReq *sr, int C, F launch) {
-    pl.stats = &sr->lay; pl.dry = true;
-    int rc = launch(pl);
-    if (rc != MVAE_OK || sr->dry) return rc;
-    if (!sr->rec || sr->rec_floats < stats_floats(sr->lay, C)) return MVAE_ERR_WS;
-    pl.dry = false;
-    return launch(pl);
-}
-
 int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const float *dpre,
-                  ConvGeom g, hipStream_t st, StatsReq *sr = nullptr) {
+                  ConvGeom g, hipStream_t st) {
     const int I = g.Cout, J = g.B * g.OH * g.OW, K = g.Cin * 16;
-    if (conv_fwd_small_ok(g, x, pre, act, dpre) && !MVAE_TUNE(wm))
-        return sr ? MVAE_ERR_ARG : conv_fwd_small(x, w, pre, act, dpre, g, st);
+    if (conv_fwd_small_ok(g, x, pre, act, dpre) && !MVAE_TUNE(wm)) return conv_fwd_small(x, w, pre, act, dpre, g, st);
     Plan pl = make_plan(I, J, K, false);
     // >= 128 output channels and enough columns for >= 384 blocks of 128 x 64: two accumulators per wave share
     // every gathered fragment (dec2 / dec1 dgrad at 512 images: 91 -> 99 and 77 -> 80 TFLOP/s; at 256 images the
@@ -816,13 +789,6 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
-    if (sr) {
-        if (!aligned16(w)) return MVAE_ERR_ARG;
-        const EpNCHWStats es = with_stats(e, *sr);
-        return launch_with_stats(pl, sr, e.C, [&](Plan p2) {
-            return launch_igemm<LdRowsKC, LdIm2col, EpNCHWStats, false>(p2, mp, mq, es, I, J, K, make_sink(nullptr, I, J, false), st);
-        });
-    }
     if (aligned16(w))
         return launch_igemm<LdRowsKC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
     return launch_igemm<LdRowsKSC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
@@ -1157,18 +1123,17 @@ inline size_t dgrad_ws_floats(const ConvGeom &g) { return (size_t)g.Cout * g.Cin
 // ---- conv dgrad form: dx[n][ci][ih][iw] = sum_(co,kh,kw) w[co][ci][kh][kw] * dy[n][co][oh][ow],
 //      one launch per output parity class (4 for stride 2, 1 for stride 1) on repacked weights ----
 int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, const float *dpre,
-                    ConvGeom g, void *ws, size_t ws_bytes, hipStream_t st, StatsReq *sr = nullptr) {
+                    ConvGeom g, void *ws, size_t ws_bytes, hipStream_t st) {
     const int s = g.stride, tlog = (s == 2) ? 1 : 2;
     const int H2 = g.H / s, W2 = g.W / s;
     const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << (2 * tlog);
     // w == NULL: `ws` already holds the repacked weights (mvae_conv_k4_repack_batched) -- only valid for launches
     // that read them (mvae_conv_k4_repack_floats != 0)
-    if (conv_dgrad_small_ok(g) && !MVAE_TUNE(wm)) return (w && !sr) ? conv_dgrad_small(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
-    if (conv_dgrad_s1_ok(g, w) && !MVAE_TUNE(wm)) return (w && !sr) ? conv_dgrad_s1(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
-    const bool dry = sr && sr->dry;
-    if (!dry && (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float))) return MVAE_ERR_WS;
+    if (conv_dgrad_small_ok(g) && !MVAE_TUNE(wm)) return w ? conv_dgrad_small(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
+    if (conv_dgrad_s1_ok(g, w) && !MVAE_TUNE(wm)) return w ? conv_dgrad_s1(dy, w, dx, act, dpre, g, st) : MVAE_ERR_ARG;
+    if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
     float *wr = (float *)ws;
-    if (w && !dry) {
+    if (w) {
         const int total = s * s * K * g.Cin;
         int blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
@@ -1188,14 +1153,6 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     SplitSink sink = make_sink(nullptr, I, J, false);
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
     sink.cls_minor = MVAE_CLS_MINOR;
-    if (sr) {
-        if (g.Cin % 4 != 0 || (!dry && !aligned16(wr))) return MVAE_ERR_ARG;
-        const EpNCHWStats es = with_stats(e, *sr);
-        return launch_with_stats(pl, sr, e.C, [&](Plan p2) {
-            if (s == 2) return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHWStats, false>(p2, mp, mq, es, I, J, K, sink, st);
-            return launch_igemm<LdRowsMNC, LdDgradDyS1, EpNCHWStats, false>(p2, mp, mq, es, I, J, K, sink, st);
-        });
-    }
     if (vec) {
         if (s == 2) return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
         return launch_igemm<LdRowsMNC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
@@ -1513,51 +1470,6 @@ MVAE_EXPORT int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, 
     ConvGeom g;
     if (!x || (!w && !ws) || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
     return conv_dgrad_impl(x, w, pre, act, nullptr, g, ws, ws_bytes, (hipStream_t)stream);
-}
-
-// ---- forward launches that leave the statistics of their output for the BatchNorm behind them ----
-static inline void put_layout(mvae_stats_layout *out, const StatsLayout &l) {
-    if (out) { out->ncls = l.ncls; out->tiles_j = l.tiles_j; out->ppt = l.ppt; out->cols = l.cols; }
-}
-
-MVAE_EXPORT int mvae_conv_k4_stats_layout(int transposed, int B, int Cin, int H, int W, int Cout, int stride, int pad,
-                                          mvae_stats_layout *lay) {
-    if (!lay || B <= 0) return MVAE_ERR_ARG;
-    StatsReq sr{nullptr, 0, StatsLayout{0, 0, 0, 0}, true};
-    int rc;
-    if (transposed) {
-        ConvGeom g;
-        if (!convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
-        rc = conv_dgrad_impl(nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, 0, nullptr, &sr);
-    } else {
-        if (!conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
-        // the direct small-channel kernel is chosen on pointer alignment too: ask with aligned (null) pointers
-        rc = conv_fwd_impl(nullptr, nullptr, nullptr, nullptr, nullptr, make_geom(B, Cin, H, W, Cout, stride, pad), nullptr, &sr);
-    }
-    if (rc == MVAE_OK) put_layout(lay, sr.lay);
-    return rc;
-}
-
-MVAE_EXPORT int mvae_conv2d_k4_fwd_stats(const float *x, const float *w, float *pre, int B, int Cin, int H, int W,
-                                         int Cout, int stride, int pad, float *stats, size_t stats_floats,
-                                         mvae_stats_layout *lay, mvae_stream_t stream) {
-    if (!x || !w || !stats || !conv_args_ok(B, Cin, H, W, Cout, stride, pad)) return MVAE_ERR_ARG;
-    StatsReq sr{stats, stats_floats, StatsLayout{0, 0, 0, 0}, false};
-    const int rc = conv_fwd_impl(x, w, pre, nullptr, nullptr, make_geom(B, Cin, H, W, Cout, stride, pad),
-                                 (hipStream_t)stream, &sr);
-    if (rc == MVAE_OK) put_layout(lay, sr.lay);
-    return rc;
-}
-
-MVAE_EXPORT int mvae_convT2d_k4_fwd_stats(const float *x, const float *w, float *pre, int B, int Cin, int H, int W,
-                                          int Cout, int stride, int pad, void *ws, size_t ws_bytes, float *stats,
-                                          size_t stats_floats, mvae_stats_layout *lay, mvae_stream_t stream) {
-    ConvGeom g;
-    if (!x || (!w && !ws) || !stats || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
-    StatsReq sr{stats, stats_floats, StatsLayout{0, 0, 0, 0}, false};
-    const int rc = conv_dgrad_impl(x, w, pre, nullptr, nullptr, g, ws, ws_bytes, (hipStream_t)stream, &sr);
-    if (rc == MVAE_OK) put_layout(lay, sr.lay);
-    return rc;
 }
 
 MVAE_EXPORT int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,

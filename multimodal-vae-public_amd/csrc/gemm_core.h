@@ -315,7 +315,6 @@ template <int T> using LdRowsMNS64 = LdRowsMNT<T, false, 64>;
 // Row-major destination D[i * ld + j] with the Linear fusions.
 struct EpRowMajor {
     static constexpr bool MULTI = false;      // multi-item blocks: conv forms only (set_class here is cumulative)
-    static constexpr bool STATS = false;
     float *out; float *act; int ld;           // out = raw / pre-activation result, act = swish(result)
     const float *bias;                        // per column j (Linear fwd)
     const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
@@ -346,7 +345,6 @@ struct EpRowMajor {
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
     static constexpr bool MULTI = true;
-    static constexpr bool STATS = false;
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
     int off;   // per-lane column offset, set by col()
@@ -367,70 +365,6 @@ struct EpNCHW {
         if (act) act[idx] = swishf_(v);
     }
 };
-
-// EpNCHW that also leaves the batch statistics of what it stores, for the BatchNorm that consumes the tensor: every
-// wave writes ONE record per channel of its tile -- (mean, M2) of its 32*WN consecutive columns -- to
-//   st[(part * 2 + {0, 1}) * st_C + channel],   part = (class * tiles_j + j tile) * WGN + wave column.
-// Fixed places, no atomics: the consumer (norm.hip: bn_merge_parts_kernel) merges them in a fixed order.  The host
-// only launches this with J a multiple of the tile width (every column valid) and without a reduction split.
-struct EpNCHWStats : EpNCHW {
-    static constexpr bool STATS = true;
-    float *st; int st_C;
-};
-
-// What a statistics launch leaves behind (host side; the C ABI's mvae_stats_layout)
-struct StatsLayout { int ncls, tiles_j, ppt, cols; };     // records = ncls * tiles_j * ppt, each over `cols` columns
-
-// One wave's records.  C/D layout of the 32x32 MFMA: lane (lrow, lcol) holds column lcol of rows
-// 4*lrow + (r & 3) + 8*(r >> 2): a channel's 32 columns sit in the 32 lanes of one half-wave, the wave's WN tiles
-// in WN registers of each lane.  Sums of (v - p) and (v - p)^2 around the pivot p = the channel's first column
-// (no E[x^2] - E[x]^2 cancellation; read with v_readlane), summed over the half-wave with DPP adds -- a scan
-// along each row of 16 lanes (row_shr 1, 2, 4, 8), then row_bcast:15 carries lane 15 / 47 into the next row --
-// so lanes 31 and 63 end up with their half-wave's totals and write.  ~13 vector instructions per accumulator
-// register, once per tile (the fp32 matrix pipe does not hide them: ~800 cycles against 16 K cycles of MFMAs per
-// 32x32 tile -- K in the reduction length).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_or_zero(float v) {       // lanes without a source, or in masked rows, read 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float half_wave_total(float v) {   // valid in lanes 31 and 63
-    v += dpp_or_zero<0x111, 0xf>(v);      // row_shr:1
-    v += dpp_or_zero<0x112, 0xf>(v);      // row_shr:2
-    v += dpp_or_zero<0x114, 0xf>(v);      // row_shr:4
-    v += dpp_or_zero<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of every row: the row's sum
-    v += dpp_or_zero<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    return v;
-}
-
-template <class E, int WM, int WN>
-__device__ __forceinline__ void wave_tile_stats(const E &e, const f32x16 (&acc)[WM][WN], int i_wave, int part, int lane) {
-    const int lrow = lane >> 5, lcol = lane & 31;
-    float *rec = e.st + (size_t)part * 2 * e.st_C;
-    constexpr float cnt = (float)(32 * WN);
-#pragma unroll
-    for (int x = 0; x < WM; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int first = __builtin_bit_cast(int, acc[x][0][r]);
-            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(first, 0));
-            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(first, 32));
-            const float pivot = lrow ? p1 : p0;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int y = 0; y < WN; ++y) {
-                const float d = acc[x][y][r] - pivot;
-                s1 += d; s2 += d * d;
-            }
-            s1 = half_wave_total(s1);
-            s2 = half_wave_total(s2);
-            const int i = i_wave + x * 32 + 4 * lrow + (r & 3) + 8 * (r >> 2);
-            if (lcol == 31 && i < e.C) {
-                const float mr = s1 / cnt;
-                rec[i] = pivot + mr;
-                rec[e.st_C + i] = fmaxf(s2 - s1 * mr, 0.f);
-            }
-        }
-}
 
 // Where the raw partial tiles of a split reduction go (row-major [I][J] per split), plus the
 // optional row sums of P (bias gradient of a Linear wgrad).
@@ -678,7 +612,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         if constexpr (CAN_MULTI) {
             if (!(il && nsteps >= 2 && gridDim.z == 1)) return;     // launch conditions (host): full k-tiles, >= 2 steps, no split
             const int G = n_items * nsteps;             // k-steps of the whole block
-            auto item_tile = [&](int w, int &c, int &jt) { item_of(first_item + w, c, jt); jt *= BN; };       // jt: first column
+            auto item_tile = [&](int w, int &c, int &jt) { item_of(first_item + w, c, jt); jt *= BN; };
             auto loaders_to = [&](int w) {              // point the loaders at item w (the load stream runs ahead)
                 int c, jt; item_tile(w, c, jt);
                 p.init(i0, t, c); q.init(jt, t, c);
@@ -688,8 +622,6 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
                 int c, jt; item_tile(w, c, jt);
                 e.set_class(c);
-                if constexpr (E::STATS)
-                    wave_tile_stats<E, WM, WN>(e, acc, i0 + wi * WM * 32, (c * tiles_j + jt / BN) * WGN + wj, lane);
 #pragma unroll
                 for (int y = 0; y < WN; ++y) {
                     const int j = jt + (wj * WN + y) * 32 + lcol;
@@ -968,9 +900,6 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool partial = gridDim.z > 1;
-    if constexpr (E::STATS) {
-        if (!partial) wave_tile_stats<E, WM, WN>(e, acc, i0 + wi * WM * 32, (cls * tiles_j + jt0) * WGN + wj, lane);
-    }
 #pragma unroll
     for (int y = 0; y < WN; ++y) {
         const int j = j0 + (wj * WN + y) * 32 + lcol;
@@ -1085,7 +1014,7 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; StatsLayout *stats = nullptr; bool dry = false; };   // xcd: XCD-local output sub-grids (Linear); items: (class, j tile) items per block (conv forms)
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; };   // xcd: XCD-local output sub-grids (Linear); items: (class, j tile) items per block (conv forms)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
@@ -1194,11 +1123,6 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         QLD<TN> q; make_q(q);                                                                    \
         dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
         sink.tiles_j = (J + TN - 1) / TN;                                                        \
-        if constexpr (E::STATS) {    /* statistics launch: whole tiles, one k range, per-wave epilogue; dry = layout only */ \
-            if (pl.splits != 1 || J % TN != 0 || (WGM * WGN < 4 && KW > 1)) return MVAE_ERR_ARG;    \
-            if (pl.stats) *pl.stats = StatsLayout{sink.ncls, sink.tiles_j, WGN, 32 * WN};       \
-            if (pl.dry) return MVAE_OK;                                                          \
-        }                                                                                        \
         sink.xcd_map = (pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
         sink.items = 1;                                                                          \
         if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \

@@ -112,49 +112,6 @@ __device__ inline void bn_merge(const float *ws, const BnShape &sh, int g, int c
     *var = n > 0.f ? m2 / n : 0.f;
 }
 
-// The statistics pass when the producing conv launch already left per-wave records (gemm_core.h: EpNCHWStats):
-// rec[(part * 2 + {0, 1}) * C + c] = (mean, M2) of `cnt` output positions of channel c,
-// part = (class * tiles_j + tile) * ppt + wave.  The records of group g are tiles [g * tpg, (g + 1) * tpg) of every
-// class; numbered q = (class * tpg + tile - g * tpg) * ppt + wave they are cut into the same S slices the sweep
-// produces, so bn_fwd_apply_kernel reads the workspace unchanged.  Block (s, channel block, g): 32 channels x 8
-// record lanes, each lane Chan-merging every 8th record of the slice, lanes merged in order through LDS.
-struct BnParts { const float *rec; int ncls, tiles_j, ppt, tpg; float cnt; };
-
-constexpr int BNP_CH = 32, BNP_LANES = BN_THREADS / BNP_CH;
-
-__device__ __forceinline__ void chan_add(float &n, float &m, float &m2, float nb, float mb, float m2b) {
-    const float nt = n + nb, d = mb - m;
-    m += d * (nb / nt);
-    m2 += m2b + d * d * (n * nb / nt);
-    n = nt;
-}
-
-__global__ __launch_bounds__(BN_THREADS) void bn_merge_parts_kernel(BnParts bp, float *__restrict__ ws, BnShape sh) {
-    __shared__ float red[BNP_LANES][BNP_CH][3];
-    const int s = blockIdx.x, g = blockIdx.z;
-    const int cl = threadIdx.x % BNP_CH, pl = threadIdx.x / BNP_CH, c = blockIdx.y * BNP_CH + cl;
-    const int per_cls = bp.tpg * bp.ppt, Q = bp.ncls * per_cls;
-    const int per = (Q + sh.S - 1) / sh.S, lo = s * per, hi = min(Q, lo + per);
-    float n = 0.f, m = 0.f, m2 = 0.f;
-    if (c < sh.C) {
-#pragma unroll 4
-        for (int q = lo + pl; q < hi; q += BNP_LANES) {
-            const int cls = q / per_cls, rem = q - cls * per_cls;
-            const size_t part = (size_t)(cls * bp.tiles_j + g * bp.tpg) * bp.ppt + rem;
-            const float *r = bp.rec + part * 2 * sh.C;
-            chan_add(n, m, m2, bp.cnt, r[c], r[sh.C + c]);
-        }
-    }
-    red[pl][cl][0] = n; red[pl][cl][1] = m; red[pl][cl][2] = m2;
-    __syncthreads();
-    if (pl == 0 && c < sh.C) {
-        for (int l = 1; l < BNP_LANES; ++l)
-            if (red[l][cl][0] > 0.f) chan_add(n, m, m2, red[l][cl][0], red[l][cl][1], red[l][cl][2]);
-        float *o = ws + ((size_t)(g * sh.C + c) * sh.S + s) * 3;
-        o[0] = n; o[1] = m; o[2] = m2;
-    }
-}
-
 // y = swish?(gamma * ((x - mean) * invstd) + beta); also saves mean/invstd and advances the
 // running statistics (one block per channel does that, sequentially over groups).
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *__restrict__ x, const float *gamma,
@@ -315,32 +272,6 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
     dim3 grid(sh.S, C, G);
     hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(BN_THREADS), 0, st, x, (float *)ws, sh);
     // y == NULL: only the (s = 0) block of each (channel, group) has work -- saved + running statistics
-    const dim3 agrid(y ? sh.S : 1, C, G);
-    hipLaunchKernelGGL(bn_fwd_apply_kernel, agrid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
-                       save_mean, save_invstd, running_mean, running_var, sh, eps, momentum, n_updates,
-                       n_updates_dev, (flags & MVAE_ACT_SWISH) ? 1 : 0);
-    return mvae_launch_status();
-}
-
-MVAE_EXPORT int mvae_bn_train_fwd_parts(const float *x, const float *gamma, const float *beta, float *y,
-                                        float *save_mean, float *save_invstd, float *running_mean,
-                                        float *running_var, int G, int B, int C, int HW, float eps, float momentum,
-                                        int n_updates, const int *n_updates_dev, int flags, const float *stats,
-                                        const mvae_stats_layout *lay, void *ws, size_t ws_bytes,
-                                        mvae_stream_t stream) {
-    BnShape sh;
-    if ((!x && y) || !gamma || !beta || !save_mean || !save_invstd || !stats || !lay ||
-        !bn_shape(G, B, C, HW, x, y, nullptr, &sh))
-        return MVAE_ERR_ARG;
-    if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
-    if (lay->ncls <= 0 || lay->tiles_j <= 0 || lay->ppt <= 0 || lay->cols <= 0 || lay->tiles_j % G != 0 ||
-        (long)lay->ncls * lay->tiles_j * lay->ppt * lay->cols != (long)G * B * HW)
-        return MVAE_ERR_ARG;
-    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
-    hipStream_t st = (hipStream_t)stream;
-    BnParts bp{stats, lay->ncls, lay->tiles_j, lay->ppt, lay->tiles_j / G, (float)lay->cols};
-    hipLaunchKernelGGL(bn_merge_parts_kernel, dim3(sh.S, (C + BNP_CH - 1) / BNP_CH, G), dim3(BN_THREADS), 0, st, bp,
-                       (float *)ws, sh);
     const dim3 agrid(y ? sh.S : 1, C, G);
     hipLaunchKernelGGL(bn_fwd_apply_kernel, agrid, dim3(BN_THREADS), 0, st, x, gamma, beta, y, (const float *)ws,
                        save_mean, save_invstd, running_mean, running_var, sh, eps, momentum, n_updates,

@@ -19,7 +19,8 @@ constexpr float POE_EPS = 1e-8f;
 
 struct PoeArgs {
     mvae_experts_t ex;
-    int ld, E, T, B, D, variant;
+    int ld, E, T, B, D, variant;      // variant: MVAE_POE_VARIANT_A / _B (the NO_PRIOR bit is split off into no_prior)
+    int no_prior;
 };
 
 // precision of one expert: 1 / (exp(lv) + eps [+ eps])
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
     if (b >= a.B) return;                              // whole waves exit together; no block barrier below
     float *mine = lds + threadIdx.x;
     float *klacc = lds + (size_t)a.E * 2 * POE_THREADS + threadIdx.x;      // this lane's KL partial per term
-    const float t0 = poe_precision(0.f, a.variant);   // the N(0,1) prior: mu = 0, logvar = 0
+    // the N(0,1) prior: mu = 0, logvar = 0 (MVAE_POE_NO_PRIOR: the caller's experts are the whole stack)
+    const float t0 = a.no_prior ? 0.f : poe_precision(0.f, a.variant);
     for (int t = 0; t < a.T; ++t) klacc[t * POE_THREADS] = 0.f;
     for (int d = lane; d < a.D; d += 64) {
         const size_t oe = (size_t)b * a.ld + d;
@@ -185,7 +187,9 @@ __global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float *mu, const
 inline bool poe_args_ok(const mvae_experts_t *ex, int ld, int E, int T, int B, int D, int variant) {
     if (!ex || E < 0 || E > MVAE_MAX_EXPERTS || T <= 0 || T > POE_MAX_TERMS || B <= 0 || D <= 0 || ld < D)
         return false;
-    if (variant != MVAE_POE_VARIANT_A && variant != MVAE_POE_VARIANT_B) return false;
+    const int base = variant & ~MVAE_POE_NO_PRIOR;
+    if (base != MVAE_POE_VARIANT_A && base != MVAE_POE_VARIANT_B) return false;
+    if ((variant & MVAE_POE_NO_PRIOR) && E < 1) return false;       // an empty product has no precision
     for (int e = 0; e < E; ++e)
         if (!ex->mu[e] || !ex->logvar[e]) return false;
     return true;
@@ -198,7 +202,8 @@ MVAE_EXPORT int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E, const
                              int variant, mvae_stream_t stream) {
     if (!poe_args_ok(experts, ld, E, T, B, D, variant) || !masks_dev || !mu || !logvar) return MVAE_ERR_ARG;
     PoeArgs a;
-    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
+    a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = ((size_t)E * 2 + T) * POE_THREADS * sizeof(float);
     hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
@@ -218,7 +223,8 @@ MVAE_EXPORT int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E, const
     for (int e = 0; e < E; ++e)
         if (!grads->dmu[e] || !grads->dlogvar[e]) return MVAE_ERR_ARG;
     PoeArgs a;
-    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
+    a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
     PoeDzMap none = {};
@@ -245,7 +251,8 @@ MVAE_EXPORT int mvae_poe_bwd_split(const mvae_experts_t *experts, int ld, int E,
         m.slot_a[t] = (signed char)slot_a[t]; m.slot_b[t] = (signed char)slot_b[t];
     }
     PoeArgs a;
-    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D; a.variant = variant;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
+    a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
     hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,

@@ -220,14 +220,16 @@ class _StepBase(object):
         """Launch the whole forward + backward.  Gradients go to ``p.grad`` (the arena); returns
         the device tensor ``elbo[T+1]`` = per-term ELBOs (engine order) and their sum."""
         self._step_begin()
-        self._phase_a(image, label)
-        if self.on_bucket_ready is not None and self.n_buckets > 1:
-            self.on_bucket_ready(0)      # decoder gradients are final
-        for k, part in enumerate(self._phases_b()):
-            part()
-            if self.on_bucket_ready is not None:
-                self.on_bucket_ready(k + 1 if self.n_buckets > 1 else 0)   # this group of encoder gradients is final
-        self._step_end()
+        try:
+            self._phase_a(image, label)
+            if self.on_bucket_ready is not None and self.n_buckets > 1:
+                self.on_bucket_ready(0)      # decoder gradients are final
+            for k, part in enumerate(self._phases_b()):
+                part()
+                if self.on_bucket_ready is not None:
+                    self.on_bucket_ready(k + 1 if self.n_buckets > 1 else 0)   # this group of encoder gradients is final
+        finally:
+            self._step_end()         # also when a launch raised: a later forward must not read this step's weight copies
         return self.elbo
 
     def _step_begin(self):
@@ -287,14 +289,16 @@ class _StepBase(object):
             # one kernel per bucket
             pool = torch.cuda.graph_pool_handle()
             graphs = [torch.cuda.CUDAGraph()]
-            with torch.cuda.graph(graphs[0], pool=pool):
-                self._body_a()
-            for part in self._phases_b():
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    part()
-                graphs.append(g)
-            self._step_end()
+            try:
+                with torch.cuda.graph(graphs[0], pool=pool):
+                    self._body_a()
+                for part in self._phases_b():
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        part()
+                    graphs.append(g)
+            finally:
+                self._step_end()
             self._graphs = tuple(graphs)
             self._optimizer = optimizer
         _restore(self.model, optimizer, self.counter, snap)   # warm-up steps must leave no trace
@@ -309,9 +313,11 @@ class _StepBase(object):
         early = (os.environ.get('MVAE_EARLY_COUNTER', '1') != '0' and self.side is not None
                  and hasattr(optimizer, 'step_counted'))
         self._adam_counter = optimizer.step_counter() if early else None
-        self._body_a()
-        self._phase_b('all')
-        self._step_end()
+        try:
+            self._body_a()
+            self._phase_b('all')
+        finally:
+            self._step_end()
         if early:
             optimizer.step_counted()
         else:
@@ -341,9 +347,16 @@ class _StepBase(object):
         if self._comm is None:
             self._graphs[0].replay()
         else:
+            # graph 0 = phase A (decoder gradients final), graphs 1.. = the encoder groups: bucket k's all-reduce
+            # runs behind the next graph / the Adam launches.  With ONE bucket (a model without encoder ranges)
+            # nothing is reduced after phase A -- the whole arena goes out behind the last graph, exactly as
+            # forward_backward() does it eagerly
             for k, g in enumerate(self._graphs):
                 g.replay()
-                self._comm.launch(k)      # bucket k's all-reduce runs behind the next graph / the Adam launches
+                if self.n_buckets > 1:
+                    self._comm.launch(k)
+                elif k == len(self._graphs) - 1:
+                    self._comm.launch(0)
             self._comm.finish(self._optimizer)
         return self.elbo
 
@@ -822,7 +835,14 @@ class Celeba19Step(_StepBase):
         self.drop_masks = torch.ones(self.n_img, B, 512, dtype=torch.float32, device=dev)
         self.elbo = torch.zeros(T + 1, dtype=torch.float32, device=dev)
         self.combos = None
-        self.set_terms(sample_subsets(self.rng, 1 + N_ATTRS, self.M))
+        # tables start from a FIXED placeholder ({image, attribute j} for sampled term j): the constructor must not
+        # draw from ``rng`` -- with ``rng = numpy.random`` every engine built (also the ragged-last-batch ones built
+        # mid-epoch) would otherwise consume a draw the reference never makes, and the subsets would no longer be
+        # the reference's draw for draw.  step() / replay() draw the step's real subsets.
+        first = np.zeros((self.M, 1 + N_ATTRS), dtype=bool)
+        first[:, 0] = True
+        first[np.arange(self.M), 1 + np.arange(self.M) % N_ATTRS] = True
+        self.set_terms(first)
 
     # ------------------------------------------------------------------ host-side tables
     def set_terms(self, combos, commit=True):

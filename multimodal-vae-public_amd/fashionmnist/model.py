@@ -13,6 +13,10 @@ import torch.nn as nn
 
 from .. import layers as L
 from ..base import MVAEBase, Stack
+# module-level names of the reference's model.py (``from model import ProductOfExperts, Swish, prior_expert``):
+# ProductOfExperts here is variant A -- fashionmnist/model.py:168-182
+from ..base import ProductOfExperts, prior_expert  # noqa: F401
+from ..layers import Swish  # noqa: F401
 
 
 class _SplitEncoder(Stack):

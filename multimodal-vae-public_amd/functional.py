@@ -63,6 +63,37 @@ class PoEFn(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class PoEStackFn(torch.autograd.Function):
+    """``ProductOfExperts.forward`` of the reference on a stacked [M, B, D] pair (mnist/model.py:156-163,
+    celeba/model.py:200-207): the product over ALL M rows (no built-in prior -- row 0 of the reference's stack is
+    what ``prior_expert`` returned), one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, mu_stack, lv_stack, variant):
+        mu_stack, lv_stack = mu_stack.contiguous(), lv_stack.contiguous()
+        M, B, D = mu_stack.shape
+        dev = mu_stack.device
+        masks = torch.full((1,), (1 << M) - 1, dtype=torch.int32, device=dev)
+        mu = torch.empty(1, B, D, dtype=torch.float32, device=dev)
+        lv = torch.empty_like(mu)
+        mus = [mu_stack[e] for e in range(M)]
+        lvs = [lv_stack[e] for e in range(M)]
+        K.poe_fwd(mus, lvs, masks, None, mu, lv, None, None, variant + '-noprior')
+        ctx.variant = variant
+        ctx.save_for_backward(mu, lv, mu_stack, lv_stack, masks)
+        return mu[0], lv[0]
+
+    @staticmethod
+    def backward(ctx, dmu, dlv):
+        mu, lv, mu_stack, lv_stack, masks = ctx.saved_tensors
+        M = mu_stack.shape[0]
+        g_mu, g_lv = torch.empty_like(mu_stack), torch.empty_like(lv_stack)
+        K.poe_bwd([mu_stack[e] for e in range(M)], [lv_stack[e] for e in range(M)], masks, None, mu, lv, None,
+                  dmu.contiguous().reshape(mu.shape), dlv.contiguous().reshape(lv.shape), None,
+                  [g_mu[e] for e in range(M)], [g_lv[e] for e in range(M)], ctx.variant + '-noprior')
+        return g_mu, g_lv, None
+
+
 class ReparamFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, logvar, eps):

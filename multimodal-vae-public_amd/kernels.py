@@ -322,65 +322,6 @@ def convT2d_fwd(x, w, pre, act, stride, pad, wr=None):
     _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad, repack=True, wr=wr)
 
 
-# ---- forward launches that leave their output's batch statistics for the BatchNorm behind them (EXPERIMENTAL:
-#      include/mvae_hip.h; layers.forward_tape uses them under MVAE_FUSED_BN_STATS=1) ----
-def conv_stats_layout(transposed, B, Cin, H, W, Cout, stride, pad):
-    """The record layout a ``conv*_fwd_stats`` launch of this shape leaves, or None when the shape has no such
-    launch (then: ordinary forward + ``bn_train_fwd``)."""
-    lay = _lib.StatsLayout()
-    rc = _lib.lib().mvae_conv_k4_stats_layout(1 if transposed else 0, B, Cin, H, W, Cout, stride, pad, ctypes.byref(lay))
-    return lay if rc == 0 else None
-
-
-def conv2d_fwd_stats(x, w, pre, stride, pad, stats):
-    """``conv2d_fwd`` without activation + statistics records into ``stats`` (float32, >= parts*2*Cout); ``pre``
-    None: statistics only.  Returns the layout."""
-    _need_gpu(x, w, pre, stats); _f32c(x, w, pre, stats)
-    B, Cin, H, W = x.shape
-    lay = _lib.StatsLayout()
-    check(_lib.lib().mvae_conv2d_k4_fwd_stats(_ptr(x), _ptr(w), _ptr(pre), B, Cin, H, W, w.shape[0], stride, pad,
-                                              _ptr(stats), stats.numel(), ctypes.byref(lay), _stream()),
-          'mvae_conv2d_k4_fwd_stats')
-    return lay
-
-
-def convT2d_fwd_stats(x, w, pre, stride, pad, stats, wr=None):
-    _need_gpu(x, w, pre, stats); _f32c(x, w, pre, stats)
-    B, Cin, H, W = x.shape
-    Cout = w.shape[1]
-    lay = _lib.StatsLayout()
-    if wr is not None:
-        _need_gpu(wr); _f32c(wr)
-        wp, ws, wsb = None, _ptr(wr), wr.numel() * 4
-    else:
-        wp = _ptr(w)
-        ws, wsb = _ws_args(Cout * Cin * 16 * 4, x.device)
-    check(_lib.lib().mvae_convT2d_k4_fwd_stats(_ptr(x), wp, _ptr(pre), B, Cin, H, W, Cout, stride, pad, ws, wsb,
-                                               _ptr(stats), stats.numel(), ctypes.byref(lay), _stream()),
-          'mvae_convT2d_k4_fwd_stats')
-    return lay
-
-
-def bn_train_fwd_parts(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, G, shape, stats, lay,
-                       eps=1e-5, momentum=0.1, n_updates=1, swish=True, n_updates_dev=None):
-    """``bn_train_fwd`` on the records of a ``conv*_fwd_stats`` launch.  ``shape`` = (G*B, C, H, W) of the tensor
-    the records describe; ``x`` may be None when ``y`` is None (nothing was stored)."""
-    _need_gpu(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, stats)
-    _f32c(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, stats)
-    GB, C = shape[0], shape[1]
-    HW = 1
-    for d in shape[2:]:
-        HW *= d
-    B = GB // G
-    nbytes = _lib.lib().mvae_bn_ws_bytes(G, C, B * HW)
-    ws, wsb = _ws_args(nbytes, stats.device)
-    check(_lib.lib().mvae_bn_train_fwd_parts(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(save_mean),
-                                             _ptr(save_invstd), _ptr(running_mean), _ptr(running_var),
-                                             G, B, C, HW, eps, momentum, n_updates, _ptr(n_updates_dev),
-                                             ACT_SWISH if swish else 0, _ptr(stats), ctypes.byref(lay),
-                                             ws, wsb, _stream()), 'mvae_bn_train_fwd_parts')
-
-
 def convT2d_dgrad(dy, w, dx, pre_in, stride, pad):
     _need_gpu(dy, w, dx, pre_in); _f32c(dy, w, dx, pre_in)
     B, Cin, H, W = dx.shape

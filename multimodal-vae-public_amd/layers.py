@@ -19,8 +19,6 @@ A stack may process ``G`` groups of ``B`` rows at once (``groups=G``): BatchNorm
 per group, so the G separate ``model()`` calls of the reference's train step become one launch
 per layer with identical results.
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -60,7 +58,7 @@ class Linear(nn.Linear):
 class _RepackMixin(object):
     """Conv modules may carry a repacked weight copy (``_probe_repack``); moving the module drops it."""
     def _apply(self, fn, *a, **kw):
-        for name in ('_wr', '_wr_item', '_wr_fresh'):
+        for name in ('_wr', '_wr_item', '_wr_fresh', '_wr_need'):
             self.__dict__.pop(name, None)
         return super()._apply(fn, *a, **kw)
 
@@ -254,25 +252,6 @@ def _lin_weights(op):
     return w, bias
 
 
-def fused_bn_stats():
-    """MVAE_FUSED_BN_STATS=1 (EXPERIMENTAL, default off: written in round 2, not yet run on hardware): a conv /
-    transposed conv in front of a training-mode BatchNorm leaves the batch statistics of its output from its own
-    epilogue (include/mvae_hip.h: mvae_conv*_k4_fwd_stats), the BatchNorm merges those records instead of sweeping
-    the tensor, and a ``stats_only`` pass does not store the last conv's output at all."""
-    return os.environ.get('MVAE_FUSED_BN_STATS', '0') == '1'
-
-
-def _stats_layout(m, transposed, B, Cin, H, W, Cout, s, p, groups):
-    """The record layout of this layer's statistics launch at this shape (cached on the module), or None when
-    the shape has none or a tile would straddle two BatchNorm groups."""
-    cache = m.__dict__.setdefault('_stats_lay', {})
-    key = (transposed, B, H, W, groups)
-    if key not in cache:
-        lay = K.conv_stats_layout(transposed, B, Cin, H, W, Cout, s, p)
-        cache[key] = lay if (lay is not None and lay.tiles_j % groups == 0) else None
-    return cache[key]
-
-
 def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, final_out=None,
                  bn_updates_dev=None, stats_only=False):
     """Run the plan.  Returns (output, tape); tape is None when not training.
@@ -289,8 +268,6 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
     last_bn = max([i for i, op in enumerate(plan) if op.kind == 'bn'] or [-1]) if stats_only else -1
     if stats_only and (last_bn < 0 or not training):
         raise RuntimeError('stats_only needs a training-mode stack with a BatchNorm')
-    fuse_stats = training and fused_bn_stats()
-    parts = None                # (records, layout, shape) a statistics launch left for the BatchNorm behind it
     for op_index, op in enumerate(plan):
         saved = None
         if op.kind in ('lin', 'lin2'):
@@ -328,25 +305,6 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
             else:
                 Cout, OH, OW = m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4
             pre = act = None
-            lay = None
-            if fuse_stats and not op.act and op_index + 1 < len(plan) and plan[op_index + 1].kind == 'bn':
-                lay = _stats_layout(m, op.kind == 'convT', Bn, h.shape[1], H, W, Cout, s, p, groups)
-            if lay is not None:
-                # the statistics leave with this launch; a stats_only pass ends here without storing anything
-                if not (stats_only and op_index + 1 == last_bn):
-                    pre = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
-                rec = torch.empty(lay.parts() * 2 * Cout, dtype=torch.float32, device=h.device)
-                if op.kind == 'conv':
-                    K.conv2d_fwd_stats(h, m.weight.detach(), pre, s, p, rec)
-                else:
-                    _probe_repack(m, True, Bn, h.shape[1], H, W, Cout, s, p)
-                    K.convT2d_fwd_stats(h, m.weight.detach(), pre, s, p, rec, wr=_fresh_repack(m))
-                parts = (rec, lay, (Bn, Cout, OH, OW))
-                saved = (h, None, None)
-                h = pre
-                if training:
-                    tape.append(saved)
-                continue
             if (not op.act) or training:
                 pre = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
             if op.act:
@@ -354,29 +312,14 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
             if op.kind == 'conv':
                 K.conv2d_fwd(h, m.weight.detach(), pre, act, s, p)
             else:
-                if training:
-                    _probe_repack(m, True, Bn, h.shape[1], H, W, Cout, s, p)
-                K.convT2d_fwd(h, m.weight.detach(), pre, act, s, p, wr=_fresh_repack(m))
+                wr = None
+                if training:        # eval / sample.py launches always repack for themselves
+                    wr = _fresh_repack(m, _probe_repack(m, True, Bn, h.shape[1], H, W, Cout, s, p))
+                K.convT2d_fwd(h, m.weight.detach(), pre, act, s, p, wr=wr)
             saved = (h, pre if op.act else None, None)
             h = act if op.act else pre
         elif op.kind == 'bn':
             m = op.mod
-            if parts is not None:
-                rec, lay, shape = parts
-                parts = None
-                dev = rec.device
-                y = None if (stats_only and op_index == last_bn) else torch.empty(shape, dtype=torch.float32, device=dev)
-                sm = torch.empty(groups, shape[1], dtype=torch.float32, device=dev)
-                si = torch.empty(groups, shape[1], dtype=torch.float32, device=dev)
-                K.bn_train_fwd_parts(h, m.weight.detach(), m.bias.detach(), y, sm, si, m.running_mean,
-                                     m.running_var, groups, shape, rec, lay, eps=m.eps, momentum=m.momentum,
-                                     n_updates=bn_updates, swish=op.act, n_updates_dev=bn_updates_dev)
-                m._nbt_pending += groups * bn_updates
-                if y is None:
-                    return None, None
-                tape.append((h, sm, si))
-                h = y
-                continue
             h = h.contiguous()
             y = None if (stats_only and op_index == last_bn) else torch.empty_like(h)
             if training:
@@ -490,8 +433,8 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
                 dx = torch.empty_like(x)
                 pin = None if pre_in is None else pre_in.reshape(x.shape)
                 if op.kind == 'conv':
-                    _probe_repack(m, False, x.shape[0], x.shape[1], x.shape[2], x.shape[3], m.out_channels, s, p)
-                    K.conv2d_dgrad(g, m.weight.detach(), dx, pin, s, p, wr=_fresh_repack(m))
+                    key = _probe_repack(m, False, x.shape[0], x.shape[1], x.shape[2], x.shape[3], m.out_channels, s, p)
+                    K.conv2d_dgrad(g, m.weight.detach(), dx, pin, s, p, wr=_fresh_repack(m, key))
                 else:
                     K.convT2d_dgrad(g, m.weight.detach(), dx, pin, s, p)
                 g = dx
@@ -541,15 +484,28 @@ def _conv_out_shape(op, x):
 # start of its step (``repack_weights``) and withdraws them at its end (``repack_done``) -- between steps the
 # optimizer changes the weights, and anything run outside an engine step takes the self-contained path.
 def _probe_repack(m, transposed, B, Cin, H, W, Cout, s, p):
-    if getattr(m, '_wr_item', None) is None:
+    """Ask the library -- once per GEOMETRY -- whether this launch reads a repacked weight copy
+    (``mvae_conv_k4_repack_floats``: the answer and the kernel selection depend on B, H, W; the direct kernels of
+    the <= 4-channel layers read ``w`` itself).  The copy's content depends only on the layer, so a module keeps
+    one buffer; which geometries may use it is remembered per (B, H, W) (one cached answer per module
+    handed ``w = NULL`` to a geometry that needs ``w``)."""
+    need = m.__dict__.setdefault('_wr_need', {})
+    key = (B, H, W)
+    if key not in need:
         n = K.conv_repack_floats(transposed, m.weight.detach(), B, Cin, H, W, Cout, s, p)
-        m._wr = torch.empty(n, dtype=torch.float32, device=m.weight.device) if n else None
-        m._wr_item = (bool(transposed), Cin, Cout, s, p)
-        m._wr_fresh = False
+        need[key] = n > 0
+        if n > 0 and getattr(m, '_wr', None) is None:
+            m._wr = torch.empty(n, dtype=torch.float32, device=m.weight.device)
+            m._wr_item = (bool(transposed), Cin, Cout, s, p)
+            m._wr_fresh = False
+    return key
 
 
-def _fresh_repack(m):
-    return m._wr if getattr(m, '_wr_fresh', False) else None
+def _fresh_repack(m, key):
+    """The module's repacked copy if an engine step made it for THIS step and this geometry reads one."""
+    if getattr(m, '_wr_fresh', False) and m.__dict__.get('_wr_need', {}).get(key, False):
+        return m._wr
+    return None
 
 
 def repack_weights(mods):

@@ -10,6 +10,10 @@ constructor arguments, ``forward`` keywords, return tuple and ``state_dict`` key
 """
 from .. import layers as L
 from ..base import MVAEBase, Stack
+# module-level names of the reference's model.py (``from model import ProductOfExperts, Swish, prior_expert``):
+# ProductOfExperts here is variant A -- mnist/model.py:149-163
+from ..base import ProductOfExperts, prior_expert  # noqa: F401
+from ..layers import Swish  # noqa: F401
 
 
 class _TwoHeadEncoder(Stack):

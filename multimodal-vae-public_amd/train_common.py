@@ -152,6 +152,25 @@ def read_idx(path):
     return data.reshape(dims)
 
 
+def shard_order(order, rank, world):
+    """This rank's share of one shared permutation: ``order`` is padded by wrapping around to a multiple of
+    ``world`` (what ``DistributedSampler`` does) and dealt out round-robin, so EVERY rank sees the same number of
+    samples and therefore the same number of batches -- a rank with one batch more would enter a round of
+    gradient all-reduces its peers never join (deadlock), on a BatchNorm batch of one."""
+    n = int(order.shape[0]) if hasattr(order, 'shape') else len(order)
+    if world <= 1 or n == 0:
+        return order
+    per_rank = (n + world - 1) // world
+    pad = per_rank * world - n
+    if pad:
+        order = torch.cat([order, order[:pad]]) if torch.is_tensor(order) else list(order) + list(order[:pad])
+    return order[rank::world]
+
+
+def shard_len(n_total, world):
+    return (n_total + world - 1) // world if world > 1 else n_total
+
+
 class IdxLoader(object):
     """MNIST / FashionMNIST from the raw IDX files, without torchvision: the whole split sits in HBM as
     uint8 (47 MB), a batch is an index gather + ``preprocess.to_tensor`` on the device -- the
@@ -175,7 +194,7 @@ class IdxLoader(object):
         self.rank, self.world = int(rank), int(world)
         # data parallel: every rank draws the SAME permutation (shared seed) and keeps order[rank::world],
         # so one epoch is one pass over the data across all ranks (what a DistributedSampler does)
-        self.dataset = range(rank, images.shape[0], world)
+        self.dataset = range(shard_len(images.shape[0], self.world))     # len() = samples per rank, equal on all ranks
         self._n_total = images.shape[0]
         self._gen = torch.Generator().manual_seed(seed)
 
@@ -185,7 +204,7 @@ class IdxLoader(object):
     def __iter__(self):
         n_total = self._n_total
         order = torch.randperm(n_total, generator=self._gen) if self.shuffle else torch.arange(n_total)
-        order = order[self.rank::self.world].to(self.device)
+        order = shard_order(order, self.rank, self.world).to(self.device)
         n = order.numel()
         for i in range(0, n, self.batch_size):
             idx = order[i:i + self.batch_size]

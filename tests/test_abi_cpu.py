@@ -76,10 +76,6 @@ def test_bad_arguments_return_error_codes_without_a_gpu():
     assert lib.mvae_adam_apply_at(p, p, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 1.0, p, 0, None) == 0        # nothing to do
     assert lib.mvae_linear_wgrad_batched(None, 1, None) == -1
     assert lib.mvae_conv_k4_repack_batched(None, 1, None) == -1
-    assert lib.mvae_conv2d_k4_fwd_stats(p, p, p, 8, 32, 32, 32, 64, 2, 1, None, 0, None, None) == -1   # no record buffer
-    lay = _lib.StatsLayout()
-    assert lib.mvae_conv_k4_stats_layout(0, 8, 32, 32, 32, 64, 3, 1, ctypes.byref(lay)) == -1           # stride 3
-    assert lib.mvae_conv_k4_stats_layout(0, 8, 32, 32, 32, 64, 2, 1, None) == -1
 
 
 def test_no_cpu_fallback():
@@ -149,49 +145,27 @@ def test_arena_layout_on_cpu_tensors():
     assert enc.fc1.weight.data_ptr() == arena.flat.data_ptr() + 4 * enc.fc1.weight._arena_off
 
 
-# ---- statistics launches (conv epilogue -> BatchNorm): the layout query and the argument checks are host logic ----
-CELEBA_STATS_SHAPES = [
-    # transposed, B, Cin, H, W, Cout, stride, pad, has_layout       (celeba/model.py:79-86,117-126 at B = 256, 3 decodes)
-    (0, 256, 3, 64, 64, 32, 2, 1, False),        # first conv: direct small-channel kernel (and no BatchNorm behind it)
-    (0, 256, 32, 32, 32, 64, 2, 1, True),
-    (0, 256, 64, 16, 16, 128, 2, 1, True),
-    (0, 256, 128, 8, 8, 256, 1, 0, True),
-    (1, 768, 256, 1, 1, 128, 1, 0, False),       # 1x1 -> 4x4 transposed conv: its own stride-1 kernel
-    (1, 768, 128, 4, 4, 64, 2, 1, True),
-    (1, 768, 64, 8, 8, 32, 2, 1, True),
-    (1, 768, 32, 16, 16, 3, 2, 1, False),        # last layer: direct kernel
-    (1, 19 * 256, 64, 8, 8, 32, 2, 1, True),     # celeba19: 19 decodes in one launch
-    (0, 7, 128, 8, 8, 256, 1, 0, False),         # 7 * 25 positions: a ragged last tile
-]
-
-
-@pytest.mark.parametrize('tr,B,Cin,H,W,Cout,s,p,has', CELEBA_STATS_SHAPES)
-def test_stats_layout_covers_every_output_position_once(tr, B, Cin, H, W, Cout, s, p, has):
-    from mvae_amd import kernels as K
-    lay = K.conv_stats_layout(tr, B, Cin, H, W, Cout, s, p)
-    assert (lay is not None) == has
-    if lay is None:
-        return
-    OH = (H - 1) * s - 2 * p + 4 if tr else (H + 2 * p - 4) // s + 1
-    OW = (W - 1) * s - 2 * p + 4 if tr else (W + 2 * p - 4) // s + 1
-    assert lay.ncls == (s * s if tr else 1)
-    assert lay.parts() * lay.cols == B * OH * OW
-    assert lay.cols in (32, 64) and lay.ppt in (1, 2, 4)
-
-
-def test_bn_from_parts_rejects_layouts_that_do_not_match_the_tensor():
-    lib = _lib.lib()
-    buf = (ctypes.c_float * 64)()
+def test_reference_module_level_names_exist_on_every_drop_in():
+    """``from model import MVAE, ProductOfExperts, Swish, prior_expert`` and ``model.experts`` -- the names the
+    reference's model.py defines (mnist/model.py:14,149,166,172; celeba/model.py:13,193,210,216)."""
+    import re
+    header = open(os.path.join(ROOT, 'include', 'mvae_hip.h')).read()
+    assert int(re.search(r'#define\s+MVAE_POE_NO_PRIOR\s+(\d+)', header).group(1)) == _lib.POE_NO_PRIOR
+    for kind, variant in (('mnist', 'A'), ('fashionmnist', 'A'), ('celeba', 'B'), ('celeba19', 'B')):
+        mod = getattr(mvae_amd, kind).model
+        for name in ('MVAE', 'ProductOfExperts', 'Swish', 'prior_expert'):
+            assert hasattr(mod, name), '%s/model.py lacks %s' % (kind, name)
+        assert mod.ProductOfExperts.VARIANT == variant
+        m = mod.MVAE(8)
+        assert isinstance(m.experts, mod.ProductOfExperts)
+        assert not [k for k in m.state_dict() if k.startswith('experts')]      # parameter-free: keys unchanged
+        mu, lv = mod.prior_expert((1, 3, 8))
+        assert mu.shape == (1, 3, 8) and not mu.is_cuda and float(mu.abs().sum() + lv.abs().sum()) == 0.0
+        with pytest.raises(RuntimeError, match='GPU'):
+            m.experts(mu, lv)
+    # the C ABI refuses an empty product
+    ex = _lib.Experts()
+    buf = (ctypes.c_float * 16)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    G, B, C, HW = 3, 256, 64, 256
-
-    def call(lay, x=p, y=p):
-        return lib.mvae_bn_train_fwd_parts(x, p, p, y, p, p, None, None, G, B, C, HW, 1e-5, 0.1, 1, None, 0, p,
-                                           ctypes.byref(lay), p, 1 << 30, None)
-    ERR_ARG = -1
-    assert _lib.StatsLayout(4, 768, 2, 32).parts() * 32 == G * B * HW       # the layout that WOULD be accepted
-    assert call(_lib.StatsLayout(4, 768, 2, 32), x=None, y=p) == ERR_ARG    # an output needs x
-    assert call(_lib.StatsLayout(4, 192, 2, 32)) == ERR_ARG                 # covers a quarter of the tensor
-    assert call(_lib.StatsLayout(4, 767, 2, 32)) == ERR_ARG                 # wrong count
-    assert call(_lib.StatsLayout(2, 1024, 3, 32)) == ERR_ARG                # right count, tiles straddle groups
-    assert call(_lib.StatsLayout(0, 0, 0, 0)) == ERR_ARG
+    assert _lib.lib().mvae_poe_fwd(ctypes.byref(ex), 4, 0, p, 1, None, p, p, None, None, 1, 4,
+                                   _lib.POE_VARIANT['A-noprior'], None) == -1

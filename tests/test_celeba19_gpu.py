@@ -174,3 +174,21 @@ def test_graph_replay_with_changing_subsets():
         losses.append(eng.replay(image.to(DEV), attrs.to(DEV), 0.5)[-1].item())
     assert all(np.isfinite(losses))
     assert not torch.equal(before, model.arena.flat)
+
+
+def test_constructing_an_engine_draws_nothing_from_the_subset_generator():
+    """with ``rng = numpy.random`` (celeba19/train.py's global generator) every engine construction --
+    also the ragged-last-batch engines built mid-epoch -- used to consume one ``sample_combinations`` draw the
+    reference never makes."""
+    _, model, d = build_pair('celeba19', weight_seed=47)
+    rng = np.random.RandomState(99)
+    before = rng.get_state()[1].copy(), rng.get_state()[2]
+    eng = Celeba19Step(model, 4, 1.0, 10.0, approx_m=2, rng=rng)
+    after = rng.get_state()[1], rng.get_state()[2]
+    assert np.array_equal(before[0], after[0]) and before[1] == after[1]
+    assert eng.combos.shape == (2, 19) and (eng.combos.sum(axis=1) == 2).all() and eng.combos[:, 0].all()
+    # the first STEP takes the generator's first draw -- the reference's first sample_combinations call
+    expect = sample_subsets(np.random.RandomState(99), 19, 2)
+    image, attrs = OS.synthetic_batch('celeba19', 4, seed=86)
+    eng.step(image.to(DEV), attrs.to(DEV), 0.5)
+    assert np.array_equal(eng.combos, expect)

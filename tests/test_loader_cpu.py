@@ -37,3 +37,21 @@ def test_read_idx_rejects_garbage(tmp_path):
     open(p, 'ab').write(b'\x01')                                    # one byte too many
     with pytest.raises(ValueError):
         read_idx(p)
+
+
+@pytest.mark.parametrize('n,world,batch', [(10, 3, 3), (9, 2, 4), (8, 2, 4), (7, 4, 1), (5, 1, 2), (60000, 8, 512)])
+def test_every_rank_gets_the_same_number_of_batches(n, world, batch):
+    """ADVICE r2: ``order[rank::world]`` gave rank 0 one sample -- sometimes one BATCH -- more than the last rank;
+    the extra batch's all-reduces have no peer (deadlock).  The shared permutation is padded by wrapping, like
+    DistributedSampler: equal shares, every sample still seen once per epoch."""
+    import torch
+    from mvae_amd.train_common import shard_len, shard_order
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    shares = [shard_order(order, r, world) for r in range(world)]
+    assert len({int(s.numel()) for s in shares}) == 1
+    assert shares[0].numel() == shard_len(n, world)
+    n_batches = {(int(s.numel()) + batch - 1) // batch for s in shares}
+    assert len(n_batches) == 1
+    seen = torch.cat(shares)
+    assert set(seen.tolist()) == set(range(n)) and seen.numel() - n < world
+    assert shard_order(list(range(n)), 0, world)[:2] == list(range(n))[0::world][:2]      # plain lists too

@@ -129,3 +129,43 @@ def test_per_bucket_fences_world2(tmp_path):
     mp.spawn(_finish_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert torch.load(os.path.join(str(tmp_path), 'order%d.pt' % r)) == [3.0, 3.0, 3.0]
+
+
+# ----------------------------------------------------------------------------- bench.py as its own launcher
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, env=env, timeout=timeout,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_n_spawns_n_ranks_by_itself():
+    """``python bench.py --gpus 2`` with no launcher (it silently ran ONE rank): the script re-runs
+    itself as two ranks under torch.distributed.run; the gloo backend stands in for RCCL on this CPU-only box
+    and the line shows two ranks that really exchanged data."""
+    rc, line, err = _run_bench(['--gpus', '2', '--backend', 'gloo'])
+    assert rc == 0, err[-2000:]
+    assert line['n_gpus'] == 2
+    assert line['dist']['world_size'] == 2 and line['dist']['allreduce_of_ones'] == 2.0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('CPU-box check')
+    rc, line, err = _run_bench(['--gpus', '2'])
+    assert rc != 0 and line is None and 'only 0 GPU(s) visible' in err
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_the_flag():
+    rc, line, err = _run_bench(['--gpus', '4', '--backend', 'gloo'],
+                               {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert rc != 0 and line is None and 'WORLD_SIZE=1' in err

@@ -1,0 +1,177 @@
+"""GPU parity of the path bench.py TIMES: ``capture()`` + ``replay()`` -- hipGraph, two streams, device Philox
+noise, early Adam counter, batched weight gradients / weight repacks -- against the oracle, at BASELINE.json's
+per-GPU batch sizes, for all four experiments; and the same for the data-parallel launch path (one graph per
+gradient bucket, RCCL all-reduces between them, per-bucket Adam) at world size 1.
+
+How: snapshot the weights -> capture -> ONE replay -> read back what the graph used and produced at their fixed
+addresses (``eng.noise``, ``eng.drop_masks``, the ELBO vector, ``model.arena.grad``, BatchNorm running statistics,
+the post-Adam parameters) -> run the oracle step (mnist/train.py:197-219, celeba19/train.py:257-308) from the
+snapshot on exactly that noise.  Bars as everywhere: ELBO terms and every gradient 1e-4 relative, BatchNorm
+running statistics 1e-5; the optimizer update against ``torch.optim.Adam`` (mnist/train.py:168,219) on the same
+gradients to fp32 round-off, and against Adam on the ORACLE's gradients wherever the gradient's sign is
+resolved (the first Adam step is lr * g / (|g| + 1e-8): a sign function)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from mvae_amd.engine import BimodalStep, Celeba19Step, sample_subsets
+from mvae_amd.optim import FusedAdam
+from mvae_amd.parallel import DataParallel
+from oracle import steps as OS
+from test_engine_gpu import build_pair, check_bn_vs, check_grads_vs_oracle, hits_bce_jump
+from util import ZERO_GRAD_PARAMS, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+LR = 1e-3
+LAM = {'mnist': 50.0, 'fashionmnist': 50.0, 'celeba': 10.0, 'celeba19': 10.0}
+BETA = 0.5
+N_ATTRS = 18
+
+
+@pytest.fixture(scope='module')
+def rccl_world1():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield
+    dist.destroy_process_group()
+
+
+def _engine(kind, model, batch):
+    if kind == 'celeba19':
+        return Celeba19Step(model, batch, 1.0, LAM[kind], approx_m=1, seed=77)
+    return BimodalStep(model, batch, 1.0, LAM[kind], seed=77)
+
+
+def _noise_in_reference_order(kind, eng, combos):
+    """What the replayed graph drew on the device (Philox), as the oracle's explicit-noise dict."""
+    noise = eng.noise.detach().cpu()
+    masks = None if eng.drop_masks is None else eng.drop_masks.detach().cpu()
+    if masks is not None:
+        assert set(torch.unique(masks).tolist()) <= {0.0, 1.0}
+    if kind == 'celeba19':
+        terms = OS.celeba19_terms(combos)
+        img_terms = [0, 1] + [2 + N_ATTRS + j for j in range(eng.M)]
+        out = {'eps': [noise[t] for t in range(eng.T)], 'mask': [None] * eng.T}
+        for k, t in enumerate(img_terms):
+            if terms[t][0][0]:
+                out['mask'][t] = masks[k]
+        return out, terms
+    out = {'eps': [noise[eng.ref_order.index(r)] for r in range(3)], 'mask': [None, None, None]}
+    if masks is not None:
+        out['mask'][0], out['mask'][1] = masks[0], masks[1]
+    return out, None
+
+
+def _check_adam(kind, model, oracle, w0, g_hip, w1):
+    """``w1`` (parameters after the captured optimizer launch) vs torch.optim.Adam from ``w0``."""
+    p = torch.nn.Parameter(w0.clone())
+    p.grad = g_hip.clone()
+    torch.optim.Adam([p], lr=LR).step()
+    # same formula in fp32 on both sides: equal to a couple of ulps of the parameter (+ round-off of the update)
+    bound = 1e-5 * LR + 2.4e-7 * p.detach().abs()
+    excess = ((w1 - p.detach()).abs() - bound).max().item()
+    assert excess <= 0, 'captured Adam vs torch.optim.Adam on the same gradients: %.3e beyond 2 ulp' % excess
+    ref_opt = torch.optim.Adam(oracle.parameters(), lr=LR)
+    before = {n: q.detach().clone() for n, q in oracle.named_parameters()}
+    ref_opt.step()
+    flat0 = model.arena.flat.data_ptr()
+    for name, q in model.named_parameters():
+        off = (q.data_ptr() - flat0) // 4
+        got = w1[off:off + q.numel()].reshape(q.shape)
+        ref = dict(oracle.named_parameters())[name].detach()
+        g = dict(oracle.named_parameters())[name].grad
+        d = (got - ref).abs()
+        assert d.max().item() <= 2.0 * LR + 1e-7, 'post-Adam %s beyond the step size: %.3e' % (name, d.max().item())
+        if name in ZERO_GRAD_PARAMS.get(kind, ()):
+            continue
+        resolved = g.abs() > max(2e-4 * g.abs().max().item(), 1e-5)
+        assert resolved.any(), name
+        e = d[resolved].max().item()
+        assert e <= 1e-3 * LR + 1e-8, 'post-Adam %s (sign-resolved entries): %.3e' % (name, e)
+        moved = (ref - before[name]).abs()[resolved].min().item()
+        assert moved > 0.5 * LR, name
+
+
+def _replay_once(kind, batch, input_seed, use_dp, combos):
+    oracle, model, d = build_pair(kind, weight_seed=53)
+    opt = FusedAdam(model.parameters(), lr=LR)
+    eng = _engine(kind, model, batch)
+    dp = DataParallel(model, eng) if use_dp else None
+    image, label = OS.synthetic_batch(kind, batch, seed=input_seed)
+    w0 = model.arena.flat.detach().clone()
+    eng.capture(opt, image.shape[1:], label, comm=dp)
+    assert torch.equal(w0, model.arena.flat), 'capture() left a trace in the parameters'
+    if kind == 'celeba19':
+        elbo = eng.replay(image.to(DEV), label.to(DEV), BETA, combos=combos)
+    else:
+        elbo = eng.replay(image.to(DEV), label.to(DEV), BETA)
+    torch.cuda.synchronize()
+    assert opt._step_dev.item() == 1
+    return oracle, model, eng, d, image, label, w0.cpu(), elbo.detach().cpu().clone()
+
+
+@pytest.mark.parametrize('use_dp', [False, True], ids=['single_graph', 'dp_world1'])
+@pytest.mark.parametrize('kind,batch', [('mnist', 512), ('fashionmnist', 1024), ('celeba', 256), ('celeba19', 256)])
+def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch, use_dp):
+    combos = sample_subsets(np.random.RandomState(2025), 19, 1) if kind == 'celeba19' else None
+    redraws = 0
+    for attempt in range(4):
+        oracle, model, eng, d, image, label, w0, elbo = _replay_once(kind, batch, 191 + attempt, use_dp, combos)
+        if kind == 'celeba19' or not hits_bce_jump(eng):
+            break
+        redraws += 1
+    else:
+        pytest.fail('four consecutive draws with an exactly-zero logit')
+    if use_dp:
+        assert len(eng._graphs) == (2 if kind == 'mnist' else 3)
+    noise, terms = _noise_in_reference_order(kind, eng, combos)
+    if kind == 'celeba19':
+        total, elbos, _ = OS.celeba19_step(oracle, image, label, terms, noise, 1.0, LAM[kind], BETA)
+        T = len(terms)
+        got = elbo
+    else:
+        total, elbos, _ = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, LAM[kind], BETA)
+        T = 3
+        got = eng.terms_in_reference_order(elbo)
+    total.backward()
+    assert_close(got[:T], torch.stack(elbos).detach(), 'ELBO terms (replay)')
+    assert_close(got[T], total.detach(), 'total (replay)')
+    # the gradient arena still holds this step's gradients (Adam only reads them)
+    g_hip = model.arena.grad.detach().cpu().clone()
+    w1 = model.arena.flat.detach().cpu().clone()
+    for p in model.parameters():       # graph replays do not touch the python-side .grad views: re-attach them
+        if p.grad is None:
+            off = (p.data_ptr() - model.arena.flat.data_ptr()) // 4
+            p.grad = model.arena.grad[off:off + p.numel()].view(p.shape)
+    worst = check_grads_vs_oracle(model, oracle)
+    check_bn_vs(model, oracle.state_dict())
+    _check_adam(kind, model, oracle, w0, g_hip, w1)
+    print('%s B=%d %s: replayed step vs oracle, worst gradient rel err %.2e, %d input re-draw(s) for an exact-zero '
+          'logit' % (kind, batch, 'dp(3 graphs)' if use_dp else 'one graph', worst, redraws))
+
+
+def test_replay_noise_is_fresh_every_step_and_standard_normal():
+    """The device Philox stream behind the timed path: a new draw per replay, N(0,1) / Bernoulli(0.9) moments."""
+    _, model, d = build_pair('celeba', weight_seed=59)
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    eng = BimodalStep(model, 64, 1.0, 10.0, seed=5)
+    image, label = OS.synthetic_batch('celeba', 64, seed=7)
+    eng.capture(opt, image.shape[1:], label)
+    seen = []
+    for _ in range(3):
+        eng.replay(image.to(DEV), label.to(DEV), 1.0)
+        torch.cuda.synchronize()
+        seen.append((eng.noise.clone(), eng.drop_masks.clone()))
+    assert not torch.equal(seen[0][0], seen[1][0]) and not torch.equal(seen[1][0], seen[2][0])
+    assert not torch.equal(seen[0][1], seen[1][1])
+    eps = torch.cat([s[0].reshape(-1) for s in seen])
+    assert abs(eps.mean().item()) < 0.02 and abs(eps.std().item() - 1.0) < 0.02
+    keep = torch.cat([s[1].reshape(-1) for s in seen])
+    assert abs(keep.mean().item() - 0.9) < 0.01
