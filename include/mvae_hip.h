@@ -17,8 +17,8 @@
  *   - re-entrant: no global mutable state (launch plans are pure functions of the shapes).  The
  *     tuning overrides at the end of this header exist only in the separate -DMVAE_TUNING build
  *     (libmvae_hip_tuning.so, used by tools/gemm_bench.py); libmvae_hip.so does not export them;
- *   - collectives are NOT part of this ABI: data-parallel replicas all-reduce the gradient arena with
- *     torch.distributed (RCCL), see INTEGRATION.md.
+ *   - the data-parallel gradient exchange (RCCL over xGMI) is part of the ABI: mvae_comm_* at the end of this
+ *     header; RCCL is bound at run time, so the library has no link-time dependency on it.
  */
 #ifndef MVAE_HIP_H
 #define MVAE_HIP_H
@@ -34,6 +34,7 @@ extern "C" {
 #define MVAE_ERR_ARG    (-1)   /* bad shape / null pointer / unsupported stride */
 #define MVAE_ERR_LAUNCH (-2)   /* hipLaunchKernel reported an error */
 #define MVAE_ERR_WS     (-3)   /* workspace too small */
+#define MVAE_ERR_COMM   (-4)   /* RCCL not loadable / an RCCL or HIP runtime call of mvae_comm_* failed (mvae_comm_last_error) */
 
 /* flags */
 #define MVAE_ACT_SWISH   1     /* fwd: also write swish(out); bwd: multiply by swish'(preact) */
@@ -249,6 +250,14 @@ int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E,
                  const uint32_t *masks_dev, int T,
                  const float *noise, float *mu, float *logvar, float *z, float *kl,
                  int B, int D, int variant, mvae_stream_t stream);
+/* mvae_poe_fwd that draws its own reparameterisation noise (mnist/model.py:32: eps = std.data.new(size).normal_()):
+ * eps[T,B,D] = exactly the standard normals mvae_philox_fill(seed, *counter_dev + counter_offset) would write,
+ * generated inside the launch and stored to noise_out for the backward.  The counter is not advanced. */
+int mvae_poe_fwd_draw(const mvae_experts_t *experts, int ld, int E,
+                      const uint32_t *masks_dev, int T,
+                      float *noise_out, uint64_t seed, const uint64_t *counter_dev, uint64_t counter_offset,
+                      float *mu, float *logvar, float *z, float *kl,
+                      int B, int D, int variant, mvae_stream_t stream);
 int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E,
                  const uint32_t *masks_dev, int T,
                  const float *noise, const float *mu, const float *logvar,
@@ -410,6 +419,41 @@ int mvae_resize_crop_u8_to_f32(const uint8_t *src, float *dst, int B, int H, int
                                const int *bx_dev, int ksx, const int *ky_dev, const int *by_dev,
                                int ksy, int y0, int y1, mvae_stream_t stream);
 int mvae_u8_to_f32(const uint8_t *src, float *dst, size_t n, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * C1  Gradient exchange of data-parallel replicas -- RCCL over xGMI.
+ *     The reference has NO counterpart: it is single-process, single-device (no DataParallel, no
+ *     torch.distributed anywhere; README.md:47 `CUDA_VISIBLE_DEVICES=0`).  What this replaces is what N
+ *     independent copies of mnist/train.py:197-219 would have to add between `backward()` (:218) and
+ *     `optimizer.step()` (:219): the average of every parameter's gradient over the replicas.
+ *
+ *   One process per GPU, one communicator per process.  Start-up: rank 0 calls mvae_comm_unique_id and hands the
+ *   128 bytes to its peers over any host transport (a file, a socket, MPI, torch.distributed's store); every rank
+ *   calls mvae_comm_init (collective: returns when all `world` ranks joined); mvae_comm_broadcast makes parameters
+ *   and buffers equal.  Per step: after the last weight-gradient launch of a bucket (a contiguous fp32 range of the
+ *   gradient arena) was enqueued on `stream`, mvae_comm_allreduce_async sums that range over the ranks IN PLACE on
+ *   the communicator's own stream -- ordered after `stream`'s work so far, concurrent with what `stream` gets next --
+ *   and returns a ticket; mvae_comm_wait(ticket, stream) makes `stream` wait for it (then: mvae_adam_apply on the
+ *   range with grad_scale = 1 / world).  Enqueue-only, no host sync, and capturable: issued between
+ *   hipStreamBeginCapture / EndCapture on `stream` the collectives become nodes of the step's hipGraph (the
+ *   communicator's stream forks from and joins back into the capturing stream -- every ticket must be waited on
+ *   before EndCapture).  RCCL is dlopen-ed on first use: mvae_comm_use_library(path) > $MVAE_RCCL_LIB >
+ *   "librccl.so.1" on the loader path.  At most 16 tickets may be outstanding; tickets are per communicator.
+ *   Returns MVAE_OK / MVAE_ERR_ARG / MVAE_ERR_COMM (text: mvae_comm_last_error).
+ * ------------------------------------------------------------------------------------ */
+#define MVAE_COMM_ID_BYTES 128
+typedef struct mvae_comm mvae_comm_t;
+int mvae_comm_use_library(const char *librccl_path);         /* before first use; MVAE_ERR_ARG once another one is bound */
+int mvae_comm_rccl_version(void);                            /* RCCL's version code (e.g. 22606), or MVAE_ERR_COMM */
+int mvae_comm_unique_id(void *id_out, size_t id_bytes);      /* id_bytes >= MVAE_COMM_ID_BYTES */
+int mvae_comm_init(mvae_comm_t **comm, const void *id, size_t id_bytes, int rank, int world, int device);
+int mvae_comm_rank(const mvae_comm_t *comm);
+int mvae_comm_world(const mvae_comm_t *comm);
+const char *mvae_comm_last_error(const mvae_comm_t *comm);
+int mvae_comm_broadcast(mvae_comm_t *comm, void *buf, size_t bytes, int root, mvae_stream_t stream);
+int mvae_comm_allreduce_async(mvae_comm_t *comm, float *buf, size_t count, mvae_stream_t stream, int *ticket);
+int mvae_comm_wait(mvae_comm_t *comm, int ticket /* < 0: everything issued so far */, mvae_stream_t stream);
+int mvae_comm_destroy(mvae_comm_t *comm);
 
 #ifdef MVAE_TUNING
 /* ------------------------------------------------------------------------------------

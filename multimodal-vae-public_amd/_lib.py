@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(_HERE, 'libmvae_hip.so')
 MVAE_OK = 0
 ERRORS = {-1: 'MVAE_ERR_ARG (bad shape / null pointer / unsupported stride)',
           -2: 'MVAE_ERR_LAUNCH (hip kernel launch failed)',
-          -3: 'MVAE_ERR_WS (workspace too small)'}
+          -3: 'MVAE_ERR_WS (workspace too small)',
+          -4: 'MVAE_ERR_COMM (RCCL not loadable, or an RCCL / HIP runtime call of mvae_comm_* failed)'}
+COMM_ID_BYTES = 128   # MVAE_COMM_ID_BYTES
 ACT_SWISH = 1
 ACCUMULATE = 2
 POE_NO_PRIOR = 4     # MVAE_POE_NO_PRIOR
@@ -95,6 +97,8 @@ _SIGNATURES = {
     'mvae_u8_to_f32': (c_int, [P, P, c_size_t, P]),
     'mvae_poe_fwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P,
                              c_int, c_int, c_int, P]),
+    'mvae_poe_fwd_draw': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, c_uint64, P, c_uint64, P, P, P, P,
+                                  c_int, c_int, c_int, P]),
     'mvae_poe_bwd': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P, P, P, P, c_int,
                              ctypes.POINTER(ExpertGrads), c_int, c_int, c_int, c_int, P]),
     'mvae_poe_bwd_split': (c_int, [ctypes.POINTER(Experts), c_int, c_int, P, c_int, P, P, P, P,
@@ -129,6 +133,18 @@ _SIGNATURES = {
     'mvae_scatter_sums': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'mvae_bce_elem_fwd': (c_int, [P, P, P, c_size_t, P]),
     'mvae_bce_elem_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
+    # C1: the gradient exchange (RCCL bound at run time)
+    'mvae_comm_use_library': (c_int, [ctypes.c_char_p]),
+    'mvae_comm_rccl_version': (c_int, []),
+    'mvae_comm_unique_id': (c_int, [P, c_size_t]),
+    'mvae_comm_init': (c_int, [ctypes.POINTER(P), P, c_size_t, c_int, c_int, c_int]),
+    'mvae_comm_rank': (c_int, [P]),
+    'mvae_comm_world': (c_int, [P]),
+    'mvae_comm_last_error': (ctypes.c_char_p, [P]),
+    'mvae_comm_broadcast': (c_int, [P, P, c_size_t, c_int, P]),
+    'mvae_comm_allreduce_async': (c_int, [P, P, c_size_t, P, ctypes.POINTER(c_int)]),
+    'mvae_comm_wait': (c_int, [P, c_int, P]),
+    'mvae_comm_destroy': (c_int, [P]),
 }
 
 # tuning overrides: only exported by libmvae_hip_tuning.so (csrc built with -DMVAE_TUNING); bound when

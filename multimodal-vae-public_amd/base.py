@@ -29,6 +29,12 @@ class Stack(nn.Module):
         return p
 
     def run(self, x, groups=1, masks=None, bn_updates=1):
+        # a stack called on its own (``model.image_decoder(z)``, mnist/sample.py:111; ``model.image_encoder(x)`` in
+        # user code) before any model-level call: make sure the owner's parameters sit in the arena
+        owner = self.__dict__.get('_owner_ref')
+        owner = owner() if owner is not None else None
+        if owner is not None and x.is_cuda and id(self) in owner.__dict__.get('_stack_ids', ()):
+            owner.finalize()
         return L.run_plan(self.plan(), x, groups=groups, masks=masks, bn_updates=bn_updates,
                           training=self.training)
 
@@ -83,6 +89,25 @@ class MVAEBase(nn.Module):
         self.__dict__['_arena'] = None
         self.__dict__['_rng'] = None
 
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        import weakref
+        mods = [value] if isinstance(value, Stack) else (list(value) if isinstance(value, nn.ModuleList) else [])
+        for m in mods:
+            if isinstance(m, Stack):
+                m.__dict__['_owner_ref'] = weakref.ref(self)      # not a child link: no cycle in modules()
+                self.__dict__.setdefault('_stack_ids', set()).add(id(m))
+
+    def _link_stacks(self):
+        """(Re-)attach every stack to THIS model (a deepcopy keeps the original's back-references)."""
+        import weakref
+        ids = set()
+        for m in self.modules():
+            if isinstance(m, Stack):
+                m.__dict__['_owner_ref'] = weakref.ref(self)
+                ids.add(id(m))
+        self.__dict__['_stack_ids'] = ids
+
     # ------------------------------------------------------------------ arena / device plumbing
     def arena_order(self):
         """Sub-modules in backward-completion order (decoders first)."""
@@ -106,6 +131,7 @@ class MVAEBase(nn.Module):
                                    'the HIP path has no CPU fallback')
             self.__dict__['_arena'] = ParamArena(self, order=self.arena_order(),
                                                  adjacent=self.arena_adjacent(), tail=self.arena_tail())
+            self._link_stacks()
         return self.__dict__['_arena']
 
     @property

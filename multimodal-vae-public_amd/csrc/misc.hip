@@ -1,6 +1,7 @@
 // misc.hip -- the remaining HBM-bound pieces of the step: stand-alone Swish, Embedding(+Swish)
 // gather / scatter, counter-based Philox noise, fused Adam over the flat parameter arena, fill.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -98,29 +99,7 @@ __global__ __launch_bounds__(64 * EMB_LANES) void embedding_swish_bwd_kernel(con
     }
 }
 
-// ---- Philox4x32-10 (Salmon et al. 2011), counter = (element group, launch offset), key = seed ----
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t seed, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
+// Philox4x32-10 and the draw conventions: philox.h (shared with poe.hip, which draws its own noise)
 // mode 0: standard normal (Box-Muller on pairs), mode 1: Bernoulli(keep) in {0,1}
 __global__ __launch_bounds__(256) void philox_fill_kernel(float *out, size_t n, uint64_t seed,
                                                           const uint64_t *counter, int mode, float keep,
@@ -132,11 +111,8 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(float *out, size_t n, 
         philox4x32_10(gidx, launch, seed, r);
         float v[4];
         if (mode == 0) {
-            const float r0 = sqrtf(-2.0f * logf(u01(r[0]))), r1 = sqrtf(-2.0f * logf(u01(r[2])));
-            float s0, c0, s1, c1;
-            sincosf(6.2831853071795864f * u01(r[1]), &s0, &c0);
-            sincosf(6.2831853071795864f * u01(r[3]), &s1, &c1);
-            v[0] = r0 * c0; v[1] = r0 * s0; v[2] = r1 * c1; v[3] = r1 * s1;
+            box_muller(r[0], r[1], v[0], v[1]);
+            box_muller(r[2], r[3], v[2], v[3]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = u01(r[q]) < keep ? 1.f : 0.f;

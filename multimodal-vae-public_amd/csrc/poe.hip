@@ -10,6 +10,7 @@
 // mu/logvar is fetched once from L1/L2.  The [M,B,D] expert stack of the reference (torch.cat
 // per expert) is never materialised; the N(0,1) prior is a constant.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -21,6 +22,9 @@ struct PoeArgs {
     mvae_experts_t ex;
     int ld, E, T, B, D, variant;      // variant: MVAE_POE_VARIANT_A / _B (the NO_PRIOR bit is split off into no_prior)
     int no_prior;
+    // draw mode (mvae_poe_fwd_draw): eps is generated here -- element o of the Philox stream (seed, *counter +
+    // counter_offset), the values mvae_philox_fill would have written -- and stored to `noise` for the backward
+    uint64_t seed; const uint64_t *counter; uint64_t counter_offset; int draw;
 };
 
 // precision of one expert: 1 / (exp(lv) + eps [+ eps])
@@ -31,7 +35,7 @@ __device__ __forceinline__ float poe_precision(float lv, int variant) {
 }
 
 __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const uint32_t *masks,
-                                                              const float *noise, float *mu, float *logvar,
+                                                              float *noise, float *mu, float *logvar,
                                                               float *z, float *kl) {
     // per thread: the precision T_e and mu_e * T_e of every expert at this (row, latent) -- computed ONCE and
     // reused by all the terms that contain the expert (celeba19: 21 terms x 21 experts would otherwise
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
     // the N(0,1) prior: mu = 0, logvar = 0 (MVAE_POE_NO_PRIOR: the caller's experts are the whole stack)
     const float t0 = a.no_prior ? 0.f : poe_precision(0.f, a.variant);
     for (int t = 0; t < a.T; ++t) klacc[t * POE_THREADS] = 0.f;
+    const uint64_t launch = a.draw ? *a.counter + a.counter_offset : 0;
     for (int d = lane; d < a.D; d += 64) {
         const size_t oe = (size_t)b * a.ld + d;
 #pragma unroll 4
@@ -67,7 +72,13 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
             const size_t o = ((size_t)t * a.B + b) * a.D + d;
             mu[o] = pmu;
             logvar[o] = plv;
-            if (z) z[o] = noise ? noise[o] * expf(0.5f * plv) + pmu : pmu;
+            if (a.draw) {
+                const float eps = philox_normal_at(o, launch, a.seed);
+                noise[o] = eps;
+                z[o] = eps * expf(0.5f * plv) + pmu;
+            } else if (z) {
+                z[o] = noise ? noise[o] * expf(0.5f * plv) + pmu : pmu;
+            }
             klacc[t * POE_THREADS] += 1.0f + plv - pmu * pmu - expf(plv);
         }
     }
@@ -204,10 +215,32 @@ MVAE_EXPORT int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E, const
     PoeArgs a;
     a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
     a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
+    a.seed = 0; a.counter = nullptr; a.counter_offset = 0; a.draw = 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = ((size_t)E * 2 + T) * POE_THREADS * sizeof(float);
     hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
-                       masks_dev, noise, mu, logvar, z, kl);
+                       masks_dev, const_cast<float *>(noise), mu, logvar, z, kl);
+    return mvae_launch_status();
+}
+
+// mvae_poe_fwd that DRAWS its reparameterisation noise: eps[T,B,D] = the standard normals mvae_philox_fill(seed,
+// *counter_dev + counter_offset) would write, generated inside the launch and stored to `noise_out` (the backward
+// reads it).  One launch less at the head of a fused step.
+MVAE_EXPORT int mvae_poe_fwd_draw(const mvae_experts_t *experts, int ld, int E, const uint32_t *masks_dev, int T,
+                                  float *noise_out, uint64_t seed, const uint64_t *counter_dev,
+                                  uint64_t counter_offset, float *mu, float *logvar, float *z, float *kl, int B,
+                                  int D, int variant, mvae_stream_t stream) {
+    if (!poe_args_ok(experts, ld, E, T, B, D, variant) || !masks_dev || !mu || !logvar || !z || !noise_out ||
+        !counter_dev)
+        return MVAE_ERR_ARG;
+    PoeArgs a;
+    a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
+    a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
+    a.seed = seed; a.counter = counter_dev; a.counter_offset = counter_offset; a.draw = 1;
+    const int rows = POE_THREADS / 64;
+    const size_t lds_bytes = ((size_t)E * 2 + T) * POE_THREADS * sizeof(float);
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
+                       masks_dev, noise_out, mu, logvar, z, kl);
     return mvae_launch_status();
 }
 
@@ -225,6 +258,7 @@ MVAE_EXPORT int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E, const
     PoeArgs a;
     a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
     a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
+    a.seed = 0; a.counter = nullptr; a.counter_offset = 0; a.draw = 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
     PoeDzMap none = {};
@@ -253,6 +287,7 @@ MVAE_EXPORT int mvae_poe_bwd_split(const mvae_experts_t *experts, int ld, int E,
     PoeArgs a;
     a.ex = *experts; a.ld = ld; a.E = E; a.T = T; a.B = B; a.D = D;
     a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
+    a.seed = 0; a.counter = nullptr; a.counter_offset = 0; a.draw = 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
     hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,

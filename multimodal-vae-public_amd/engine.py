@@ -142,6 +142,8 @@ class _StepBase(object):
         # with two branches in flight the kernels already fill the CUs; a fork per LAYER was 30 %
         # slower (every fork is a cross-queue signal).
         self.batch_wgrad = os.environ.get('MVAE_BATCH_WGRAD', '1') != '0'
+        self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
+        self._draw_in_poe = False
         self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
         self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
         self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 3 else None
@@ -268,10 +270,14 @@ class _StepBase(object):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         bns = [m for m in self.model.modules() if isinstance(m, L._BatchNormMixin)]
+        in_graph = comm is not None and getattr(comm, 'in_graph', False)
         with torch.cuda.stream(side):
             for it in range(warmup):
                 before = [m._nbt_pending for m in bns]
-                self._single_gpu_step(optimizer)
+                if in_graph:
+                    self._dp_step(optimizer)       # with the real collectives: RCCL sets its connections up OUTSIDE the capture
+                else:
+                    self._single_gpu_step(optimizer)
                 # graph replays skip the host code that counts BatchNorm calls: remember the
                 # per-step increments of num_batches_tracked and re-apply them in replay()
                 self._bn_inc = [(m, m._nbt_pending - b) for m, b in zip(bns, before)]
@@ -282,6 +288,15 @@ class _StepBase(object):
             with torch.cuda.graph(g):
                 self._single_gpu_step(optimizer)
             self._graphs = (g,)
+        elif in_graph:
+            # data parallel over the library's communicator (mvae_comm_*): launch / wait are stream + event operations
+            # and one RCCL enqueue -- the WHOLE step is one graph: forward, backward, the bucket all-reduces on the
+            # communicator's stream (forked from / joined into this one), per-bucket Adam, the counter launch
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._dp_step(optimizer)
+            self._graphs = (g,)
+            self._optimizer = optimizer
         else:
             # data parallel: one graph per gradient bucket (A = forward + decoder backward, then one or two
             # groups of encoder backward); the bucket all-reduces are issued between the replays, outside any
@@ -324,6 +339,32 @@ class _StepBase(object):
             optimizer.step()
         self._adam_counter = None
 
+    def _dp_step(self, optimizer):
+        """One data-parallel step as a plain launch sequence (capturable when the communicator is): bucket k's
+        all-reduce goes out the moment its gradients are final and runs behind the remaining backward; Adam follows
+        bucket by bucket (parallel.DataParallel.finish)."""
+        comm = self._comm
+        self._adam_counter = None
+        try:
+            self._body_a()
+            if self.n_buckets > 1:
+                comm.launch(0)
+            for k, part in enumerate(self._phases_b()):
+                part()
+                comm.launch(k + 1 if self.n_buckets > 1 else 0)
+        finally:
+            self._step_end()
+        comm.finish(optimizer)
+
+    def _poe_forward(self, mus, lvs, mu, lv, z, kl):
+        """PoE + reparameterise + KL for all the step's terms; eps either sits in ``self.noise`` (set_noise /
+        philox_fill) or is drawn by the launch itself into ``self.noise`` (same Philox stream, offset 0)."""
+        if self._draw_in_poe:
+            K.poe_fwd_draw(mus, lvs, self.masks_dev, self.noise, self.seed, self.counter, 0, mu, lv, z, kl,
+                           self.model.POE_VARIANT)
+        else:
+            K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, self.model.POE_VARIANT)
+
     def _early_counter(self):
         """Called at the end of the side stream's encoder forward (the shorter of the two encoder branches)."""
         if getattr(self, '_adam_counter', None) is not None:
@@ -344,8 +385,8 @@ class _StepBase(object):
         self.static_image.copy_(image, non_blocking=True)
         self.static_label.copy_(label, non_blocking=True)
         self.set_coefficients(annealing_factor)
-        if self._comm is None:
-            self._graphs[0].replay()
+        if self._comm is None or getattr(self._comm, 'in_graph', False):
+            self._graphs[0].replay()         # single GPU, or data parallel with the collectives inside the graph
         else:
             # graph 0 = phase A (decoder gradients final), graphs 1.. = the encoder groups: bucket k's all-reduce
             # runs behind the next graph / the Adam launches.  With ONE bucket (a model without encoder ranges)
@@ -510,6 +551,7 @@ class BimodalStep(_StepBase):
     def set_noise(self, noise):
         """Parity mode: ``noise`` = {'eps': [3 x [B,D]], 'mask': [3 x [B,512] or None]} in the
         REFERENCE's call order (joint, image, label), e.g. oracle.steps.draw_bimodal_noise."""
+        self._draw_in_poe = False
         for t in range(self.T):
             self.noise[t].copy_(noise['eps'][self.ref_order[t]].to(self.dev, non_blocking=True))
         if self.has_dropout:
@@ -517,8 +559,12 @@ class BimodalStep(_StepBase):
             self.drop_masks[1].copy_(noise['mask'][1].to(self.dev))
 
     def draw_noise(self):
-        # launch indices counter + 0 / + 1; the counter itself advances once per step (phase A's bookkeeping)
-        K.philox_fill(self.noise, self.seed, self.counter, 0)
+        # launch indices counter + 0 / + 1; the counter itself advances once per step (phase A's bookkeeping).
+        # eps is drawn INSIDE the PoE launch (mvae_poe_fwd_draw: same values, one launch less at the head of the
+        # step; MVAE_POE_DRAW=0: a philox_fill launch); the Dropout masks are needed before it and keep theirs
+        self._draw_in_poe = self.poe_draw
+        if not self.poe_draw:
+            K.philox_fill(self.noise, self.seed, self.counter, 0)
         if self.has_dropout:
             K.philox_fill(self.drop_masks, self.seed ^ 0x9E3779B97F4A7C15, self.counter, 1, keep_prob=KEEP)
 
@@ -558,7 +604,7 @@ class BimodalStep(_StepBase):
         lv = torch.empty_like(mu)
         z = torch.empty_like(mu)
         kl = torch.empty(T, B, dtype=torch.float32, device=self.dev)
-        K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, m.POE_VARIANT)
+        self._poe_forward(mus, lvs, mu, lv, z, kl)
         self.last_latents = (mu, lv, z)
         i0, ni = self.img_terms
         l0, nl = self.lbl_terms
@@ -883,6 +929,7 @@ class Celeba19Step(_StepBase):
 
     def set_noise(self, noise):
         """``noise`` in the reference's term order (oracle.steps.draw_celeba19_noise)."""
+        self._draw_in_poe = False
         for t in range(self.T):
             self.noise[t].copy_(noise['eps'][t].to(self.dev, non_blocking=True))
         img_terms = [0, 1] + [2 + N_ATTRS + j for j in range(self.M)]
@@ -894,7 +941,9 @@ class Celeba19Step(_StepBase):
                 self.drop_masks[k].fill_(1.0)      # expert masked out of the PoE: value irrelevant
 
     def draw_noise(self):
-        K.philox_fill(self.noise, self.seed, self.counter, 0)
+        self._draw_in_poe = self.poe_draw
+        if not self.poe_draw:
+            K.philox_fill(self.noise, self.seed, self.counter, 0)
         K.philox_fill(self.drop_masks, self.seed ^ 0x9E3779B97F4A7C15, self.counter, 1, keep_prob=KEEP)
 
     def step(self, image, attrs, annealing_factor, noise=None, combos=None):
@@ -947,7 +996,7 @@ class Celeba19Step(_StepBase):
         mu = torch.empty(T, B, D, dtype=torch.float32, device=dev)
         lv = torch.empty_like(mu); z = torch.empty_like(mu)
         kl = torch.empty(T, B, dtype=torch.float32, device=dev)
-        K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, m.POE_VARIANT)
+        self._poe_forward(mus, lvs, mu, lv, z, kl)
         self.last_latents = (mu, lv, z)
         t_s = 2 + N_ATTRS
         # ---- attribute decoders (side stream): gather the z rows each one needs, one pass per

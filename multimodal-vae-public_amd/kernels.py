@@ -495,6 +495,18 @@ def poe_fwd(mus, lvs, masks_dev, noise, mu, logvar, z, kl, variant):
                                   _stream()), 'mvae_poe_fwd')
 
 
+def poe_fwd_draw(mus, lvs, masks_dev, noise_out, seed, counter_dev, counter_offset, mu, logvar, z, kl, variant):
+    """``poe_fwd`` drawing its own eps: the values ``philox_fill(noise_out, seed, counter_dev, counter_offset)`` would
+    have written, generated in the launch and stored to ``noise_out`` for the backward."""
+    ld = _expert_ld(mus, lvs)
+    _need_gpu(masks_dev, noise_out, counter_dev, mu, logvar, z, kl); _f32c(noise_out, mu, logvar, z, kl)
+    T, B, D = mu.shape
+    ex = _experts(mus, lvs)
+    check(_lib.lib().mvae_poe_fwd_draw(ctypes.byref(ex), ld, len(mus), _ptr(masks_dev), T, _ptr(noise_out), seed,
+                                       _ptr(counter_dev), int(counter_offset), _ptr(mu), _ptr(logvar), _ptr(z),
+                                       _ptr(kl), B, D, _lib.POE_VARIANT[variant], _stream()), 'mvae_poe_fwd_draw')
+
+
 def poe_bwd(mus, lvs, masks_dev, noise, mu, logvar, dz, dmu, dlogvar, dkl, g_mus, g_lvs, variant,
             dkl_per_term=False):
     """dkl: [T,B] row gradients of the KL output, or with dkl_per_term a [T] table (beta/B)."""

@@ -21,7 +21,23 @@ for.  Design for MI355X rather than a per-parameter DDP hook storm:
 
 ``GradBuckets`` is backend-agnostic (it only needs a flat tensor), which is how the gloo CPU
 tests exercise the N > 1 logic without GPUs.
+
+Two transports for the bucket all-reduces:
+
+  * ``RcclComm`` + ``RcclBuckets`` (default on GPUs, ``MVAE_COMM=rccl``): the library's own communicator behind
+    the C ABI (``mvae_comm_*``, csrc/comm.hip -- what a host that is not PyTorch would call).  Enqueue-only stream /
+    event operations + one RCCL enqueue, so the engine captures the WHOLE data-parallel step -- forward, backward,
+    the bucket all-reduces on the communicator's stream, per-bucket Adam -- into ONE hipGraph: no host round-trip
+    between buckets (the three-graph path cost MNIST +25 % at world size 1).  ``torch.distributed`` is then only
+    the rendezvous that carries the 128-byte unique id.
+  * ``GradBuckets`` over ``torch.distributed`` (``MVAE_COMM=torch``; always for gloo): ``async_op`` all-reduces
+    issued between three captured graphs.
 """
+import ctypes
+import os
+import sys
+
+import torch
 import torch.distributed as dist
 
 
@@ -60,6 +76,129 @@ class GradBuckets(object):
                 work.wait()
 
 
+class RcclComm(object):
+    """The library's RCCL communicator (``mvae_comm_*``): one per process, on the current device."""
+
+    def __init__(self, rank, world, unique_id, device_index):
+        from . import _lib
+        self._lib = _lib.lib()
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.mvae_comm_init(ctypes.byref(h), unique_id, len(unique_id), int(rank), int(world),
+                                            int(device_index)), 'mvae_comm_init')
+        self._h = h
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def bind_torch_rccl():
+        """Point the C side at the librccl.so this process's torch already loaded: one RCCL copy per process."""
+        from . import _lib
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        if os.path.exists(path) and not os.environ.get('MVAE_RCCL_LIB'):
+            _lib.lib().mvae_comm_use_library(path.encode())      # refused (harmlessly) once a library is bound
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        """Collective over ``group``: rank 0 makes the unique id, torch.distributed carries it to the peers."""
+        from . import _lib
+        cls.bind_torch_rccl()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+            _lib.check(_lib.lib().mvae_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'mvae_comm_unique_id')
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(device)
+        dist.broadcast(ident, src=0, group=group)
+        raw = bytes(ident.cpu().tolist())
+        torch.cuda.synchronize(device)
+        return cls(rank, world, (ctypes.c_ubyte * len(raw)).from_buffer_copy(raw), device.index)
+
+    @property
+    def rccl_version(self):
+        v = self._lib.mvae_comm_rccl_version()
+        return '%d.%d.%d' % (v // 10000, (v // 100) % 100, v % 100) if v > 0 else None
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (what, rc, (self._lib.mvae_comm_last_error(self._h) or b'').decode()))
+
+    def allreduce_async(self, t):
+        """In-place sum of the contiguous fp32 tensor ``t`` over the ranks, ordered after the current stream's work,
+        on the communicator's stream.  Returns the ticket for ``wait``."""
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError('RcclComm.allreduce_async wants a contiguous fp32 GPU tensor')
+        ticket = ctypes.c_int(-1)
+        self._check(self._lib.mvae_comm_allreduce_async(self._h, ctypes.c_void_p(t.data_ptr()), t.numel(),
+                                                        self._stream(), ctypes.byref(ticket)), 'mvae_comm_allreduce_async')
+        return ticket.value
+
+    def wait(self, ticket=-1):
+        """The current stream waits for the collective behind ``ticket`` (-1: all issued so far)."""
+        self._check(self._lib.mvae_comm_wait(self._h, int(ticket), self._stream()), 'mvae_comm_wait')
+
+    def broadcast(self, t, root=0):
+        if not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError('RcclComm.broadcast wants a contiguous GPU tensor')
+        self._check(self._lib.mvae_comm_broadcast(self._h, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                                  int(root), self._stream()), 'mvae_comm_broadcast')
+
+    def self_check(self, device):
+        """An all-reduce whose answer is known, eagerly and then from a captured hipGraph -- the two ways the engine
+        issues collectives.  Raises if either gives a wrong sum."""
+        expect = float(self.world * (self.world + 1) // 2)
+        x = torch.full((1024,), float(self.rank + 1), dtype=torch.float32, device=device)
+        self.wait(self.allreduce_async(x))
+        torch.cuda.synchronize(device)
+        if not bool((x == expect).all().item()):
+            raise RuntimeError('eager all-reduce self-check: got %r, expected %r' % (x[0].item(), expect))
+        y = torch.empty_like(x)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y.fill_(float(self.rank + 1))
+                self.wait(self.allreduce_async(y))
+            for _ in range(2):
+                g.replay()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        if not bool((y == expect).all().item()):
+            raise RuntimeError('captured all-reduce self-check: got %r, expected %r' % (y[0].item(), expect))
+
+    def destroy(self):
+        if self._h is not None:
+            self._lib.mvae_comm_destroy(self._h)
+            self._h = None
+
+
+class RcclBuckets(object):
+    """``GradBuckets`` over the library's communicator: launch(k) / wait(k) are enqueue-only on the current
+    stream (capturable)."""
+    in_graph = True
+
+    def __init__(self, flat_grad, ranges, comm):
+        GradBuckets.__init__(self, flat_grad, ranges, group=None)      # range checks
+        self.comm = comm
+        self.pending = {}
+
+    def launch(self, k):
+        lo, hi = self.ranges[k]
+        if k in self.pending:
+            raise RuntimeError('bucket %d launched twice in one step' % k)
+        self.pending[k] = self.comm.allreduce_async(self.flat[lo:hi])
+
+    def wait(self, k=None):
+        keys = sorted(self.pending) if k is None else [k]
+        for key in keys:
+            ticket = self.pending.pop(key, None)
+            if ticket is not None:
+                self.comm.wait(ticket)
+
+
 class DataParallel(object):
     """Wrap a fused step engine: ``dp = DataParallel(model, engine)``.  Every
     ``engine.forward_backward`` then launches bucket k's all-reduce the moment the last weight gradient of
@@ -67,7 +206,7 @@ class DataParallel(object):
     reductions land (``FusedAdam(..., grad_scale=dp.grad_scale)``): the update of bucket k overlaps the
     all-reduce of bucket k+1, and the last bucket -- the image encoder's first layers -- is small."""
 
-    def __init__(self, model, engine, group=None):
+    def __init__(self, model, engine, group=None, transport=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.world = dist.get_world_size(group)
@@ -77,7 +216,22 @@ class DataParallel(object):
         for b in model.buffers():
             dist.broadcast(b, src=0, group=group)
         ranges = bucket_ranges(model, arena)
-        self.buckets = GradBuckets(arena.grad, ranges, group=group)
+        self.comm, self.transport = None, 'torch.distributed (%s)' % dist.get_backend(group)
+        want = os.environ.get('MVAE_COMM', 'rccl' if transport is None else transport)
+        if want == 'rccl' and dist.get_backend(group) == 'nccl' and arena.flat.is_cuda:
+            try:
+                self.comm = RcclComm.from_process_group(arena.flat.device, group)
+                self.comm.self_check(arena.flat.device)
+                self.transport = 'mvae_comm (RCCL %s, collectives inside the step graph)' % self.comm.rccl_version
+            except Exception as e:       # an error (not a hang) here is recoverable: the three-graph path needs nothing of it
+                sys.stderr.write('[mvae parallel] C-ABI RCCL communicator unavailable (%s: %s); falling back to '
+                                 'torch.distributed all-reduces between three graphs\n' % (type(e).__name__, e))
+                self.comm = None
+                self.transport += ' [fallback: %s]' % type(e).__name__
+        if self.comm is not None:
+            self.buckets = RcclBuckets(arena.grad, ranges, self.comm)
+        else:
+            self.buckets = GradBuckets(arena.grad, ranges, group=group)
         engine.configure_buckets(len(ranges))
         engine.on_bucket_ready = self.buckets.launch
         self.engine = engine
@@ -85,6 +239,11 @@ class DataParallel(object):
     @property
     def n_buckets(self):
         return len(self.buckets.ranges)
+
+    @property
+    def in_graph(self):
+        """True: launch / wait / finish are enqueue-only and may be captured with the step."""
+        return getattr(self.buckets, 'in_graph', False)
 
     def launch(self, k):
         """Start the all-reduce of bucket k (called by the engine between captured graphs)."""

@@ -38,7 +38,8 @@ def nccl_world1():
 
 
 @pytest.mark.parametrize('kind,batch', [('mnist', 32), ('celeba', 8)])
-def test_dp_three_graph_path_matches_single_graph(nccl_world1, kind, batch):
+def test_dp_three_graph_path_matches_single_graph(nccl_world1, kind, batch, monkeypatch):
+    monkeypatch.setenv('MVAE_COMM', 'torch')      # the torch.distributed transport: one graph per bucket
     lam = 50.0 if kind == 'mnist' else 10.0
     runs = []
     for use_dp in (False, True):
@@ -62,8 +63,10 @@ def test_dp_three_graph_path_matches_single_graph(nccl_world1, kind, batch):
     assert_close(runs[1][1], runs[0][1], 'parameters dp vs single', tol=1e-6)
 
 
-def test_dp_eager_hooks(nccl_world1):
+@pytest.mark.parametrize('transport', ['torch', 'rccl'])
+def test_dp_eager_hooks(nccl_world1, transport, monkeypatch):
     """Eager mode: the engine's bucket hooks launch the all-reduces, wait() fences them."""
+    monkeypatch.setenv('MVAE_COMM', transport)
     _, model, d = build_pair('mnist', weight_seed=43)
     eng = BimodalStep(model, 16, 1.0, 50.0, seed=3)
     opt = FusedAdam(model.parameters(), lr=1e-3)

@@ -1,7 +1,7 @@
 """GPU parity of the path bench.py TIMES: ``capture()`` + ``replay()`` -- hipGraph, two streams, device Philox
 noise, early Adam counter, batched weight gradients / weight repacks -- against the oracle, at BASELINE.json's
-per-GPU batch sizes, for all four experiments; and the same for the data-parallel launch path (one graph per
-gradient bucket, RCCL all-reduces between them, per-bucket Adam) at world size 1.
+per-GPU batch sizes, for all four experiments; and the same for the data-parallel launch path (ONE graph holding
+the step, the bucket all-reduces over the library's RCCL communicator and the per-bucket Adam) at world size 1.
 
 How: snapshot the weights -> capture -> ONE replay -> read back what the graph used and produced at their fixed
 addresses (``eng.noise``, ``eng.drop_masks``, the ELBO vector, ``model.arena.grad``, BatchNorm running statistics,
@@ -117,7 +117,7 @@ def _replay_once(kind, batch, input_seed, use_dp, combos):
     return oracle, model, eng, d, image, label, w0.cpu(), elbo.detach().cpu().clone()
 
 
-@pytest.mark.parametrize('use_dp', [False, True], ids=['single_graph', 'dp_world1'])
+@pytest.mark.parametrize('use_dp', [False, True], ids=['single_graph', 'dp_world1_one_graph'])
 @pytest.mark.parametrize('kind,batch', [('mnist', 512), ('fashionmnist', 1024), ('celeba', 256), ('celeba19', 256)])
 def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch, use_dp):
     combos = sample_subsets(np.random.RandomState(2025), 19, 1) if kind == 'celeba19' else None
@@ -129,8 +129,8 @@ def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch
         redraws += 1
     else:
         pytest.fail('four consecutive draws with an exactly-zero logit')
-    if use_dp:
-        assert len(eng._graphs) == (2 if kind == 'mnist' else 3)
+    if use_dp:      # default transport: the library's communicator, collectives inside ONE graph (tests/test_comm_gpu.py)
+        assert len(eng._graphs) == 1
     noise, terms = _noise_in_reference_order(kind, eng, combos)
     if kind == 'celeba19':
         total, elbos, _ = OS.celeba19_step(oracle, image, label, terms, noise, 1.0, LAM[kind], BETA)
@@ -154,7 +154,7 @@ def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch
     check_bn_vs(model, oracle.state_dict())
     _check_adam(kind, model, oracle, w0, g_hip, w1)
     print('%s B=%d %s: replayed step vs oracle, worst gradient rel err %.2e, %d input re-draw(s) for an exact-zero '
-          'logit' % (kind, batch, 'dp(3 graphs)' if use_dp else 'one graph', worst, redraws))
+          'logit' % (kind, batch, 'dp (collectives in the graph)' if use_dp else 'one graph', worst, redraws))
 
 
 def test_replay_noise_is_fresh_every_step_and_standard_normal():
