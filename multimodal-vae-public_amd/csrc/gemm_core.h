@@ -594,10 +594,6 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     // so ONE tile in flight in registers is enough -- the second register stage made the 128 x 128 kernels
     // spill (256 VGPRs)
     constexpr bool DEEP = WM * WN < 2;
-#ifndef MVAE_RING4
-#define MVAE_RING4 1
-#endif
-    constexpr bool RING4 = DEEP && NT > NTHREADS && MVAE_RING4;     // see the phased loop below
     auto no_hook = [](int, int) {};
     // Interleaved main loop (every thread a mover, every k-tile full): the next tile's global loads are issued
     // slice by slice right after the first MFMA groups of the current tile and its LDS stores after the last
@@ -787,38 +783,6 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                     if (mover && more) STORE(fullc, (s + 1) & 1, pr0, qr0);
                     __syncthreads();
                 }
-                return;
-            }
-            if constexpr (RING4) {
-                // k-grouped blocks (KW k-groups of one-tile waves, 512 threads, ONE block per CU): a k-step is 8-16
-                // MFMAs per wave (0.2-0.4 us) against a ~1-2 us global-load round trip, and nothing else runs on
-                // the CU -- with two tiles in flight every k-step waited most of a round trip for its successor's
-                // tile (the 1024 x 512 x 512 Linear: 8 k-steps, ~1 us each, 1.7 us of them MFMAs).  FOUR tiles in
-                // flight in registers (tile t in set t % 4, staged into LDS buffer t & 1 one step ahead): a load has
-                // three k-steps to land.  The sub-steps are guarded, not exited from: one loop exit (a break in
-                // the middle made hipcc ping-pong the accumulators between two register sets).
-                typename P::Regs pr2, pr3;
-                typename Q::Regs qr2, qr3;
-                if (mover && nsteps > 0) LOAD(fullc, kbeg, pr0, qr0);
-                if (mover && nsteps > 1) LOAD(fullc, kbeg + BKK, pr1, qr1);
-                if (mover && nsteps > 2) LOAD(fullc, kbeg + 2 * BKK, pr2, qr2);
-                if (mover && nsteps > 3) LOAD(fullc, kbeg + 3 * BKK, pr3, qr3);
-                if (mover && nsteps > 0) STORE(fullc, 0, pr0, qr0);
-                __syncthreads();
-#define MVAE_RING_STEP(U, PA, QA, PB, QB)                                                                   \
-                    if (s + U < nsteps) {      /* tile s+U sits in LDS buffer U & 1; set U is free again */    \
-                        if (mover && s + U + 4 < nsteps) LOAD(fullc, kbeg + (s + U + 4) * BKK, PA, QA);        \
-                        compute(U & 1, no_hook);                                                               \
-                        if (mover && s + U + 1 < nsteps) STORE(fullc, (U + 1) & 1, PB, QB);                    \
-                        __syncthreads();                                                                       \
-                    }
-                for (int s = 0; s < nsteps; s += 4) {
-                    MVAE_RING_STEP(0, pr0, qr0, pr1, qr1)
-                    MVAE_RING_STEP(1, pr1, qr1, pr2, qr2)
-                    MVAE_RING_STEP(2, pr2, qr2, pr3, qr3)
-                    MVAE_RING_STEP(3, pr3, qr3, pr0, qr0)
-                }
-#undef MVAE_RING_STEP
                 return;
             }
             // one tile per wave -- prologue: tiles 0 and 1 in flight, tile 0 staged

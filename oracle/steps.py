@@ -101,9 +101,11 @@ def sample_combinations(pool, size=1, rng=np.random):
 # steps
 # ----------------------------------------------------------------------------
 def bimodal_step(model, kind, image, label, noise, lambda_image, lambda_label,
-                 annealing_factor):
+                 annealing_factor, return_recon=False):
     """One train-step loss (no optimizer): returns (total, [joint, image, label] terms,
-    [(mu, logvar, z)] per call)."""
+    [(mu, logvar, z)] per call); with ``return_recon`` also the reconstructions that enter a
+    loss, [(image logits, label logits)] per call (None where the reference passes None,
+    mnist/train.py:208,211)."""
     elbo = OF.elbo_loss_attrs if kind == 'celeba' else OF.elbo_loss_label
     ri1, rl1, mu1, lv1, z1 = model(image, label, eps=noise['eps'][0], dropout_mask=noise['mask'][0])
     ri2, rl2, mu2, lv2, z2 = model(image, None, eps=noise['eps'][1], dropout_mask=noise['mask'][1])
@@ -112,7 +114,10 @@ def bimodal_step(model, kind, image, label, noise, lambda_image, lambda_label,
     img = elbo(ri2, image, None, None, mu2, lv2, lambda_image, lambda_label, annealing_factor)
     lbl = elbo(None, None, rl3, label, mu3, lv3, lambda_image, lambda_label, annealing_factor)
     total = joint + img + lbl
-    return total, [joint, img, lbl], [(mu1, lv1, z1), (mu2, lv2, z2), (mu3, lv3, z3)]
+    latents = [(mu1, lv1, z1), (mu2, lv2, z2), (mu3, lv3, z3)]
+    if return_recon:
+        return total, [joint, img, lbl], latents, [(ri1, rl1), (ri2, None), (None, rl3)]
+    return total, [joint, img, lbl], latents
 
 
 def celeba19_step(model, image, attrs2d, terms, noise, lambda_image, lambda_attrs,

@@ -122,24 +122,33 @@ def _replay_once(kind, batch, input_seed, use_dp, combos):
 def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch, use_dp):
     combos = sample_subsets(np.random.RandomState(2025), 19, 1) if kind == 'celeba19' else None
     redraws = 0
-    for attempt in range(4):
+    for attempt in range(6):
         oracle, model, eng, d, image, label, w0, elbo = _replay_once(kind, batch, 191 + attempt, use_dp, combos)
-        if kind == 'celeba19' or not hits_bce_jump(eng):
+        noise, terms = _noise_in_reference_order(kind, eng, combos)
+        if kind == 'celeba19':
+            total, elbos, _ = OS.celeba19_step(oracle, image, label, terms, noise, 1.0, LAM[kind], BETA)
+            T = len(terms)
+            got = elbo
+            break
+        total, elbos, _, recon = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, LAM[kind], BETA,
+                                                 return_recon=True)
+        T = 3
+        got = eng.terms_in_reference_order(elbo)
+        # the hand-written BCE's gradient JUMPS at a logit of exactly 0 (mnist/train.py:73-74): a
+        # logit that rounds to 0.0 on ONE side only -- here or in the oracle (tools/replay_probe.py found one on the
+        # oracle's side at CelebA B = 256) -- moves one d loss / d logit by lambda / 2B, which says nothing about the
+        # kernels: such draws are repeated with the next input seed, and counted
+        bce_logits = [r[0] for r in recon if r[0] is not None]
+        if kind == 'celeba':
+            bce_logits += [r[1] for r in recon if r[1] is not None]
+        oracle_zero = any(bool((x == 0).any()) for x in bce_logits)
+        if not (hits_bce_jump(eng) or oracle_zero):
             break
         redraws += 1
     else:
-        pytest.fail('four consecutive draws with an exactly-zero logit')
+        pytest.fail('six consecutive draws with an exactly-zero logit')
     if use_dp:      # default transport: the library's communicator, collectives inside ONE graph (tests/test_comm_gpu.py)
         assert len(eng._graphs) == 1
-    noise, terms = _noise_in_reference_order(kind, eng, combos)
-    if kind == 'celeba19':
-        total, elbos, _ = OS.celeba19_step(oracle, image, label, terms, noise, 1.0, LAM[kind], BETA)
-        T = len(terms)
-        got = elbo
-    else:
-        total, elbos, _ = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, LAM[kind], BETA)
-        T = 3
-        got = eng.terms_in_reference_order(elbo)
     total.backward()
     assert_close(got[:T], torch.stack(elbos).detach(), 'ELBO terms (replay)')
     assert_close(got[T], total.detach(), 'total (replay)')
