@@ -421,6 +421,38 @@ int mvae_resize_crop_u8_to_f32(const uint8_t *src, float *dst, int B, int H, int
 int mvae_u8_to_f32(const uint8_t *src, float *dst, size_t n, mvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * K16  The recurrent text stacks of the MultiMNIST MVAE: multimnist/model.py:145-235 --
+ *      TextEncoder: nn.Embedding(12, 200) -> nn.GRU(200, 200, 1, bidirectional) -> x[-1], directions summed ->
+ *      nn.Linear(200, 2D) (:162-179); TextDecoder: nn.Linear(D, 200) -> 4 steps of
+ *      swish(nn.Embedding) | z -> nn.GRU(200 + D, 200, 2, dropout=0.1) -> | z -> nn.Linear(200 + D, 12), greedy
+ *      arg-max feedback (:196-228).  The matrix products are mvae_linear_* launches with leading dimensions (the
+ *      torch.cat's of :222,226 are column ranges of one buffer); these are the remaining element kernels.
+ *   gru_cell_fwd  torch's gate order r | z | n in gi = x.W_ih^T + b_ih and gh = h.W_hh^T + b_hh ([B, 3H] each):
+ *                 r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) n + z h;
+ *                 gates [B, 4H] (r | z | n | gh_n, nullable) is what the backward needs.
+ *   gru_cell_bwd  dh' = dh_new (+ dh_extra, nullable) -> dgi, dgh [B, 3H] contiguous and dh_prev [B, H] = dh' * z
+ *                 (the caller adds dgh.W_hh with an accumulating mvae_linear_dgrad).
+ *   embedding_fwd / _bwd   nn.Embedding with an index stride (column t of text[B, 4]: stride 4) and an output
+ *                 leading dimension; flags: MVAE_ACT_SWISH (swish(embed(c)), :220), bwd also MVAE_ACCUMULATE.
+ *                 The backward adds the rows of a class in row order: deterministic.
+ *   copy2d        dst[r, :cols] (+)= src[r, :cols] (* mask[r, :cols] * scale): column ranges of the cat buffers, the
+ *                 inter-layer Dropout of nn.GRU (mask in {0,1}, scale 1 / 0.9) and its backward, the direction sum.
+ *   argmax_rows   first maximum per row (torch.max(F.log_softmax(c_out, dim=1), dim=1)[1], :211).
+ * ------------------------------------------------------------------------------------ */
+int mvae_gru_cell_fwd(const float *gi, int ldgi, const float *gh, int ldgh, const float *h_prev, int ldh,
+                      float *h_new, int ldo, float *gates /* nullable */, int B, int H, mvae_stream_t stream);
+int mvae_gru_cell_bwd(const float *dh_new, int lddh, const float *dh_extra /* nullable */, int ldde,
+                      const float *gates, const float *h_prev, int ldh, float *dgi, float *dgh, float *dh_prev,
+                      int B, int H, mvae_stream_t stream);
+int mvae_embedding_fwd(const int64_t *idx, int idx_stride, const float *w, float *out, int ldo, int R,
+                       int n_classes, int width, int flags, mvae_stream_t stream);
+int mvae_embedding_bwd(const int64_t *idx, int idx_stride, const float *w, const float *dout, int ldd, float *dw,
+                       int R, int n_classes, int width, int flags, mvae_stream_t stream);
+int mvae_copy2d(const float *src, int lds, float *dst, int ldd, const float *mask /* nullable */, int ldm,
+                float scale, int rows, int cols, int flags, mvae_stream_t stream);
+int mvae_argmax_rows(const float *x, int ldx, int64_t *out, int R, int K, mvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * C1  Gradient exchange of data-parallel replicas -- RCCL over xGMI.
  *     The reference has NO counterpart: it is single-process, single-device (no DataParallel, no
  *     torch.distributed anywhere; README.md:47 `CUDA_VISIBLE_DEVICES=0`).  What this replaces is what N

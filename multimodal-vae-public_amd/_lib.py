@@ -133,6 +133,13 @@ _SIGNATURES = {
     'mvae_scatter_sums': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'mvae_bce_elem_fwd': (c_int, [P, P, P, c_size_t, P]),
     'mvae_bce_elem_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
+    # K16: the recurrent text stacks of MultiMNIST
+    'mvae_gru_cell_fwd': (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, P]),
+    'mvae_gru_cell_bwd': (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, P, c_int, c_int, P]),
+    'mvae_embedding_fwd': (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'mvae_embedding_bwd': (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    'mvae_copy2d': (c_int, [P, c_int, P, c_int, P, c_int, c_float, c_int, c_int, c_int, P]),
+    'mvae_argmax_rows': (c_int, [P, c_int, P, c_int, c_int, P]),
     # C1: the gradient exchange (RCCL bound at run time)
     'mvae_comm_use_library': (c_int, [ctypes.c_char_p]),
     'mvae_comm_rccl_version': (c_int, []),

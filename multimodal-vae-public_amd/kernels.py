@@ -712,3 +712,72 @@ def bce_elem_bwd(logits, target, g, dlogits, dtarget=None):
     _need_gpu(logits, target, g, dlogits, dtarget); _f32c(logits, target, g, dlogits, dtarget)
     check(_lib.lib().mvae_bce_elem_bwd(_ptr(logits), _ptr(target), _ptr(g), _ptr(dlogits), _ptr(dtarget),
                                        logits.numel(), _stream()), 'mvae_bce_elem_bwd')
+
+
+# ---------------------------------------------------------------------------- GRU text stacks (MultiMNIST)
+def _rows(t, what, width=None):
+    """[rows, width] fp32 GPU view with unit column stride (a column range of a wider buffer is fine)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise RuntimeError('%s must be a float32 [rows, width] GPU view with unit column stride' % what)
+    if width is not None and t.shape[1] != width:
+        raise RuntimeError('%s: width %d, expected %d' % (what, t.shape[1], width))
+    return t
+
+
+def gru_cell_fwd(gi, gh, h_prev, h_new, gates=None):
+    B, H = _rows(h_prev, 'h_prev').shape
+    _rows(gi, 'gi', 3 * H); _rows(gh, 'gh', 3 * H); _rows(h_new, 'h_new', H)
+    if gates is not None:
+        _need_gpu(gates); _f32c(gates)
+    check(_lib.lib().mvae_gru_cell_fwd(_ptr(gi), gi.stride(0), _ptr(gh), gh.stride(0), _ptr(h_prev), h_prev.stride(0),
+                                       _ptr(h_new), h_new.stride(0), _ptr(gates), B, H, _stream()), 'mvae_gru_cell_fwd')
+
+
+def gru_cell_bwd(dh_new, dh_extra, gates, h_prev, dgi, dgh, dh_prev):
+    B, H = _rows(h_prev, 'h_prev').shape
+    _rows(dh_new, 'dh_new', H)
+    if dh_extra is not None:
+        _rows(dh_extra, 'dh_extra', H)
+    _need_gpu(gates, dgi, dgh, dh_prev); _f32c(gates, dgi, dgh, dh_prev)
+    check(_lib.lib().mvae_gru_cell_bwd(_ptr(dh_new), dh_new.stride(0), _ptr(dh_extra),
+                                       0 if dh_extra is None else dh_extra.stride(0), _ptr(gates), _ptr(h_prev),
+                                       h_prev.stride(0), _ptr(dgi), _ptr(dgh), _ptr(dh_prev), B, H, _stream()),
+          'mvae_gru_cell_bwd')
+
+
+def _idx64(idx):
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 1):
+        raise RuntimeError('embedding index must be a 1-D int64 GPU tensor (a column of text[B, L] is fine)')
+    return max(int(idx.stride(0)), 1)
+
+
+def embedding_fwd(idx, w, out, swish=False):
+    _need_gpu(w); _f32c(w)
+    R, width = _rows(out, 'out', w.shape[1]).shape
+    check(_lib.lib().mvae_embedding_fwd(_ptr(idx), _idx64(idx), _ptr(w), _ptr(out), out.stride(0), idx.numel(),
+                                        w.shape[0], width, ACT_SWISH if swish else 0, _stream()), 'mvae_embedding_fwd')
+
+
+def embedding_bwd(idx, w, dout, dw, swish=False, accumulate=False):
+    _need_gpu(w, dw); _f32c(w, dw)
+    _rows(dout, 'dout', w.shape[1])
+    flags = (ACT_SWISH if swish else 0) | (ACCUMULATE if accumulate else 0)
+    check(_lib.lib().mvae_embedding_bwd(_ptr(idx), _idx64(idx), _ptr(w), _ptr(dout), dout.stride(0), _ptr(dw),
+                                        idx.numel(), w.shape[0], w.shape[1], flags, _stream()), 'mvae_embedding_bwd')
+
+
+def copy2d(src, dst, mask=None, scale=1.0, accumulate=False):
+    rows, cols = _rows(src, 'src').shape
+    _rows(dst, 'dst', cols)
+    if mask is not None:
+        _rows(mask, 'mask', cols)
+    check(_lib.lib().mvae_copy2d(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), _ptr(mask),
+                                 0 if mask is None else mask.stride(0), float(scale), rows, cols,
+                                 ACCUMULATE if accumulate else 0, _stream()), 'mvae_copy2d')
+
+
+def argmax_rows(x, out):
+    R, K_ = _rows(x, 'x').shape
+    if not (out.is_cuda and out.dtype == torch.int64 and out.is_contiguous() and out.numel() == R):
+        raise RuntimeError('argmax_rows wants a contiguous int64 GPU output of one entry per row')
+    check(_lib.lib().mvae_argmax_rows(_ptr(x), x.stride(0), _ptr(out), R, K_, _stream()), 'mvae_argmax_rows')

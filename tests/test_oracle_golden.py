@@ -154,3 +154,32 @@ def test_eval_pass_matches_reference(golden_dir, exp):
         assert torch.equal(z, mu), 'eval-mode reparametrize returns mu'
         assert_close(ri[0].reshape(-1)[:256], fx['logits_image_0_%d' % c], 'eval image logits %d' % c, tol=1e-5)
         assert_close(rl, fx['logits_label_%d' % c], 'eval label logits %d' % c, tol=1e-5)
+
+
+def test_multimnist_text_oracle_reproduces_the_reference_golden(golden_dir):
+    """SURVEY 8f-4's GRU stacks: oracle/multimnist.py against the fixture captured from the imported
+    multimnist/model.py + train.py (tests/golden/make_multimnist_golden.py)."""
+    import numpy as np
+    from oracle import multimnist as OMM
+    fx, meta = load_golden(golden_dir, 'multimnist_text')
+    enc = OM.fill_parameters(OMM.TextEncoder(meta['n_latents']), meta['enc_seed']).train()
+    dec = OM.fill_parameters(OMM.TextDecoder(meta['n_latents']), meta['dec_seed']).train()
+    text = torch.from_numpy(fx['text'])
+    assert torch.equal(text, OMM.synthetic_text(meta['batch'], meta['text_seed']))
+    masks = [torch.from_numpy(fx['mask%d' % i]).float() for i in range(OMM.MAX_LENGTH)]
+    torch.manual_seed(meta['noise_seed'])
+    assert all(torch.equal(a, b) for a, b in zip(masks, OMM.draw_decoder_masks(meta['batch'])))
+    mu, logvar = enc(text)
+    words, fed = dec(mu + 0.5 * logvar, dropout_masks=masks)
+    loss = OMM.text_loss_rows(words, text).mean() + 0.1 * (mu.pow(2) + logvar.pow(2)).mean()
+    loss.backward()
+    assert_close(mu, fx['mu'], 'mu', tol=1e-5); assert_close(words, fx['words'], 'words', tol=1e-5)
+    assert np.array_equal(fed.numpy(), fx['fed'])
+    assert_close(loss.item(), fx['loss'], 'loss', tol=1e-5)
+    for prefix, mod in (('text_encoder', enc), ('text_decoder', dec)):
+        for name, p in mod.named_parameters():
+            ref = float(fx['gnorm/%s.%s' % (prefix, name)])
+            assert abs(p.grad.double().norm().item() - ref) <= 2e-5 * max(ref, 1e-30), name
+    dec.eval()
+    with torch.no_grad():
+        assert_close(dec((mu + 0.5 * logvar).detach())[0], fx['eval_words'], 'eval words', tol=1e-5)

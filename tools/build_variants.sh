@@ -13,6 +13,6 @@ while [ $# -ge 2 ]; do
     ( $HIPCC $FLAGS $extra -c conv.hip -o variants/$name/conv.o ) &
     wait
     $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip_tuning_$name.so variants/$name/linear.o variants/$name/conv.o \
-        norm.o poe.o loss.o misc.o reparam.o gather.o preprocess.o comm.o -ldl
+        norm.o poe.o loss.o misc.o reparam.o gather.o preprocess.o comm.o gru.o -ldl
     echo built libmvae_hip_tuning_$name.so
 done
