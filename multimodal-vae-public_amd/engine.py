@@ -143,6 +143,7 @@ class _StepBase(object):
         # slower (every fork is a cross-queue signal).
         self.batch_wgrad = os.environ.get('MVAE_BATCH_WGRAD', '1') != '0'
         self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
+        self.wgrad_on_side = os.environ.get('MVAE_WGRAD_SIDE', '1') != '0' and self.side is not None
         self._draw_in_poe = False
         self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
         self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
@@ -633,6 +634,11 @@ class BimodalStep(_StepBase):
                 else:
                     g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
                                             defer_input_grad=True, deferred=wl)
+                ev_lbl = None
+                if self.wgrad_on_side and self.side is not None and isinstance(wl, L.WgradBatch) \
+                        and self._comm is None and self.on_bucket_ready is None:
+                    ev_lbl = torch.cuda.Event()
+                    ev_lbl.record()              # this decoder's latent gradient is final: the PoE backward may start
                 self._launch_deferred(wl, self.wg_side)
             # ---- image branch (this stream)
             zi = z[i0:i0 + ni].reshape(ni * B, D)
@@ -657,8 +663,26 @@ class BimodalStep(_StepBase):
             else:
                 g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
                                         groups=ni, defer_input_grad=True, deferred=wi)
-            self._launch_deferred(wi, self.wg_main)     # decoder weight gradients run behind phase B
-            self._join()
+            if ev_lbl is not None and isinstance(wi, L.WgradBatch):
+                # The image side is the longer chain and the label side has slack (MNIST: ~225 vs ~150 us of kernels):
+                # the image decoder's weight-gradient batch -- nothing before the optimizer reads it -- goes to the
+                # SIDE stream behind the label decoder's, and this stream waits only for the label decoder's latent
+                # gradient (an event), not for the side stream's weight gradients.  MVAE_WGRAD_SIDE=0: both on their
+                # own stream and a full join here.
+                ev_img = torch.cuda.Event()
+                ev_img.record()
+                # the batch's gradient tensors were allocated on THIS stream and are read on the other one: they must
+                # stay referenced until the streams have joined, or the allocator hands their memory to this
+                # stream's next launches while the weight-gradient kernel is still queued
+                c['wgrad_on_side_keep'] = list(wi)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev_img)
+                    wi.flush()
+                torch.cuda.current_stream(self.dev).wait_event(ev_lbl)
+                c['events'] = (ev_lbl, ev_img)
+            else:
+                self._launch_deferred(wi, self.wg_main)     # decoder weight gradients run behind phase B
+                self._join()
             keep_dec = (logits_lbl, tape_dl, dlog_lbl, logits_img, tape_di, dlog_img)
         # ---- ELBO per term and total (mnist/train.py:57-58,214), the cleared dz and the step's Philox counter
         #      advance: one bookkeeping launch
