@@ -372,6 +372,14 @@ int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *e
                        const int64_t *step_dev, int64_t step_add, mvae_stream_t stream);
 int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
 int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
+/* One launch that puts a step's inputs where a captured graph reads them -- what `image.cuda()`, `text.cuda()`
+ * (mnist/train.py:188-190) and the per-step scalars (annealing factor :180-186) amount to for a replayed step:
+ * image_dst <- image_src (device, 16-byte aligned, a multiple of 4 floats), label_dst <- label_src (device, a multiple
+ * of 4 bytes), table_dst <- table_src_host: PINNED HOST memory (hipHostMalloc / torch pin_memory) read by the kernel
+ * itself.  Any of the three may be empty (size 0). */
+int mvae_ingest(const float *image_src, float *image_dst, size_t image_floats,
+                const void *label_src, void *label_dst, size_t label_bytes,
+                const void *table_src_host, void *table_dst, size_t table_bytes, mvae_stream_t stream);
 
 /* CelebA-19 term plumbing (celeba19/train.py:264-302, celeba19/model.py:56-60): gather the z blocks
  * a decoder needs, scatter-add the gradients back per term, and sum ELBO pieces by term table.

@@ -124,6 +124,7 @@ _SIGNATURES = {
                                    ctypes.c_int64, P]),
     'mvae_counter_add': (c_int, [P, ctypes.c_int64, P]),
     'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
+    'mvae_ingest': (c_int, [P, P, c_size_t, P, P, c_size_t, P, P, c_size_t, P]),
     'mvae_reparam_fwd': (c_int, [P, P, P, P, c_size_t, P]),
     'mvae_reparam_bwd': (c_int, [P, P, P, P, P, c_size_t, P]),
     'mvae_dropout_fanout_fwd': (c_int, [P, P, P, c_float, c_int, c_int, c_int, P]),

@@ -328,6 +328,38 @@ MVAE_EXPORT int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_strea
     return mvae_launch_status();
 }
 
+// One launch that brings a step's inputs to the fixed addresses a captured graph reads: the image batch (float4
+// copy), the label batch (32-bit words) and the per-step table block (loss coefficients, PoE masks, ...), whose
+// source is PINNED HOST memory read by the kernel itself (zero-copy over the host link: a few dozen words).  Three
+// runtime copy commands in front of every graph replay were ~15 us of a 325-us MNIST step.
+__global__ __launch_bounds__(256) void ingest_kernel(const float4 *img_src, float4 *img_dst, size_t n4,
+                                                     const uint32_t *lbl_src, uint32_t *lbl_dst, size_t lbl_words,
+                                                     const uint32_t *tbl_src, uint32_t *tbl_dst, size_t tbl_words) {
+    const size_t total = n4 + lbl_words + tbl_words;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (i < n4) img_dst[i] = img_src[i];
+        else if (i < n4 + lbl_words) lbl_dst[i - n4] = lbl_src[i - n4];
+        else tbl_dst[i - n4 - lbl_words] = tbl_src[i - n4 - lbl_words];
+    }
+}
+
+MVAE_EXPORT int mvae_ingest(const float *image_src, float *image_dst, size_t image_floats, const void *label_src,
+                            void *label_dst, size_t label_bytes, const void *table_src_host, void *table_dst,
+                            size_t table_bytes, mvae_stream_t stream) {
+    if ((image_floats && (!image_src || !image_dst)) || (label_bytes && (!label_src || !label_dst)) ||
+        (table_bytes && (!table_src_host || !table_dst)))
+        return MVAE_ERR_ARG;
+    if (image_floats % 4 || label_bytes % 4 || table_bytes % 4 || !aligned16(image_src) || !aligned16(image_dst))
+        return MVAE_ERR_ARG;
+    const size_t total = image_floats / 4 + label_bytes / 4 + table_bytes / 4;
+    if (total == 0) return MVAE_OK;
+    hipLaunchKernelGGL(ingest_kernel, dim3(ew_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)image_src, (float4 *)image_dst, image_floats / 4, (const uint32_t *)label_src,
+                       (uint32_t *)label_dst, label_bytes / 4, (const uint32_t *)table_src_host, (uint32_t *)table_dst,
+                       table_bytes / 4);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream) {
     if (!out) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;

@@ -87,6 +87,8 @@ class StepTables(object):
             self._np.append(h.numpy())
             self._events.append(None)
         self._i = 0
+        self.defer = False
+        self._pending = False
         self._np_float = [a.view(np.float32) for a in self._np]
 
     def ints(self, lo, n):
@@ -103,13 +105,28 @@ class StepTables(object):
         return self._np[k], self._np_float[k]
 
     def commit(self):
+        if self.defer:
+            self._pending = True        # replay(): the slot goes to the device with the batch, in ONE ingest launch
+            return
         k = self._i % len(self._host)
         self.dev.copy_(self._host[k], non_blocking=True)
+        self._mark(k)
+
+    def _mark(self, k):
         if torch.cuda.is_available():
             if self._events[k] is None:
                 self._events[k] = torch.cuda.Event()
             self._events[k].record()
         self._i += 1
+        self._pending = False
+
+    def pending_slot(self):
+        """The pinned slot a deferred commit left to be sent (None: nothing pending)."""
+        return self._host[self._i % len(self._host)] if self._pending else None
+
+    def sent(self):
+        """The pending slot was queued for transfer on the current stream (by an ingest launch)."""
+        self._mark(self._i % len(self._host))
 
 
 class _StepBase(object):
@@ -144,6 +161,7 @@ class _StepBase(object):
         self.batch_wgrad = os.environ.get('MVAE_BATCH_WGRAD', '1') != '0'
         self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
         self.wgrad_on_side = os.environ.get('MVAE_WGRAD_SIDE', '1') != '0' and self.side is not None
+        self.use_ingest = os.environ.get('MVAE_INGEST', '1') != '0'      # replay(): batch + tables in one launch
         self._draw_in_poe = False
         self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
         self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
@@ -383,9 +401,20 @@ class _StepBase(object):
 
     def replay(self, image, label, annealing_factor):
         self._bump_bn_counters()
-        self.static_image.copy_(image, non_blocking=True)
-        self.static_label.copy_(label, non_blocking=True)
-        self.set_coefficients(annealing_factor)
+        if self.use_ingest and K.ingest_ok(image, self.static_image, label, self.static_label):
+            # batch + per-step tables in ONE launch (the table slot is pinned host memory the kernel reads itself)
+            self.tables.defer = True
+            try:
+                self.set_coefficients(annealing_factor)
+            finally:
+                self.tables.defer = False
+            slot = self.tables.pending_slot()
+            K.ingest(image, self.static_image, label, self.static_label, slot, self.tables.dev)
+            self.tables.sent()
+        else:
+            self.static_image.copy_(image, non_blocking=True)
+            self.static_label.copy_(label, non_blocking=True)
+            self.set_coefficients(annealing_factor)
         if self._comm is None or getattr(self._comm, 'in_graph', False):
             self._graphs[0].replay()         # single GPU, or data parallel with the collectives inside the graph
         else:

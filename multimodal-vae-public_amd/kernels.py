@@ -687,6 +687,30 @@ def fill_(out, value):
     check(_lib.lib().mvae_fill(_ptr(out), out.numel(), float(value), _stream()), 'mvae_fill')
 
 
+def ingest(image_src, image_dst, label_src, label_dst, table_host, table_dst):
+    """One launch: image and label batch to their static (graph-visible) buffers, the pinned host table block to
+    its device block.  ``table_host`` is a pinned CPU tensor the kernel reads directly."""
+    _need_gpu(image_src, image_dst, label_src, label_dst, table_dst)
+    if not table_host.is_pinned():
+        raise RuntimeError('ingest: the table source must be pinned host memory')
+    for a, b in ((image_src, image_dst), (label_src, label_dst), (table_host, table_dst)):
+        if a.dtype != b.dtype or a.numel() != b.numel() or not (a.is_contiguous() and b.is_contiguous()):
+            raise RuntimeError('ingest: source and destination must be contiguous and alike')
+    check(_lib.lib().mvae_ingest(_ptr(image_src), _ptr(image_dst), image_src.numel(),
+                                 _ptr(label_src), _ptr(label_dst), label_src.numel() * label_src.element_size(),
+                                 _ptr(table_host), _ptr(table_dst), table_host.numel() * table_host.element_size(),
+                                 _stream()), 'mvae_ingest')
+
+
+def ingest_ok(image_src, image_dst, label_src, label_dst):
+    """Whether ``ingest`` takes this batch (else: plain copies)."""
+    return (image_src.is_cuda and label_src.is_cuda and image_src.dtype == torch.float32 == image_dst.dtype
+            and label_src.dtype == label_dst.dtype and image_src.is_contiguous() and label_src.is_contiguous()
+            and image_src.numel() == image_dst.numel() and label_src.numel() == label_dst.numel()
+            and image_src.numel() % 4 == 0 and (label_src.numel() * label_src.element_size()) % 4 == 0
+            and image_src.data_ptr() % 16 == 0 and image_dst.data_ptr() % 16 == 0)
+
+
 def dropout_fanout_fwd(h, masks, out, scale):
     """h [B,N], masks [G,B,N] -> out [G*B,N]"""
     _need_gpu(h, masks, out); _f32c(h, masks, out)

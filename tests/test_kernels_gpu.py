@@ -699,3 +699,23 @@ def test_sigmoid_and_affine():
     assert_close(y, x * sc + sh, 'affine (row broadcast)', tol=1e-6)
     K.affine_fwd(dev(x), torch.ones(1, device=DEV), torch.zeros(1, device=DEV), y)
     assert torch.equal(y.cpu(), x)
+
+
+def test_ingest_one_launch_for_batch_and_tables():
+    """mvae_ingest: image + label batch to their static buffers and the PINNED host table block to its device block
+    (read by the kernel itself), bit-exact, for int64 labels and float attribute rows."""
+    g = torch.Generator().manual_seed(3)
+    for label in (torch.randint(0, 10, (33,), generator=g), torch.randint(0, 2, (33, 18), generator=g).float()):
+        image = torch.rand(33, 1, 28, 28, generator=g).to(DEV)
+        label = label.to(DEV)
+        table = torch.arange(57, dtype=torch.int32).pin_memory()
+        s_img, s_lbl = torch.zeros_like(image), torch.zeros_like(label)
+        s_tbl = torch.zeros(57, dtype=torch.int32, device=DEV)
+        assert K.ingest_ok(image, s_img, label, s_lbl)
+        K.ingest(image, s_img, label, s_lbl, table, s_tbl)
+        torch.cuda.synchronize()
+        assert torch.equal(s_img, image) and torch.equal(s_lbl, label) and torch.equal(s_tbl.cpu(), table)
+    assert not K.ingest_ok(image.cpu(), s_img, label, s_lbl)
+    assert not K.ingest_ok(image[:, :, :, :27], s_img[:, :, :, :27], label, s_lbl)       # not contiguous
+    with pytest.raises(RuntimeError, match='pinned'):
+        K.ingest(image, s_img, label, s_lbl, torch.arange(57, dtype=torch.int32), s_tbl)
