@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries
                    left them.  ``hot_cache_reissue`` = the same call re-issued back to back in a hipGraph
                    (round 1's figure), ``conv_kernels`` / ``all_gemm_kernels`` = the in-situ aggregates,
                    ``top_hbm_kernel`` = the HBM-bound kernel with the most time, ``traffic`` = HBM-side bytes
-                   per launch from the committed PMC table (profiles/r02_traffic.json),
+                   per launch from the committed PMC tables (profiles/r03_traffic.json, r02_traffic.json),
   cpu_baseline  -- the oracle (CPU restatement of the reference step, kind "port") timed on the
                    host cores of this box on a bounded sample of the same workload; ``cores`` = intra-op
                    threads used (fastest of a few counts), ``host`` = nproc + CPU model,
@@ -110,6 +110,9 @@ def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, f
         for i in range(n):
             last = one(first + i)
         if world > 1:
+            # drain this rank's queue first: the step's collectives run on the library's own RCCL communicator, the
+            # barrier on torch.distributed's -- two communicators should not have kernels in flight at once
+            torch.cuda.synchronize(device)
             dist.barrier()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
@@ -234,20 +237,23 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
     return roof
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+TRAFFIC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_traffic.json', 'r02_traffic.json')]
 
 
 def traffic_for(name, key):
     """HBM bytes per launch of the call from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
     tools/traffic_probe.py + tools/rocpd_summary.py --pmc).  None when that call was not probed."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            table = json.load(f)
-    except (IOError, ValueError):
-        return None
-    ent = table.get('%s %s' % (name, key))
-    return None if ent is None else ent['hbm_bytes_per_launch']
+    for path in TRAFFIC_FILES:          # this round's table first, then the previous round's for calls not re-probed
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (IOError, ValueError):
+            continue
+        ent = table.get('%s %s' % (name, key))
+        if ent is not None:
+            return ent['hbm_bytes_per_launch']
+    return None
 
 
 def elbo_delta(kind, batch=32):

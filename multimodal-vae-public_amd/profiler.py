@@ -99,7 +99,8 @@ HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bw
            'bce_rowsum_bwd', 'ce_fwd', 'ce_bwd', 'group_sums', 'randn_', 'bernoulli_', 'adam_step', 'fill_',
            'dropout_fanout_fwd', 'dropout_fanin_bwd', 'bce_elem_fwd', 'bce_elem_bwd', 'embedding_swish_fwd_grouped',
            'embedding_swish_bwd_grouped', 'block_gather', 'block_scatter_add', 'elbo_reduce', 'philox_fill',
-           'adam_apply', 'sigmoid_fwd', 'affine_fwd', 'scatter_sums']
+           'adam_apply', 'sigmoid_fwd', 'affine_fwd', 'scatter_sums', 'poe_fwd_draw', 'poe_bwd_split', 'adam_apply_at',
+           'counter_add', 'conv_repack_batched']
 
 
 class KernelProfile(object):

@@ -82,7 +82,7 @@ def lin_cases(M, N, Kd, tag):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv', 'knockout', 'dec19'])
+    ap.add_argument('--cases', default='all', choices=['all', 'lin', 'conv', 'knockout', 'dec19', 'biglin'])
     ap.add_argument('--auto-only', action='store_true', help='time only the automatic plan')
     args = ap.parse_args()
     conv, lin = [], []
@@ -96,6 +96,27 @@ def main():
                              convT_cases(rows, 32, 32, 3, 2, 1, 'c19 dec4 32->3 32x32')[:1]):
             ms = timeit(fn, launches=4, replays=3)
             print('%-34s %8.2f GFLOP %8.1f TFLOP/s %9.1f us' % (name, fl / 1e9, fl / (ms * 1e-3) / 1e12, ms * 1e3))
+        return
+    if args.cases == 'biglin':
+        # the 6272- / 6400-wide Linear layers (FashionMNIST B = 1024: two decoder terms = 2048 rows; CelebA B = 256)
+        # under the wide tilings: is 64x64 still the right tile for a GEMM with thousands of tiles?
+        big = (lin_cases(2048, 6272, 512, 'fmnist 512->6272 M2048') + lin_cases(1024, 512, 6272, 'fmnist 6272->512 M1024') +
+               lin_cases(256, 512, 6400, 'celeba 6400->512 M256') + lin_cases(768, 6400, 100, 'celeba 100->6400 M768'))
+        lib = _lib.lib()
+        cfgs = [('auto', (0, 0, 0)), ('64x64', (1, 1, 0)), ('64x128', (1, 2, 0)), ('128x64', (2, 1, 0)), ('128x128', (2, 2, 0)),
+                ('64x128 s1', (1, 2, 1)), ('128x128 s1', (2, 2, 1))]
+        print('%-34s %8s | ' % ('op', 'GFLOP') + ' '.join('%11s' % c[0] for c in cfgs) + '   (TFLOP/s)')
+        for name, fl, fn in big:
+            row = []
+            for cname, (wm, wn, sp) in cfgs:
+                lib.mvae_debug_set_tiling(wm, wn, sp)
+                lib.mvae_debug_set_small(1 if wm else 0, 0)
+                try:
+                    row.append(fl / (timeit(fn, launches=8, replays=3) * 1e-3) / 1e12)
+                except RuntimeError:
+                    row.append(float('nan'))
+            lib.mvae_debug_set_tiling(0, 0, 0); lib.mvae_debug_set_small(0, 0)
+            print('%-34s %8.2f | ' % (name, fl / 1e9) + ' '.join('%11.1f' % v for v in row))
         return
     conv += conv_cases(B, 3, 64, 32, 2, 1, 'enc1 3->32 64x64')
     conv += conv_cases(B, 32, 32, 64, 2, 1, 'enc2 32->64 32x32')
