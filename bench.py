@@ -321,7 +321,7 @@ def host_description():
     return {'nproc': os.cpu_count() or 1, 'usable_cpus': usable, 'cpu_model': model}
 
 
-def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True):
+def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True, threads=None):
     """The oracle (a port of the reference's step to explicit-noise torch CPU ops) on this box's
     host cores: full steps incl. Adam on the same synthetic workload, bounded by ~budget_s.
     ``cores`` = the intra-op threads actually used (the fastest of a few counts: torch's CPU kernels do
@@ -358,6 +358,8 @@ def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True):
     # made the choice, and with it the reported rate, swing by +-60 % between runs
     probe = (16, 32) if kind == 'celeba19' else (8, 16, 32, 64)      # a celeba19 step is ~20 model() calls
     cands = [t for t in probe if t <= cores] or [cores]
+    if threads is not None:          # a second batch size of the same model: keep the main run's choice
+        cands = [int(threads)]
     n_probe = 2 if kind == 'celeba19' else 3
     probed = {}
     for th in cands:
@@ -535,7 +537,8 @@ def main():
         out['cpu_baseline'] = cpu_baseline(kind, batch)
         if kind == 'mnist':
             # BASELINE.json configs[0]: the reference's own CPU-runnable case, mnist batch 128
-            out['cpu_baseline']['cfg0_mnist_b128'] = cpu_baseline('mnist', 128, budget_s=6.0, with_delta=False)
+            out['cpu_baseline']['cfg0_mnist_b128'] = cpu_baseline('mnist', 128, budget_s=6.0, with_delta=False,
+                                                                   threads=out['cpu_baseline']['threads'])
         if kind == 'mnist' and args.batch is None:
             # the other three GPU configurations of BASELINE.json at their per-GPU batch, bounded: configs[2]
             # FashionMNIST 1024, configs[3] CelebA 256 (the conv stack north_star's 40 % MFMA target is about),
