@@ -219,15 +219,26 @@ class DataParallel(object):
         self.comm, self.transport = None, 'torch.distributed (%s)' % dist.get_backend(group)
         want = os.environ.get('MVAE_COMM', 'rccl' if transport is None else transport)
         if want == 'rccl' and dist.get_backend(group) == 'nccl' and arena.flat.is_cuda:
+            why = None
             try:
                 self.comm = RcclComm.from_process_group(arena.flat.device, group)
                 self.comm.self_check(arena.flat.device)
-                self.transport = 'mvae_comm (RCCL %s, collectives inside the step graph)' % self.comm.rccl_version
             except Exception as e:       # an error (not a hang) here is recoverable: the three-graph path needs nothing of it
-                sys.stderr.write('[mvae parallel] C-ABI RCCL communicator unavailable (%s: %s); falling back to '
-                                 'torch.distributed all-reduces between three graphs\n' % (type(e).__name__, e))
+                why = '%s: %s' % (type(e).__name__, e)
+            # the choice of transport is COLLECTIVE: one rank on the fallback while its peers wait in the
+            # communicator's all-reduce is a deadlock
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device=arena.flat.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                self.transport = 'mvae_comm (RCCL %s, collectives inside the step graph)' % self.comm.rccl_version
+            else:
+                sys.stderr.write('[mvae parallel] rank %d: C-ABI RCCL communicator unavailable here or on a peer (%s); '
+                                 'all ranks fall back to torch.distributed all-reduces between three graphs\n'
+                                 % (dist.get_rank(group), why or 'peer failed'))
+                if self.comm is not None and why is None:
+                    self.comm.destroy()
                 self.comm = None
-                self.transport += ' [fallback: %s]' % type(e).__name__
+                self.transport += ' [fallback from mvae_comm]'
         if self.comm is not None:
             self.buckets = RcclBuckets(arena.grad, ranges, self.comm)
         else:
