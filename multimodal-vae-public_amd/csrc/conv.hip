@@ -252,6 +252,7 @@ template <int T> using LdIm2col = LdIm2colT<T>;
 template <int TILE_, int TLOG, int BKV_ = MVAE_CONV_BK>
 struct LdDgradDyT {
     static constexpr int TILE = TILE_, BKV = BKV_;
+    static constexpr bool PAIRABLE = (TLOG == 1);     // stride 2: classes = the 2 x 2 output parities (EpNCHW pair stores)
     static constexpr int NV = TILE * BKV / NTHREADS;
     static constexpr int KSTEP = NTHREADS / TILE;
     static constexpr int TMASK = (1 << TLOG) - 1;
@@ -1146,6 +1147,12 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     e.out = dx; e.act = act; e.dpre = dpre;
     e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
     e.sy = s; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+#ifndef MVAE_PAIR_STORE
+#define MVAE_PAIR_STORE 1
+#endif
+    // pair stores (gemm_core.h EpNCHW::PAIR): class-minor item order puts (py, 0), (py, 1) back to back in a block
+    e.pair = (MVAE_PAIR_STORE && s == 2 && MVAE_CLS_MINOR && g.W % 2 == 0 && (!dx || aligned8(dx)) && (!act || aligned8(act)) &&
+              (!dpre || aligned8(dpre))) ? 1 : 0;
     auto mp = [&](auto &p) {
         p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.Klen = K; p.cls_stride = (size_t)K * g.Cin;
     };
@@ -1154,6 +1161,11 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
     sink.cls_minor = MVAE_CLS_MINOR;
     if (vec) {
+        if (s == 2 && e.pair && pl.items >= 2 && pl.items % 2 == 0 && I <= 32) {
+            EpNCHWPair ep;
+            static_cast<EpNCHW &>(ep) = e;
+            return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHWPair, false>(pl, mp, mq, ep, I, J, K, sink, st);
+        }
         if (s == 2) return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
         return launch_igemm<LdRowsMNC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
     }

@@ -315,6 +315,9 @@ template <int T> using LdRowsMNS64 = LdRowsMNT<T, false, 64>;
 // Row-major destination D[i * ld + j] with the Linear fusions.
 struct EpRowMajor {
     static constexpr bool MULTI = false;      // multi-item blocks: conv forms only (set_class here is cumulative)
+    static constexpr bool PAIR = false;
+    __device__ bool pair_ok() const { return false; }
+    __device__ void put2(int, float, float) const {}
     float *out; float *act; int ld;           // out = raw / pre-activation result, act = swish(result)
     const float *bias;                        // per column j (Linear fwd)
     const float *dpre; int ldp;               // multiply by swish'(dpre[i][j])
@@ -345,6 +348,24 @@ struct EpRowMajor {
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
     static constexpr bool MULTI = true;
+    // PAIR: the two px classes of a stride-2 lattice row are neighbours in memory ((c*2 + 0), (c*2 + 1)) and the SAME
+    // lane owns both (a lane is a column j = (n, r', c') of the class lattice): a multi-item block that walks the
+    // classes (py, 0), (py, 1) back to back keeps the first one's accumulators and stores float2 -- full 256-byte
+    // segments per half-wave instead of two passes of 4-byte stores at stride 8 (`pair` set by the host: stride 2,
+    // even width, 8-byte aligned tensors, class-minor item order)
+    static constexpr bool PAIR = false;       // EpNCHWPair below
+    int pair = 0;                             // host-side choice between the two types
+    __device__ bool pair_ok() const { return pair != 0; }
+    __device__ void put2(int i, float v0, float v1) const {      // off was computed for px = 0
+        if (i >= C) return;
+        const int idx = off + i * HW;
+        if (dpre) {
+            const float2 d = *reinterpret_cast<const float2 *>(dpre + idx);
+            v0 *= swish_grad_(d.x); v1 *= swish_grad_(d.y);
+        }
+        if (out) *reinterpret_cast<float2 *>(out + idx) = make_float2(v0, v1);
+        if (act) *reinterpret_cast<float2 *>(act + idx) = make_float2(swishf_(v0), swishf_(v1));
+    }
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
     int off;   // per-lane column offset, set by col()
@@ -364,6 +385,14 @@ struct EpNCHW {
         if (out) out[idx] = v;
         if (act) act[idx] = swishf_(v);
     }
+};
+
+// EpNCHW whose multi-item blocks store the two px classes of a stride-2 lattice row TOGETHER (see EpNCHW::put2): a
+// separate type, so that only launches the host found pairable carry the second accumulator set, and the kernel
+// has no run-time choice between the two store forms (with one, hipcc spilled the loader state of the 32-row
+// kernel to scratch: 630 scratch instructions, 466 of them among the MFMAs, and the launch ran 40 % longer).
+struct EpNCHWPair : EpNCHW {
+    static constexpr bool PAIR = true;
 };
 
 // Where the raw partial tiles of a split reduction go (row-major [I][J] per split), plus the
@@ -397,6 +426,10 @@ __device__ __forceinline__ void finish_rowsum(const SplitSink &sink, int splits,
     if (sink.rowsum_final_accumulate) s += *dst;
     *dst = s;
 }
+
+// a Q loader says `static constexpr bool PAIRABLE = true` when its classes are the parity classes of a stride-2 lattice
+template <class T, class = void> struct loader_pairable : std::false_type {};
+template <class T> struct loader_pairable<T, std::void_t<decltype(T::PAIRABLE)>> : std::integral_constant<bool, T::PAIRABLE> {};
 
 // ------------------------------------------------------------------------------------------
 // the kernel
@@ -619,8 +652,35 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 p.begin(kbeg, t); q.begin(kbeg, t);
             };
             auto kof = [&](int g) { return kbeg + (g % nsteps) * BKK; };
+            // PAIR (one-tile waves only: a second accumulator set costs the 2- and 4-tile kernels an occupancy step
+            // or spills): the px = 0 class of a stride-2 row is kept until px = 1 is done
+            // ... and only in the 32-row layout (1 x 4 waves): the host sends ONLY short reductions (K <= 256: the <= 64-channel
+            // layers, whose outputs have 32 channels) through multi-item blocks; in the 64-row kernels the second
+            // accumulator set would cost an occupancy step for a path they never take
+            constexpr bool PAIRK = E::PAIR && WM * WN == 1 && WGM == 1 && WGN == 4 && loader_pairable<Q>::value;
+            std::conditional_t<PAIRK, f32x16, char> hold;
             auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
                 int c, jt; item_tile(w, c, jt);
+                if constexpr (PAIRK) {
+                    // the host only launches this type with an even number of items per block in class-minor order:
+                    // item w even = class (py, 0), item w + 1 = (py, 1) of the same j tile
+                    if (!(w & 1)) {
+                        hold = acc[0][0];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+                    } else {
+                        e.set_class(c - 1);
+                        const int j = jt + wj * 32 + lcol;
+                        if (e.col(j)) {
+                            const int ib = i0 + wi * 32 + 4 * lrow;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) e.put2(ib + (r & 3) + 8 * (r >> 2), hold[r], acc[0][0][r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+                    }
+                    return;
+                }
                 e.set_class(c);
 #pragma unroll
                 for (int y = 0; y < WN; ++y) {
