@@ -1150,6 +1150,12 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
 #ifndef MVAE_PAIR_STORE
 #define MVAE_PAIR_STORE 1
 #endif
+#ifndef MVAE_PAIR_MAXK
+#define MVAE_PAIR_MAXK 512
+#endif
+#ifndef MVAE_PAIR_MINBLOCKS
+#define MVAE_PAIR_MINBLOCKS 2048
+#endif
     // pair stores (gemm_core.h EpNCHW::PAIR): class-minor item order puts (py, 0), (py, 1) back to back in a block
     e.pair = (MVAE_PAIR_STORE && s == 2 && MVAE_CLS_MINOR && g.W % 2 == 0 && (!dx || aligned8(dx)) && (!act || aligned8(act)) &&
               (!dpre || aligned8(dpre))) ? 1 : 0;
@@ -1161,7 +1167,14 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
     sink.cls_minor = MVAE_CLS_MINOR;
     if (vec) {
-        if (s == 2 && e.pair && pl.items >= 2 && pl.items % 2 == 0 && I <= 32) {
+        // pair stores want the two px classes of a tile in ONE block.  Short reductions (K <= 256) run multi-item
+        // blocks anyway; for K = 512 (the 64-channel layers) two items per block pay only when the launch still
+        // has >= 8 blocks per CU afterwards (measured: FashionMNIST's 2048-row ConvTranspose2d(128, 64) -2.9 % of
+        // the step, CelebA's 512-row one +0.9 %: profiles/r03_pair_store_ab.txt)
+        const long pair_blocks = cdiv(J, pl.wgn == 4 ? 128 : 64) * 4 / 2;
+        const bool pair_long = K > MVAE_MULTI_MAXK && K <= MVAE_PAIR_MAXK && pair_blocks >= MVAE_PAIR_MINBLOCKS;
+        if (s == 2 && e.pair && pl.wm * pl.wn == 1 && pl.kw == 1 && (K <= MVAE_MULTI_MAXK || pair_long)) {
+            if (pair_long) pl.items = 2;
             EpNCHWPair ep;
             static_cast<EpNCHW &>(ep) = e;
             return launch_igemm<LdRowsMNC, LdDgradDyS2, EpNCHWPair, false>(pl, mp, mq, ep, I, J, K, sink, st);

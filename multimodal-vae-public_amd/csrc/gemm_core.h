@@ -654,10 +654,8 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             auto kof = [&](int g) { return kbeg + (g % nsteps) * BKK; };
             // PAIR (one-tile waves only: a second accumulator set costs the 2- and 4-tile kernels an occupancy step
             // or spills): the px = 0 class of a stride-2 row is kept until px = 1 is done
-            // ... and only in the 32-row layout (1 x 4 waves): the host sends ONLY short reductions (K <= 256: the <= 64-channel
-            // layers, whose outputs have 32 channels) through multi-item blocks; in the 64-row kernels the second
-            // accumulator set would cost an occupancy step for a path they never take
-            constexpr bool PAIRK = E::PAIR && WM * WN == 1 && WGM == 1 && WGN == 4 && loader_pairable<Q>::value;
+            // ... the 32-row (1 x 4 waves) and 64-row (2 x 2 waves) layouts: 146 and 127 VGPRs, same occupancy as without
+            constexpr bool PAIRK = E::PAIR && WM * WN == 1 && loader_pairable<Q>::value;
             std::conditional_t<PAIRK, f32x16, char> hold;
             auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
                 int c, jt; item_tile(w, c, jt);
