@@ -7,7 +7,7 @@ out=gpurun_out/final3; rm -rf $out; mkdir -p $out
 timeout 900 python -m pytest tests -m gpu -q > $out/tests.log 2>&1; echo "tests rc=$?" > $out/status.txt
 grep -E "passed|failed|^FAILED" $out/tests.log >> $out/status.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?" >> $out/status.txt
-timeout 400 python bench.py > $out/r03_bench_default.json 2> $out/bench.err; echo "bench rc=$?" >> $out/status.txt
+t0=$(date +%s); timeout 400 python bench.py > $out/r03_bench_default.json 2> $out/bench.err; echo "bench rc=$? wall=$(( $(date +%s) - t0 ))s" >> $out/status.txt
 for w in mnist fashionmnist celeba celeba19; do
     timeout 200 python bench.py --workload $w --force-dp --no-extras > $out/dp_$w.json 2> $out/dp_$w.err; echo "dp $w rc=$?" >> $out/status.txt
 done
