@@ -163,6 +163,10 @@ class _StepBase(object):
         self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
         self.wgrad_on_side = os.environ.get('MVAE_WGRAD_SIDE', '1') != '0' and self.side is not None
         self.use_ingest = os.environ.get('MVAE_INGEST', '1') != '0'      # replay(): batch + tables in one launch
+        # one-graph data-parallel step: buckets 0 and 1 go out from the SIDE stream (MVAE_DP_SIDE_LAUNCH=0: from the
+        # main stream behind a full join)
+        self.dp_side_launch = os.environ.get('MVAE_DP_SIDE_LAUNCH', '1') != '0'
+        self._bucket1_done = False
         self._draw_in_poe = False
         self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
         self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
@@ -365,16 +369,19 @@ class _StepBase(object):
         bucket by bucket (parallel.DataParallel.finish)."""
         comm = self._comm
         self._adam_counter = None
-        self._bucket0_done = False
+        self._bucket0_done = self._bucket1_done = False
         try:
             self._body_a()
             if self.n_buckets > 1 and not self._bucket0_done:      # else: phase A sent it from the side stream
                 comm.launch(0)
             for k, part in enumerate(self._phases_b()):
                 part()
-                comm.launch(k + 1 if self.n_buckets > 1 else 0)
+                bucket = k + 1 if self.n_buckets > 1 else 0
+                if not (bucket == 1 and self._bucket1_done):        # else: phase B's first half sent it from the side stream
+                    comm.launch(bucket)
         finally:
             self._step_end()
+        self._join()            # every stream of the step is back on this one before the optimizer (and the end of a capture)
         comm.finish(optimizer)
 
     def _poe_forward(self, mus, lvs, mu, lv, z, kl):
@@ -385,6 +392,31 @@ class _StepBase(object):
                            self.model.POE_VARIANT)
         else:
             K.poe_fwd(mus, lvs, self.masks_dev, self.noise, mu, lv, z, kl, self.model.POE_VARIANT)
+
+    def _side_launch_ok(self):
+        """The one-graph data-parallel step may issue a bucket's all-reduce from the side stream: the communicator's
+        launch is a stream operation (parallel.RcclBuckets), so the main stream need not join the side stream -- and
+        wait for its weight gradients -- just to start a collective."""
+        return (self.dp_side_launch and self.side is not None and self._comm is not None
+                and getattr(self._comm, 'in_graph', False) and self.on_bucket_ready is None)
+
+    def _upper_done(self):
+        """End of phase B's first half with three buckets: bucket 1 (the encoders without the image encoder's first
+        layers) is final once BOTH streams are here.  Old form: join, then the caller launches from the main stream --
+        which made the main stream wait for the side stream's weight gradients before the conv trunk's backward.
+        Now the side stream waits for the main stream's event and launches; the main stream goes straight on."""
+        if self._side_launch_ok() and self.n_buckets == 3:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self._comm.launch(1)
+            self._carry.setdefault('events', ())
+            self._carry['events'] += (ev,)
+            self._bucket1_done = True
+            self._forked = True
+        else:
+            self._join()
 
     def _early_counter(self):
         """Called at the end of the side stream's encoder forward (the shorter of the two encoder branches)."""
@@ -668,11 +700,8 @@ class BimodalStep(_StepBase):
                 ev_lbl = None
                 # single-GPU step, or the one-graph data-parallel step (the communicator's launch is a stream
                 # operation: bucket 0 can then go out from the side stream, behind the last decoder gradient)
-                # -- with TWO buckets only: with three, phase B joins the streams between its two halves, and the main
-                # stream would wait there for the side stream's weight gradients (measured under --force-dp: MNIST
-                # 0.324 -> 0.313 ms, but FashionMNIST 2.52 -> 2.57 and CelebA 2.71 -> 2.74 with their three buckets)
-                dp_side = (self._comm is not None and getattr(self._comm, 'in_graph', False)
-                           and self.on_bucket_ready is None and self.n_buckets == 2)
+                # (with three buckets phase B's first half must then not JOIN the streams before the second: _upper_done)
+                dp_side = self._side_launch_ok() and self.n_buckets >= 2
                 if self.wgrad_on_side and self.side is not None and isinstance(wl, L.WgradBatch) \
                         and (dp_side or (self._comm is None and self.on_bucket_ready is None)):
                     ev_lbl = torch.cuda.Event()
@@ -824,7 +853,7 @@ class BimodalStep(_StepBase):
                 c['keep_b'] += (d_hd,)
             c['g_cut'] = L.backward_tape(plan[cut:], tape[cut:], g, need_input_grad=True)
             self._late_elbo()
-            self._join()
+            self._upper_done()
         else:
             L.backward_tape(plan[:cut], tape[:cut], c['g_cut'])
 
@@ -1155,7 +1184,10 @@ class Celeba19Step(_StepBase):
             else:   # data parallel, three buckets: stop where the arena tail (the conv stack) begins
                 cut = L.tail_cut(self.trunk, m.arena_tail())
                 c['g_cut'] = L.backward_tape(self.trunk[cut:], c['tape_trunk'][cut:], d_h, need_input_grad=True)
-            self._join()
+            if part == 'upper':
+                self._upper_done()
+            else:
+                self._join()
         else:
             cut = L.tail_cut(self.trunk, m.arena_tail())
             L.backward_tape(self.trunk[:cut], c['tape_trunk'][:cut], c['g_cut'])
