@@ -47,6 +47,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_KO
 #define MVAE_KO 0               // knock-out experiments on the interleaved loop (results are wrong): 1 no global loads,
 #endif                          // 2 + no LDS stores, 3 + no barrier, 4 + no fragment reads (MFMAs only)
+#ifndef MVAE_XCD_ROWS
+#define MVAE_XCD_ROWS 0         // 1: Linear launches map XCDs to ROW BANDS of the output (experiment; see igemm_kernel)
+#endif
 #ifndef MVAE_SETPRIO
 #define MVAE_SETPRIO 0          // 1: raise the wave priority around each MFMA group (measured: see DESIGN.md)
 #endif
@@ -480,9 +483,20 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         // fabric for 5 MB of operands).  Re-map the launch order so that XCD x owns a (tiles_i / 4) x (tiles_j / 2)
         // sub-grid of the output: P is fetched by 2 XCDs, Q by 4 (host checks divisibility, one class, no split).
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+#if MVAE_XCD_ROWS
+        if (sink.xcd_map == 2) {
+            // row bands: XCD x owns rows [x * tiles_i / 8, (x + 1) * tiles_i / 8) x ALL column tiles -- the layer behind
+            // this one (same rows, same bands) then finds its whole input in the L2 that produced it
+            const unsigned sj = gridDim.x, si = gridDim.y >> 3;
+            const unsigned ti = slot / sj, tj = slot - ti * sj;
+            bx = (int)tj; by = (int)(xcd * si + ti);
+        } else
+#endif
+        {
         const unsigned sj = gridDim.x >> 1, si = gridDim.y >> 2;
         const unsigned ti = slot / sj, tj = slot - ti * sj;
         bx = (int)((xcd & 1u) * sj + tj); by = (int)((xcd >> 1) * si + ti);
+        }
     }
     // Multi-item blocks (sink.items > 1, conv forms with short reductions): the block owns `n_items` consecutive
     // (class, j tile) items, and the software pipeline runs ACROSS them -- the first k-tiles of item w+1 are
@@ -1182,6 +1196,7 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
         sink.tiles_j = (J + TN - 1) / TN;                                                        \
         sink.xcd_map = (pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
+        if (MVAE_XCD_ROWS && pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.y % 8 == 0) sink.xcd_map = 2;     \
         sink.items = 1;                                                                          \
         if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \
             K >= 2 * PLD<TM>::BKV && PLD<TM>::PARTS && QLD<TN>::PARTS) {                         \
