@@ -10,7 +10,6 @@ import mvae_amd  # noqa: F401
 from mvae_amd import kernels as K
 from mvae_amd.multimnist import model as MM
 from oracle import models as OM, multimnist as OMM
-from oracle.functional import cross_entropy as oracle_ce
 from util import assert_close, load_golden
 
 pytestmark = pytest.mark.gpu
