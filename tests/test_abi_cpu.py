@@ -169,3 +169,19 @@ def test_reference_module_level_names_exist_on_every_drop_in():
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert _lib.lib().mvae_poe_fwd(ctypes.byref(ex), 4, 0, p, 1, None, p, p, None, None, 1, 4,
                                    _lib.POE_VARIANT['A-noprior'], None) == -1
+
+
+def test_binding_arity_matches_header_prototypes():
+    """Every ctypes signature of _lib.py has exactly as many arguments as the prototype in include/mvae_hip.h (a
+    ctypes call with one argument too few does not fail -- it passes garbage)."""
+    text = open(os.path.join(ROOT, 'include', 'mvae_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\b(?:int|size_t|void|const char \*)\s*\**\s*(mvae_[a-zA-Z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ('', 'void') else args.count(',') + 1
+    table = dict(_lib._SIGNATURES)
+    table.update(_lib._TUNING_SIGNATURES)
+    assert set(table) <= set(protos), sorted(set(table) - set(protos))
+    wrong = ['%s: header %d, binding %d' % (n, protos[n], len(a)) for n, (_, a) in table.items() if protos[n] != len(a)]
+    assert not wrong, '; '.join(wrong)
