@@ -47,6 +47,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_KO
 #define MVAE_KO 0               // knock-out experiments on the interleaved loop (results are wrong): 1 no global loads,
 #endif                          // 2 + no LDS stores, 3 + no barrier, 4 + no fragment reads (MFMAs only)
+#ifndef MVAE_MULTI_MINBLOCKS
+#define MVAE_MULTI_MINBLOCKS 1024   // a multi-item launch keeps at least this many column blocks (4 per CU)
+#endif
 #ifndef MVAE_XCD_ROWS
 #define MVAE_XCD_ROWS 0         // 1: Linear launches map XCDs to ROW BANDS of the output (experiment; see igemm_kernel)
 #endif
@@ -1200,8 +1203,8 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         sink.items = 1;                                                                          \
         if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \
             K >= 2 * PLD<TM>::BKV && PLD<TM>::PARTS && QLD<TN>::PARTS) {                         \
-            int items = pl.items;                      /* keep >= 1024 blocks: 4 per CU */       \
-            while (items > 1 && (int)grid.x / items < 1024) items >>= 1;                         \
+            int items = pl.items;                      /* keep >= MVAE_MULTI_MINBLOCKS column blocks */ \
+            while (items > 1 && (int)grid.x / items < MVAE_MULTI_MINBLOCKS) items >>= 1;         \
             sink.items = items;                                                                  \
             grid.x = (grid.x + items - 1) / items;                                               \
         }                                                                                        \
