@@ -320,13 +320,29 @@ int mvae_ce_fwd(const float *logits, const int64_t *label, float *row,
 int mvae_ce_bwd(const float *logits, const int64_t *label, const float *drow_dev,
                 float *dlogits, int R, int K, int rows_per_group, int label_rows,
                 mvae_stream_t stream);
+/* K1 + K12 / K13 in one launch: a decoder's LAST Linear whose only consumer is its reconstruction term
+ * (mnist/model.py:104 -> mnist/train.py:47-49,62-74; mnist/model.py:146 -> mnist/train.py:52,77-94).  The logits
+ * stay in the GEMM's accumulators: the epilogue writes d loss / d logits (what the backward consumes) and the loss.
+ *   bce: dlogits[m][n] = drow[m / rows_per_group] * dBCE(logit, target[(m % target_rows) * target_row_stride + n]),
+ *        partial[m][n / 32] = sum of the 32 columns' terms  (partial is [M, ceil(N / 32)] floats; a row's term is
+ *        the sum of its partials -- mvae_elbo_reduce with rows_per_group = B * ceil(N / 32) adds them up);
+ *   ce : N <= 32 classes; row[m] and dlogits as mvae_ce_fwd defines them, label[m % label_rows].
+ * `logits` (nullable): also store the logits (tests).  The reduction is never split. */
+int mvae_linear_bce_fwd(const float *x, int ldx, const float *w, const float *bias, const float *target,
+                        int target_rows, int target_row_stride, const float *drow_dev, int rows_per_group,
+                        float *dlogits, int ldy, float *logits, float *partial, int M, int N, int K,
+                        mvae_stream_t stream);
+int mvae_linear_ce_fwd(const float *x, int ldx, const float *w, const float *bias, const int64_t *label,
+                       int label_rows, const float *drow_dev, int rows_per_group, float *dlogits, int ldy,
+                       float *logits, float *row, int M, int N, int K, mvae_stream_t stream);
 /* The ELBO of a whole fused step in one launch (mnist/train.py:57-58 batch mean per term, :214 sum of terms;
  * celeba19/train.py:59,265-302).  Each part is a vector of loss rows in `groups` groups of `rows_per_group`;
  * group g feeds term `term_of[g]` (device table) or `first_term + g`:
  *     elbo[t] = sum over parts and groups of term t of  coef[g] * sum(rows of g),   elbo[T] = sum over everything,
  * accumulated part by part, group by group (fixed order).  Optionally clears `zero[0..zero_n)` (the latent
  * gradient the decoders' first layers accumulate into) and advances a Philox launch counter by `counter_inc`
- * -- the step's bookkeeping that would otherwise be 5-6 single-purpose launches. */
+ * -- the step's bookkeeping that would otherwise be 5-6 single-purpose launches.  At most 1024 groups over all
+ * parts; a part of more than one row per group has at most MVAE_ELBO_MAX_TERMS groups. */
 #define MVAE_ELBO_MAX_PARTS 4
 #define MVAE_ELBO_MAX_TERMS 40
 typedef struct {

@@ -63,6 +63,8 @@ _SIGNATURES = {
     'mvae_abi_version': (c_int, []),
     'mvae_gemm_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'mvae_linear_fwd': (c_int, [P, c_int, P, P, P, P, c_int, P, c_float, c_int, c_int, c_int, P, c_size_t, P]),
+    'mvae_linear_bce_fwd': (c_int, [P, c_int, P, P, P, c_int, c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P]),
+    'mvae_linear_ce_fwd': (c_int, [P, c_int, P, P, P, c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, P]),
     'mvae_linear_dgrad': (c_int, [P, c_int, P, P, c_int, P, P, c_float, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_wgrad': (c_int, [P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'mvae_linear_fwd_grouped': (c_int, [P, c_int, c_size_t, P, c_size_t, P, c_size_t, P, P, c_int, c_size_t,

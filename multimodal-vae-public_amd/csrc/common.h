@@ -37,6 +37,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the 32 lanes of a half wavefront (lanes 0-31 and 32-63 separately); every lane receives its half's total.
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float half_wave_max(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Bernoulli reconstruction term on a logit: clamp(x,0) - x*t + log(1 + exp(-|x|))   (mnist/train.py:73-74)
+__device__ __forceinline__ float bce_elem(float x, float t) {
+    return fmaxf(x, 0.f) - x * t + logf(1.0f + expf(-fabsf(x)));
+}
+// autograd of the expression above, term by term: 1[x>=0] - t - sign(x) * e/(1+e), e = exp(-|x|)
+__device__ __forceinline__ float bce_grad(float x, float t) {
+    const float e = expf(-fabsf(x));
+    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e / (1.0f + e));
+}
+
 // Block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.
 // Every thread receives the total.
 __device__ __forceinline__ float block_sum(float v, float *red) {

@@ -322,6 +322,7 @@ template <int T> using LdRowsMNS64 = LdRowsMNT<T, false, 64>;
 struct EpRowMajor {
     static constexpr bool MULTI = false;      // multi-item blocks: conv forms only (set_class here is cumulative)
     static constexpr bool PAIR = false;
+    static constexpr bool ROWRED = false;     // EpRowBce / EpRowCe below
     __device__ bool pair_ok() const { return false; }
     __device__ void put2(int, float, float) const {}
     float *out; float *act; int ld;           // out = raw / pre-activation result, act = swish(result)
@@ -350,10 +351,85 @@ struct EpRowMajor {
     }
 };
 
+// Linear forward whose only consumer is a reconstruction term of the ELBO: the logits never reach memory, the
+// epilogue emits d loss / d logits (the backward's input) and the loss itself.  ROWRED epilogues are driven through
+// put_row(i, j, v), called TOGETHER by the 32 lanes of a half wavefront that hold 32 consecutive columns
+// j = 32 * q + (lane & 31) of ONE row i (the kernel guarantees it; out-of-range rows / columns take part with
+// i >= I or j >= J), so a row reduction is five cross-lane steps in a fixed order.  Split reductions never reach
+// these (the host plans them without a split); put() exists for the finish kernels' instantiation only.
+//
+// Bernoulli term (mnist/train.py:47-49,62-74 on mnist/model.py:104's last Linear): part[i][j / 32] = the sum of the
+// 32 columns' terms, summed over j / 32 by the ELBO launch (a group of B rows is B * nparts consecutive floats).
+struct EpRowBce {
+    static constexpr bool MULTI = false, PAIR = false, ROWRED = true;
+    __device__ bool pair_ok() const { return false; }
+    __device__ void put2(int, float, float) const {}
+    float *dlogits; int ld;                          // d loss / d logits [I, ld]
+    float *logits;                                   // optional: the logits as well (tests)
+    const float *bias;
+    const float *target; int t_rs, target_rows;      // target row of output row i: i % target_rows
+    const float *drow; int rows_per_group;           // d loss / d rowsum of group i / rows_per_group
+    float *part; int nparts;                         // [I, nparts], nparts = ceil(J / 32)
+    int I, J;
+    __device__ void set_class(int) const {}
+    __device__ bool col(int j) const { return j < J; }
+    __device__ void put(int, int, float) const {}
+    __device__ void put_row(int i, int j, float v) const {
+        float l = 0.f;
+        if (i < I && j < J) {
+            if (bias) v += bias[j];
+            const float tg = target[(size_t)(i % target_rows) * t_rs + j];
+            l = bce_elem(v, tg);
+            const size_t idx = (size_t)i * ld + j;
+            dlogits[idx] = drow[i / rows_per_group] * 1.f * bce_grad(v, tg);     // bce_row_block_kernel's product, bit for bit
+            if (logits) logits[idx] = v;
+        }
+        l = half_wave_sum(l);
+        if ((threadIdx.x & 31) == 0 && i < I && j < J) part[(size_t)i * nparts + (j >> 5)] = l;
+    }
+};
+
+// Categorical term (mnist/train.py:52,77-94 on mnist/model.py:146's last Linear), J <= 32 classes: a half wavefront
+// holds the whole row.  row[i] = -log_softmax(x + 1e-6)[label], dlogits = drow * (softmax(x + 1e-6) - onehot);
+// a label outside 0..J-1 makes both NaN (ce_kernel's rule).
+struct EpRowCe {
+    static constexpr bool MULTI = false, PAIR = false, ROWRED = true;
+    __device__ bool pair_ok() const { return false; }
+    __device__ void put2(int, float, float) const {}
+    float *dlogits; int ld;
+    float *logits;
+    const float *bias;
+    const int64_t *label; int label_rows;            // label of output row i: label[i % label_rows]
+    const float *drow; int rows_per_group;
+    float *row;                                      // [I]
+    int I, J;
+    __device__ void set_class(int) const {}
+    __device__ bool col(int j) const { return j < J; }
+    __device__ void put(int, int, float) const {}
+    __device__ void put_row(int i, int j, float v) const {
+        const bool in = i < I && j < J;
+        if (in && bias) v += bias[j];
+        const float x = in ? v + 1e-6f : -INFINITY;
+        const float mx = half_wave_max(x);
+        const float se = half_wave_sum(in ? expf(x - mx) : 0.f);
+        if (!in) return;
+        const float lse = logf(se) + mx;
+        const int64_t yraw = label[i % label_rows];
+        const bool bad = yraw < 0 || yraw >= J;
+        const int y = bad ? 0 : (int)yraw;
+        if (j == y) row[i] = bad ? NAN : -(x - lse);
+        const float dr = bad ? NAN : drow[i / rows_per_group];
+        const size_t idx = (size_t)i * ld + j;
+        dlogits[idx] = dr * (expf(x - lse) - (j == y ? 1.f : 0.f));
+        if (logits) logits[idx] = v;
+    }
+};
+
 // NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
     static constexpr bool MULTI = true;
+    static constexpr bool ROWRED = false;
     // PAIR: the two px classes of a stride-2 lattice row are neighbours in memory ((c*2 + 0), (c*2 + 1)) and the SAME
     // lane owns both (a lane is a column j = (n, r', c') of the class lattice): a multi-item block that walks the
     // classes (py, 0), (py, 1) back to back keeps the first one's accumulators and stores float2 -- full 256-byte
@@ -930,7 +1006,12 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
 #pragma unroll
             for (int g2 = 0; g2 < KW; ++g2) v += lds_raw[g2 * (BM * TP) + il * TP + jl];
             const int i = i0 + il, j = j0 + jl;
-            if (partial_c) {
+            if constexpr (E::ROWRED) {
+                // 32 consecutive threads = 32 consecutive columns of one row (BN is a multiple of 32, the trip count
+                // is the same for every thread)
+                static_assert((BM * BN) % NT == 0, "row-reducing epilogue: every thread takes part in every round");
+                e.put_row(i, j, v);
+            } else if (partial_c) {
                 if (i < sink.I && j < sink.J)
                     sink.ws[(size_t)cls * sink.cls_region + (size_t)split * sink.stride + (size_t)i * sink.J + j] = v;
             } else if (e.col(j)) {
@@ -975,6 +1056,20 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool partial = gridDim.z > 1;
+    if constexpr (E::ROWRED) {
+        // a half wavefront holds 32 consecutive columns of row ib + ...: all lanes call (no column early-out)
+#pragma unroll
+        for (int y = 0; y < WN; ++y) {
+            const int j = j0 + (wj * WN + y) * 32 + lcol;
+#pragma unroll
+            for (int x = 0; x < WM; ++x) {
+                const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.put_row(ib + (r & 3) + 8 * (r >> 2), j, acc[x][y][r]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int y = 0; y < WN; ++y) {
         const int j = j0 + (wj * WN + y) * 32 + lcol;

@@ -63,6 +63,23 @@ static int linear_fwd_impl(const float *x, int ldx, const float *w, const float 
     return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
 }
 
+// Linear forward + reconstruction term in one launch (EpRowBce / EpRowCe, gemm_core.h): same loaders and plan as
+// linear_fwd_impl, never a split reduction (the epilogue needs whole sums).
+template <class E>
+static int linear_loss_impl(const float *x, int ldx, const float *w, E e, int M, int N, int K, hipStream_t st) {
+    const bool vec = aligned16(x) && aligned16(w) && ldx % 4 == 0 && K % 4 == 0;
+    Plan pl = make_plan(M, N, K, false, PLAN_FWD, 1, vec);
+    if (pl.splits != 1) return MVAE_ERR_ARG;
+    pl.xcd = MVAE_XCD_MAP;
+    SplitSink sink = make_sink(nullptr, M, N, false);
+    sink.ncls = 1; sink.cls_region = 0;
+    auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; p.cls_stride = 0; };
+    auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; q.cls_stride = 0; };
+    if (vec)
+        return launch_igemm_small<LdRowsK, LdRowsK, LdRowsK64, LdRowsK64, E, false>(pl, mp, mq, e, M, N, K, sink, st);
+    return launch_igemm<LdRowsKS, LdRowsKS, E, false>(pl, mp, mq, e, M, N, K, sink, st);
+}
+
 static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *dx, int lddx, const float *pre_in,
                              const float *mask, float mask_scale, int M, int N, int K, int flags, void *ws,
                              size_t ws_bytes, LinGroups gr, hipStream_t st) {
@@ -155,6 +172,34 @@ MVAE_EXPORT int mvae_linear_fwd(const float *x, int ldx, const float *w, const f
     if (!x || !w || (!pre && !act) || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return MVAE_ERR_ARG;
     return linear_fwd_impl(x, ldx, w, bias, pre, act, ldy, mask, mask_scale, M, N, K, ws, ws_bytes, kOneGroup,
                            (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_bce_fwd(const float *x, int ldx, const float *w, const float *bias, const float *target,
+                                    int target_rows, int target_row_stride, const float *drow_dev, int rows_per_group,
+                                    float *dlogits, int ldy, float *logits, float *partial, int M, int N, int K,
+                                    mvae_stream_t stream) {
+    if (!x || !w || !target || !drow_dev || !dlogits || !partial || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N ||
+        target_rows <= 0 || target_row_stride < N || rows_per_group <= 0)
+        return MVAE_ERR_ARG;
+    EpRowBce e;
+    e.dlogits = dlogits; e.ld = ldy; e.logits = logits; e.bias = bias;
+    e.target = target; e.t_rs = target_row_stride; e.target_rows = target_rows;
+    e.drow = drow_dev; e.rows_per_group = rows_per_group;
+    e.part = partial; e.nparts = (N + 31) / 32; e.I = M; e.J = N;
+    return linear_loss_impl(x, ldx, w, e, M, N, K, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_ce_fwd(const float *x, int ldx, const float *w, const float *bias, const int64_t *label,
+                                   int label_rows, const float *drow_dev, int rows_per_group, float *dlogits, int ldy,
+                                   float *logits, float *row, int M, int N, int K, mvae_stream_t stream) {
+    if (!x || !w || !label || !drow_dev || !dlogits || !row || M <= 0 || N <= 0 || N > 32 || K <= 0 || ldx < K ||
+        ldy < N || label_rows <= 0 || rows_per_group <= 0)
+        return MVAE_ERR_ARG;
+    EpRowCe e;
+    e.dlogits = dlogits; e.ld = ldy; e.logits = logits; e.bias = bias;
+    e.label = label; e.label_rows = label_rows; e.drow = drow_dev; e.rows_per_group = rows_per_group;
+    e.row = row; e.I = M; e.J = N;
+    return linear_loss_impl(x, ldx, w, e, M, N, K, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx,

@@ -12,16 +12,7 @@
 
 namespace {
 
-// clamp(x,0) - x*t + log(1 + exp(-|x|))   (mnist/train.py:73-74)
-__device__ __forceinline__ float bce_elem(float x, float t) {
-    return fmaxf(x, 0.f) - x * t + logf(1.0f + expf(-fabsf(x)));
-}
-// autograd of the expression above, term by term: 1[x>=0] - t - sign(x) * e/(1+e), e = exp(-|x|)
-__device__ __forceinline__ float bce_grad(float x, float t) {
-    const float e = expf(-fabsf(x));
-    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-    return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e / (1.0f + e));
-}
+// bce_elem / bce_grad: common.h (shared with the Linear epilogue that folds this term, gemm_core.h EpRowBce)
 
 struct BceArgs {
     const float *logits, *target, *colw, *drow;
@@ -143,6 +134,7 @@ __global__ __launch_bounds__(1024) void group_sums_kernel(const float *rows, con
 // Block 0 does the sums and advances the step's Philox counter; every block helps clear `zero` (the shared
 // latent-gradient buffer the decoders' first layers accumulate into).
 struct ElboParts { mvae_elbo_part p[MVAE_ELBO_MAX_PARTS]; int n; };
+constexpr int ELBO_MAX_GROUPS = 1024;      // all parts' groups together: one thread of block 0 each
 
 __global__ __launch_bounds__(1024) void elbo_reduce_kernel(ElboParts parts, float *elbo, int T, float *zero, size_t zero_n,
                                                            uint64_t *counter, uint64_t counter_inc) {
@@ -157,34 +149,81 @@ __global__ __launch_bounds__(1024) void elbo_reduce_kernel(ElboParts parts, floa
     // every (part, group) sum is one wave's job (16 waves take them round-robin: lane-strided partial sums in a
     // fixed order, then the wave reduction), parked in LDS; thread 0 then adds them up part by part, group by
     // group -- one barrier instead of two per group (7 groups of 512 rows: 13 -> 4 us on the MNIST step's
-    // critical path)
+    // critical path).  A LONG group (the per-32-column partials of a folded Bernoulli term: 512 rows x 25) is
+    // spread over all 16 waves instead -- one wave would walk it as 200 dependent round trips.
+    constexpr int LONG_GROUP = 2048;
     __shared__ float gsum[MVAE_ELBO_MAX_PARTS * MVAE_ELBO_MAX_TERMS];
+    __shared__ float wsum[MVAE_ELBO_MAX_PARTS * MVAE_ELBO_MAX_TERMS][16];
     __shared__ float acc[MVAE_ELBO_MAX_TERMS + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int slot = 0;
+    int slot = 0, turn = 0;
+    bool any_long = false;
     for (int q = 0; q < parts.n; ++q) {
         const mvae_elbo_part &p = parts.p[q];
         if (p.rows_per_group == 1) continue;         // a table of ready sums: read directly below
+        const bool spread = p.rows_per_group > LONG_GROUP;
+        any_long |= spread;
         for (int g = 0; g < p.groups; ++g, ++slot) {
-            if ((slot & 15) != wave) continue;
             const float *r = p.rows + (size_t)g * p.rows_per_group;
             float s = 0.f;
+            if (spread) {
+                const int chunk = (((p.rows_per_group + 15) / 16) + 63) & ~63;
+                const int lo = wave * chunk, hi = min(p.rows_per_group, lo + chunk);
+#pragma unroll 4
+                for (int i = lo + lane; i < hi; i += 64) s += r[i];
+                s = wave_sum(s);
+                if (lane == 0) wsum[slot][wave] = s;
+                continue;
+            }
+            if ((turn++ & 15) != wave) continue;
             for (int i = lane; i < p.rows_per_group; i += 64) s += r[i];
             s = wave_sum(s);
             if (lane == 0) gsum[slot] = s;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int t = 0; t <= T; ++t) acc[t] = 0.f;
+    if (any_long) {                                   // block-uniform
         slot = 0;
         for (int q = 0; q < parts.n; ++q) {
             const mvae_elbo_part &p = parts.p[q];
+            if (p.rows_per_group == 1) continue;
+            for (int g = 0; g < p.groups; ++g, ++slot)
+                if (p.rows_per_group > LONG_GROUP && threadIdx.x == (slot & 1023)) {
+                    float s = 0.f;
+                    for (int w = 0; w < 16; ++w) s += wsum[slot][w];
+                    gsum[slot] = s;
+                }
+        }
+        __syncthreads();
+    }
+    // the weighted group sums, one thread per (part, group): every coefficient / term-index / ready-sum load is in
+    // flight at once (thread 0 alone walked them as a chain of dependent global loads -- most of this launch's time)
+    __shared__ float val[ELBO_MAX_GROUPS];
+    __shared__ int term[ELBO_MAX_GROUPS];
+    {
+        int idx = 0;
+        slot = 0;
+        for (int q = 0; q < parts.n; ++q) {
+            const mvae_elbo_part &p = parts.p[q];
+            const int g = (int)threadIdx.x - idx;
+            if (g >= 0 && g < p.groups) {
+                const float sum = p.rows_per_group == 1 ? p.rows[g] : gsum[slot + g];
+                val[idx + g] = sum * (p.coef ? p.coef[g] : 1.f);
+                term[idx + g] = p.term_of ? p.term_of[g] : p.first_term + g;
+            }
+            idx += p.groups;
+            if (p.rows_per_group != 1) slot += p.groups;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 0; t <= T; ++t) acc[t] = 0.f;
+        int idx = 0;
+        for (int q = 0; q < parts.n; ++q) {           // part by part, group by group: the order of the separate launches
             float part_total = 0.f;
-            for (int g = 0; g < p.groups; ++g) {
-                const float v = (p.rows_per_group == 1 ? p.rows[g] : gsum[slot++]) * (p.coef ? p.coef[g] : 1.f);
-                acc[p.term_of ? p.term_of[g] : p.first_term + g] += v;
-                part_total += v;
+            for (int g = 0; g < parts.p[q].groups; ++g, ++idx) {
+                acc[term[idx]] += val[idx];
+                part_total += val[idx];
             }
             acc[T] += part_total;
         }
@@ -255,12 +294,15 @@ MVAE_EXPORT int mvae_elbo_reduce(const mvae_elbo_part *parts, int n_parts, float
         return MVAE_ERR_ARG;
     ElboParts ps;
     ps.n = n_parts;
+    long total_groups = 0;
     for (int q = 0; q < n_parts; ++q) {
         ps.p[q] = parts[q];
         if (!ps.p[q].rows || ps.p[q].groups <= 0 || ps.p[q].rows_per_group <= 0) return MVAE_ERR_ARG;
         if (!ps.p[q].term_of && (ps.p[q].first_term < 0 || ps.p[q].first_term + ps.p[q].groups > T)) return MVAE_ERR_ARG;
         if (ps.p[q].rows_per_group > 1 && ps.p[q].groups > MVAE_ELBO_MAX_TERMS) return MVAE_ERR_ARG;
+        total_groups += ps.p[q].groups;
     }
+    if (total_groups > ELBO_MAX_GROUPS) return MVAE_ERR_ARG;
     size_t blocks = zero ? (zero_n / 4 + 1023) / 1024 : 1;
     if (blocks < 1) blocks = 1;
     if (blocks > 256) blocks = 256;

@@ -163,6 +163,11 @@ class _StepBase(object):
         self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
         self.wgrad_on_side = os.environ.get('MVAE_WGRAD_SIDE', '1') != '0' and self.side is not None
         self.use_ingest = os.environ.get('MVAE_INGEST', '1') != '0'      # replay(): batch + tables in one launch
+        # a decoder that ends in a plain Linear: that launch also evaluates the reconstruction term (the logits never
+        # reach memory); MVAE_LOSS_FOLD=0: Linear, then the loss kernel.  'image' / 'label': only that decoder.
+        fold = os.environ.get('MVAE_LOSS_FOLD', '1')
+        self.fold_image = fold in ('1', 'image')
+        self.fold_label = fold in ('1', 'label')
         # one-graph data-parallel step: buckets 0 and 1 go out from the SIDE stream (MVAE_DP_SIDE_LAUNCH=0: from the
         # main stream behind a full join)
         self.dp_side_launch = os.environ.get('MVAE_DP_SIDE_LAUNCH', '1') != '0'
@@ -601,6 +606,51 @@ class BimodalStep(_StepBase):
         keep.append(g)
         return g[0], g[1], rows_img, rows_lbl, keep
 
+    # ------------------------------------------------------------------ reconstruction term inside the last Linear
+    def _fold_plan(self, plan, kind):
+        """Can the stack's last launch carry its reconstruction term (``kind``: 'bce' or 'class')?"""
+        op = plan[-1]
+        if not (op.kind == 'lin' and not op.act and op.drop == 0):
+            return False
+        return kind == 'bce' or op.mod.weight.shape[0] <= 32
+
+    def _decode_with_loss(self, plan, zin, groups, kind, target, drow, which):
+        """Decoder forward with the reconstruction term folded into the last Linear's launch.
+        Returns (d loss / d logits, tape, loss rows, rows per group of the loss rows)."""
+        B = self.B
+        N = plan[-1].mod.weight.shape[0]
+        if kind == 'bce':
+            nparts = K.bce_partials(N)
+            rows = torch.empty(groups * B * nparts, dtype=torch.float32, device=self.dev)
+            tgt = target.reshape(B, N)
+
+            def fold(x, w, b, out, logits=None, rows=rows):
+                K.linear_bce_fwd(x, w, b, tgt, drow, out, rows, B, B, logits=logits)
+            rpg = B * nparts
+        else:
+            rows = torch.empty(groups * B, dtype=torch.float32, device=self.dev)
+
+            def fold(x, w, b, out, logits=None, rows=rows):
+                K.linear_ce_fwd(x, w, b, target, drow, out, rows, B, B, logits=logits)
+            rpg = B
+        dlog, tape = L.forward_tape(plan, zin, groups=groups, loss_fold=fold)
+        self._carry.setdefault('folded', {})[which] = (fold, plan[-1], tape[-1][0], dlog.shape, rows.numel())
+        return dlog, tape, rows, rpg
+
+    def recon_logits(self):
+        """(image logits, label logits) of the step that just ran.  A folded decoder never stored them: its last
+        launch is re-issued -- same kernel, same accumulators -- with the optional logits output (scratch buffers for
+        the rest).  The parity tests use this to find logits that are EXACTLY zero."""
+        logits_lbl, _, _, logits_img, _, _ = self._carry['keep'][-1]
+        out = {'image': logits_img, 'label': logits_lbl}
+        for which, (fold, op, x, shape, nrows) in self._carry.get('folded', {}).items():
+            w, b = L._lin_weights(op)
+            lg = torch.empty(shape, dtype=torch.float32, device=self.dev)
+            fold(x, w.detach(), None if b is None else b.detach(), torch.empty_like(lg), logits=lg,
+                 rows=torch.empty(nrows, dtype=torch.float32, device=self.dev))
+            out[which] = lg
+        return out['image'], out['label']
+
     # ------------------------------------------------------------------ host-side setup per step
     def set_coefficients(self, annealing_factor):
         B = float(self.B)
@@ -674,19 +724,28 @@ class BimodalStep(_StepBase):
         l0, nl = self.lbl_terms
         if self.pair_dec:
             g_img, g_lbl, rows_img, rows_lbl, keep_dec = self._decoders_paired(z, image, label, lbl_in)
+            rpg_img = rpg_lbl = B
         else:
             # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
             with self._branch():
                 zl = z[l0:l0 + nl].reshape(nl * B, D)
-                logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
-                rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
-                dlog_lbl = torch.empty_like(logits_lbl)
-                if m.LABEL_KIND == 'class':
-                    K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
-                             rows_per_group=B, label_rows=B)
+                lbl_kind = 'class' if m.LABEL_KIND == 'class' else 'bce'
+                rpg_lbl = B
+                if self.fold_label and self._fold_plan(m.label_decoder.plan(), lbl_kind):
+                    logits_lbl = None
+                    dlog_lbl, tape_dl, rows_lbl, rpg_lbl = self._decode_with_loss(
+                        m.label_decoder.plan(), zl, nl, lbl_kind, label if lbl_kind == 'class' else lbl_in,
+                        self.coef[1, l0:l0 + nl], 'label')
                 else:
-                    K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
-                                     dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
+                    logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
+                    rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
+                    dlog_lbl = torch.empty_like(logits_lbl)
+                    if m.LABEL_KIND == 'class':
+                        K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
+                                 rows_per_group=B, label_rows=B)
+                    else:
+                        K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
+                                         dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
                 wl = self._deferred()
                 if self.split_dz:
                     # this decoder's latent gradient goes to its OWN buffer (terms l0 .. l0+nl-1), on this stream
@@ -709,26 +768,35 @@ class BimodalStep(_StepBase):
                 self._launch_deferred(wl, self.wg_side)
             # ---- image branch (this stream)
             zi = z[i0:i0 + ni].reshape(ni * B, D)
-            logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
+            fold_img = self.fold_image and self._fold_plan(m.image_decoder.plan(), 'bce')
+            rpg_img = B
+            if fold_img:
+                logits_img = None
+                dlog_img, tape_di, rows_img, rpg_img = self._decode_with_loss(
+                    m.image_decoder.plan(), zi, ni, 'bce', image, self.coef[0, i0:i0 + ni], 'image')
+            else:
+                logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
             if self.has_bn and ni < T:
                 # the reference also decodes the image for the label-only call: no loss, but its
                 # BatchNorm running statistics advance (celeba/train.py:195)
                 L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni,
                                stats_only=True)
-            P = logits_img[0].numel()
-            li = logits_img.reshape(ni * B, P)
-            rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
-            dlog_img = torch.empty_like(li)
-            K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
-                             rows_per_group=B, target_rows=B)
+            if not fold_img:
+                P = logits_img[0].numel()
+                li = logits_img.reshape(ni * B, P)
+                rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
+                dlog_img = torch.empty_like(li)
+                K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
+                                 rows_per_group=B, target_rows=B)
+                dlog_img = dlog_img.reshape(logits_img.shape)
             wi = self._deferred()
             if self.split_dz:
                 dz_img = torch.empty(ni * B, D, dtype=torch.float32, device=self.dev)
-                L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape), groups=ni,
+                L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img, groups=ni,
                                 need_input_grad=True, input_grad_out=dz_img, deferred=wi)
                 g_img = dz_img
             else:
-                g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img.reshape(logits_img.shape),
+                g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img,
                                         groups=ni, defer_input_grad=True, deferred=wi)
             if ev_lbl is not None and isinstance(wi, L.WgradBatch):
                 # The image side is the longer chain and the label side has slack (MNIST: ~225 vs ~150 us of kernels):
@@ -757,8 +825,8 @@ class BimodalStep(_StepBase):
         # ---- ELBO per term and total (mnist/train.py:57-58,214), the cleared dz and the step's Philox counter
         #      advance: one bookkeeping launch
         elbo_parts = [(kl, self.coef[2], None, 0, T, B),
-                      (rows_img, self.coef[0, i0:i0 + ni], None, i0, ni, B),
-                      (rows_lbl, self.coef[1, l0:l0 + nl], None, l0, nl, B)]
+                      (rows_img, self.coef[0, i0:i0 + ni], None, i0, ni, rpg_img),
+                      (rows_lbl, self.coef[1, l0:l0 + nl], None, l0, nl, rpg_lbl)]
         counter_inc = 2 if self.has_dropout else 1
         if self.split_dz and not self.pair_dec:
             # Each decoder's backward ran to its input on its own stream into its own latent-gradient buffer;

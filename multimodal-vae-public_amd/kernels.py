@@ -70,6 +70,43 @@ def linear_fwd(x, w, bias, pre=None, act=None, mask=None, mask_scale=1.0, ldx=No
                                      _ptr(mask), mask_scale, M, N, K, ws, wsb, _stream()), 'mvae_linear_fwd')
 
 
+def bce_partials(N):
+    """Partial sums per row that ``linear_bce_fwd`` writes for N columns."""
+    return (N + 31) // 32
+
+
+def linear_bce_fwd(x, w, bias, target, drow, dlogits, partial, rows_per_group, target_rows, logits=None):
+    """Last Linear of a decoder + its Bernoulli term: dlogits[M,N] and partial[M, bce_partials(N)] (a row's
+    term = the sum of its partials); the logits are stored only when ``logits`` is given."""
+    _need_gpu(x, w, bias, target, drow, dlogits, partial, logits)
+    M, K = x.shape
+    N = w.shape[0]
+    if target.dim() != 2 or target.stride(1) != 1 or target.shape[1] != N or target.shape[0] < target_rows:
+        raise RuntimeError('target must be [>= target_rows, N] with unit column stride')
+    if partial.numel() < M * bce_partials(N) or not partial.is_contiguous():
+        raise RuntimeError('partial must hold M * ceil(N / 32) floats')
+    if logits is not None and logits.stride() != dlogits.stride():
+        raise RuntimeError('logits and dlogits must share a layout')
+    check(_lib.lib().mvae_linear_bce_fwd(_ptr(x), x.stride(0), _ptr(w), _ptr(bias), _ptr(target), target_rows,
+                                         target.stride(0), _ptr(drow), rows_per_group, _ptr(dlogits),
+                                         dlogits.stride(0), _ptr(logits), _ptr(partial), M, N, K, _stream()),
+          'mvae_linear_bce_fwd')
+
+
+def linear_ce_fwd(x, w, bias, label, drow, dlogits, row, rows_per_group, label_rows, logits=None):
+    """Last Linear of a decoder (N <= 32 classes) + its categorical term: row[M] and dlogits[M,N]."""
+    _need_gpu(x, w, bias, label, drow, dlogits, row, logits)
+    M, K = x.shape
+    N = w.shape[0]
+    if label.dtype != torch.int64 or not label.is_contiguous() or label.numel() < label_rows:
+        raise RuntimeError('label must be a contiguous int64 vector of at least label_rows entries')
+    if logits is not None and logits.stride() != dlogits.stride():
+        raise RuntimeError('logits and dlogits must share a layout')
+    check(_lib.lib().mvae_linear_ce_fwd(_ptr(x), x.stride(0), _ptr(w), _ptr(bias), _ptr(label), label_rows,
+                                        _ptr(drow), rows_per_group, _ptr(dlogits), dlogits.stride(0), _ptr(logits),
+                                        _ptr(row), M, N, K, _stream()), 'mvae_linear_ce_fwd')
+
+
 def linear_dgrad(dy, w, dx, pre_in=None, mask=None, mask_scale=1.0, accumulate=False):
     _need_gpu(dy, w, dx, pre_in, mask)
     M, N = dy.shape

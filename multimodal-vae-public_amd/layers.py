@@ -253,15 +253,20 @@ def _lin_weights(op):
 
 
 def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, final_out=None,
-                 bn_updates_dev=None, stats_only=False):
+                 bn_updates_dev=None, stats_only=False, loss_fold=None):
     """Run the plan.  Returns (output, tape); tape is None when not training.
     ``final_out``: preallocated [rows, N] destination for a stack that ends in a plain Linear
     (celeba19 collects its 18 attribute decoders' logits in one buffer).  ``bn_updates_dev``:
     device int32[1] overriding ``bn_updates`` (number of running-statistics updates).
     ``stats_only``: the pass exists only for its BatchNorm running-statistics side effect -- stop at
     the last BatchNorm, which computes its statistics without writing an output; returns
-    (None, None)."""
+    (None, None).  ``loss_fold(x, w, b, out)``: the stack ends in a plain Linear whose only consumer is a
+    reconstruction term -- the callable launches Linear + term in one kernel (K.linear_bce_fwd / K.linear_ce_fwd)
+    and fills ``out`` [rows, N] with d loss / d logits, which is then what this function returns in place of the
+    logits (and what ``backward_tape`` takes as ``g``)."""
     masks = list(masks) if masks is not None else []
+    if loss_fold is not None and not (plan[-1].kind == 'lin' and not plan[-1].act and training):
+        raise RuntimeError('loss_fold needs a training-mode stack that ends in a plain Linear')
     tape = [] if training else None
     h = x
     last_op = plan[-1]
@@ -292,7 +297,10 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
                     pre = final_out.reshape(M, N)
                 else:
                     pre = torch.empty(M, N, dtype=torch.float32, device=h.device)
-                K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, None)
+                if loss_fold is not None and op is last_op:
+                    loss_fold(h, w.detach(), None if b is None else b.detach(), pre)
+                else:
+                    K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, None)
                 saved = (h, None, None)
                 h = pre
         elif op.kind in ('conv', 'convT'):

@@ -70,7 +70,7 @@ def hits_bce_jump(eng):
     is a few ulps of its bias from zero can round to 0.0 on one side and not on the other -- then ONE
     d loss / d logit differs by lambda/(2B) and every gradient behind it by ~1e-2, which says nothing about
     the kernels.  Parity cases whose HIP logits contain an exact zero are re-drawn with the next seed."""
-    logits_lbl, _, _, logits_img, _, _ = eng._carry['keep'][-1]
+    logits_img, logits_lbl = eng.recon_logits()      # a decoder whose loss rides its last Linear re-issues that launch
     return bool((logits_img == 0).any().item()) or (logits_lbl.dtype == torch.float32 and eng.model.LABEL_KIND != 'class'
                                                      and bool((logits_lbl == 0).any().item()))
 

@@ -564,6 +564,81 @@ def test_cross_entropy_rows():
     assert_close(dl, x.grad, 'ce grad')
 
 
+# the last Linear of a decoder with its reconstruction term in the same launch (mnist/model.py:104,146 ->
+# mnist/train.py:47-52): against Linear -> term on the CPU, and bit for bit against the two-launch HIP route on the
+# logits the fused launch itself reports
+FOLD_SHAPES = [(1536, 784, 512, 3), (24, 784, 512, 3), (96, 18, 512, 3), (1024, 784, 512, 2), (74, 50, 20, 2),
+               (3, 5, 7, 1), (512, 33, 64, 1)]
+
+
+@pytest.mark.parametrize('M,N,Kd,groups', FOLD_SHAPES)
+@pytest.mark.parametrize('bias', [True, False])
+def test_linear_with_bernoulli_term(M, N, Kd, groups, bias):
+    rpg = M // groups
+    x = g(M, Kd, seed=140)
+    w = (g(N, Kd, seed=141) / Kd ** 0.5).requires_grad_()
+    b = (g(N, seed=142) * 0.1).requires_grad_() if bias else None
+    t = torch.rand(rpg, N, generator=torch.Generator().manual_seed(143))
+    drow = torch.tensor([0.5, 0.0, 2.0][:groups])
+    xr = x.clone().requires_grad_()
+    logits_ref = F.linear(xr, w, b)
+    logits_ref.retain_grad()
+    rows_ref = OF.binary_cross_entropy_with_logits(logits_ref, t.repeat(groups, 1)).sum(1)
+    (rows_ref * drow.repeat_interleave(rpg)).sum().backward()
+    nparts = K.bce_partials(N)
+    dl = torch.empty(M, N, device=DEV); lg = torch.empty(M, N, device=DEV)
+    part = torch.full((M * nparts,), float('nan'), device=DEV)
+    xd, wd, bd, td, dd = dev(x), dev(w.detach()), dev(None if b is None else b.detach()), dev(t), dev(drow)
+    K.linear_bce_fwd(xd, wd, bd, td, dd, dl, part, rpg, rpg, logits=lg)
+    assert_close(lg, logits_ref.detach(), 'folded logits', tol=1e-5)
+    assert_close(part.reshape(M, nparts).sum(1), rows_ref.detach(), 'folded bce rows', tol=1e-5)
+    assert_close(dl, logits_ref.grad, 'folded d loss / d logits')
+    # the two-launch route on the same logits: the gradient bit for bit, the row sums to summation order
+    rows2 = torch.empty(M, device=DEV); dl2 = torch.empty(M, N, device=DEV)
+    K.bce_rowsum_fwd(lg, td, rows2, drow=dd, dlogits=dl2, rows_per_group=rpg, target_rows=rpg)
+    assert torch.equal(dl, dl2)
+    assert_close(part.reshape(M, nparts).sum(1), rows2, 'folded vs kernel rows', tol=1e-6)
+    # without the logits output (the step's form): the same bits
+    dl3 = torch.empty(M, N, device=DEV); part3 = torch.empty(M * nparts, device=DEV)
+    K.linear_bce_fwd(xd, wd, bd, td, dd, dl3, part3, rpg, rpg)
+    assert torch.equal(dl, dl3) and torch.equal(part, part3)
+
+
+@pytest.mark.parametrize('M,N,Kd,groups', [(1536, 10, 512, 3), (24, 10, 512, 2), (70, 32, 20, 2), (5, 1, 7, 1)])
+def test_linear_with_categorical_term(M, N, Kd, groups):
+    rpg = M // groups
+    x = g(M, Kd, seed=150)
+    w = (g(N, Kd, seed=151) / Kd ** 0.5 * 3).requires_grad_()
+    b = (g(N, seed=152) * 0.1).requires_grad_()
+    y = torch.randint(0, N, (rpg,), generator=torch.Generator().manual_seed(153))
+    drow = torch.tensor([0.7, 1.3, 0.0][:groups])
+    logits_ref = F.linear(x, w, b)
+    logits_ref.retain_grad()
+    rows_ref = OF.cross_entropy(logits_ref, y.repeat(groups)).sum(1)
+    (rows_ref * drow.repeat_interleave(rpg)).sum().backward()
+    dl = torch.empty(M, N, device=DEV); lg = torch.empty(M, N, device=DEV)
+    rows = torch.full((M,), float('nan'), device=DEV)
+    K.linear_ce_fwd(dev(x), dev(w.detach()), dev(b.detach()), dev(y), dev(drow), dl, rows, rpg, rpg, logits=lg)
+    assert_close(lg, logits_ref.detach(), 'folded logits', tol=1e-5)
+    assert_close(rows, rows_ref.detach(), 'folded ce rows', tol=1e-5)
+    assert_close(dl, logits_ref.grad, 'folded ce grad')
+    rows2 = torch.empty(M, device=DEV); dl2 = torch.empty(M, N, device=DEV)
+    K.ce_fwd(lg, dev(y), rows2, drow=dev(drow), dlogits=dl2, rows_per_group=rpg, label_rows=rpg)
+    assert_close(rows, rows2, 'folded vs kernel ce rows', tol=1e-6)
+    assert_close(dl, dl2, 'folded vs kernel ce grad', tol=1e-6)
+
+
+def test_linear_with_categorical_term_flags_a_bad_label():
+    M, N, Kd = 8, 10, 16
+    y = torch.tensor([0, 3, 10, 9, -1, 2, 5, 7])
+    dl = torch.empty(M, N, device=DEV); rows = torch.empty(M, device=DEV)
+    K.linear_ce_fwd(dev(g(M, Kd, seed=154)), dev(g(N, Kd, seed=155)), None, dev(y), torch.ones(1, device=DEV), dl, rows,
+                    M, M)
+    bad = torch.tensor([False, False, True, False, True, False, False, False])
+    assert torch.equal(torch.isnan(rows).cpu(), bad)
+    assert torch.equal(torch.isnan(dl).all(1).cpu(), bad) and not torch.isnan(dl[~bad.to(DEV)]).any()
+
+
 def test_group_sums():
     rows = g(3 * 50, seed=105)
     coef = torch.tensor([0.5, 0.0, 2.0])

@@ -31,7 +31,8 @@ def main():
     eng.step(image.cuda(), label.cuda(), 0.5, noise=noise)
     torch.cuda.synchronize()
     z, kl, rows_lbl, g_lbl, rows_img, g_img, lbl_in, keep_dec = eng._carry['keep']
-    logits_lbl, tape_dl, dlog_lbl, logits_img, tape_di, dlog_img = keep_dec
+    _, tape_dl, dlog_lbl, _, tape_di, dlog_img = keep_dec
+    logits_img, logits_lbl = eng.recon_logits()
     B = batch
     zc = z.cpu()
     coef = eng.coef.cpu()

@@ -31,7 +31,7 @@ g_replay = model.arena.grad.clone()
 noise = {'eps': [eng.noise[eng.ref_order.index(r)].cpu() for r in range(3)], 'mask': [None] * 3}
 if eng.drop_masks is not None:
     noise['mask'][0], noise['mask'][1] = eng.drop_masks[0].cpu(), eng.drop_masks[1].cpu()
-logits_lbl, _, _, logits_img, _, _ = eng._carry['keep'][-1]
+logits_img, logits_lbl = eng.recon_logits()
 li_replay = logits_img.clone()
 
 _, model2, _ = build_pair(kind, wseed)
@@ -39,7 +39,7 @@ eng2 = BimodalStep(model2, batch, 1.0, lam, seed=77)
 eng2.step(image.to(DEV), label.to(DEV), 0.5, noise=noise)
 torch.cuda.synchronize()
 g_eager = model2.arena.grad.clone()
-li_eager = eng2._carry['keep'][-1][3]
+li_eager = eng2.recon_logits()[0]
 
 total, terms, lat = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, lam, 0.5)
 total.backward()

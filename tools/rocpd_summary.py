@@ -59,7 +59,28 @@ def timeline(path, tail=0.5):
             len(gaps), sum(gaps) / 1e3, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, gaps[-1] / 1e3))
 
 
-if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == '--timeline':
+def one_step(path, marker='ingest_kernel'):
+    """One graph-replayed step, kernel by kernel: the shortest interval between two consecutive ``marker`` launches
+    (once per replay) -- start offset, duration, queue / stream column if the database has one, name."""
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info('kernels')")]
+    lane_col = next((k for k in ('stream_id', 'queue_id', 'stream', 'queue') if k in cols), None)
+    q = 'select start, end, name%s from kernels order by start' % (', ' + lane_col if lane_col else '')
+    rows = c.execute(q).fetchall()
+    marks = [i for i, r in enumerate(rows) if marker in r[2]]
+    if len(marks) < 3:
+        print('# no %s launches: columns %s' % (marker, cols)); return
+    a, b = min(zip(marks[:-1], marks[1:]), key=lambda ab: rows[ab[1]][0] - rows[ab[0]][0])
+    t0 = rows[a][0]
+    print('# one step (%d kernels, %.1f us between two %s launches); columns: offset_us dur_us %s name' % (
+        b - a, (rows[b][0] - t0) / 1e3, marker, lane_col or '-'))
+    for r in rows[a:b]:
+        print('%8.1f %7.1f %6s  %s' % ((r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, r[3] if lane_col else '-', short(r[2])[:110]))
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == '--step':
+    one_step(sys.argv[1], *(sys.argv[3:4]))
+elif __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == '--timeline':
     timeline(sys.argv[1])
 elif __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == '--pmc'):
     main(sys.argv[1])
