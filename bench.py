@@ -40,15 +40,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# a single-process run: two hardware queues, one per branch of the step's DAG (multimodal-vae-public_amd/_runtime.py
-# -- the package applies the same setting at import; repeated here because it must precede the first HIP call)
-_HWQ_SET_HERE = False
-if os.environ.get('MVAE_RUNTIME_ENV', '1') != '0' and int(os.environ.get('WORLD_SIZE', '1') or 1) == 1 \
-        and 'GPU_MAX_HW_QUEUES' not in os.environ:
-    os.environ['GPU_MAX_HW_QUEUES'] = '2'
-    os.environ['_MVAE_HWQ_AUTO'] = str(os.getpid())
-    _HWQ_SET_HERE = True
-
 import torch  # noqa: E402
 
 DEFAULT_BATCH = {'mnist': 512, 'fashionmnist': 1024, 'celeba': 256, 'celeba19': 256}
@@ -416,9 +407,6 @@ def spawn_ranks(n, argv=None):
     cmd += list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL across processes needs dmabuf IPC on this driver
-    if _HWQ_SET_HERE:
-        env.pop('GPU_MAX_HW_QUEUES', None)                 # this process' single-rank setting is not the ranks'
-        env.pop('_MVAE_HWQ_AUTO', None)
     return subprocess.call(cmd, env=env)
 
 
@@ -531,7 +519,7 @@ def main():
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'runtime_env': {k: os.environ[k] for k in ('GPU_MAX_HW_QUEUES',) if k in os.environ},
+        'runtime_env': {k: os.environ[k] for k in ('GPU_MAX_HW_QUEUES',) if k in os.environ},   # only if the caller set it
         'config': {'workload': '%s MVAE train step, n-latents %d, batch %d per GPU' % (kind, N_LATENTS[kind], batch),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                    'launch': 'eager' if args.no_graph else 'hipGraph replay', 'final_loss': round(loss, 3)},

@@ -10,7 +10,6 @@ hyphen) or ``importlib.import_module('multimodal-vae-public_amd')``.
     mvae_amd.optim.FusedAdam                                          one-launch Adam over the arena
     mvae_amd.parallel.DataParallel                                    RCCL gradient all-reduce
 """
-from . import _runtime  # noqa: F401  (first: runtime settings that must precede the first HIP call)
 from . import _lib, kernels, arena, layers, functional, base, engine, optim, parallel  # noqa: F401
 from . import mnist, fashionmnist, celeba, celeba19  # noqa: F401
 
