@@ -163,6 +163,14 @@ class _StepBase(object):
         self.poe_draw = os.environ.get('MVAE_POE_DRAW', '1') != '0'      # eps drawn inside the PoE launch
         self.wgrad_on_side = os.environ.get('MVAE_WGRAD_SIDE', '1') != '0' and self.side is not None
         self.use_ingest = os.environ.get('MVAE_INGEST', '1') != '0'      # replay(): batch + tables in one launch
+        # at a fork, issue the MAIN stream's continuation (the longer, image-side chain) BEFORE the side branch: the
+        # graph keeps the successor that was recorded first on its producer's queue (0-3 us behind it) and reaches
+        # the other over a cross-queue edge (9-12 us).  MVAE_MAIN_FIRST=0: side branch first (rounds 1-2).
+        self.main_first = os.environ.get('MVAE_MAIN_FIRST', '1') != '0'
+        # ... at the DECODER fork only when the image decoder is a conv stack (its chain is several times the label
+        # side's).  Two equal MLP decoders (MNIST): the side branch also carries both decoders' weight gradients and
+        # is the one that must not start late.  MVAE_MAIN_FIRST_DEC=0|1 overrides.
+        self.main_first_dec = os.environ.get('MVAE_MAIN_FIRST_DEC', 'auto')
         # a decoder that ends in a plain Linear: that launch also evaluates the reconstruction term (the logits never
         # reach memory); MVAE_LOSS_FOLD=0: Linear, then the loss kernel.  'image' / 'label': only that decoder.
         fold = os.environ.get('MVAE_LOSS_FOLD', '1')
@@ -181,16 +189,29 @@ class _StepBase(object):
         self._forked = False
 
     @contextlib.contextmanager
-    def _branch(self):
-        """Run the body on the side stream, ordered after everything launched so far.  Tensors it
-        allocates must stay referenced until the next fork (``_carry``)."""
+    def _branch(self, after=None):
+        """Run the body on the side stream, ordered after everything launched so far -- or, with ``after`` (an event
+        from ``_fork_point``), after that point only: the main stream's own continuation can then be issued FIRST.
+        Tensors the body allocates must stay referenced until the next fork (``_carry``)."""
         if self.side is None:
             yield
             return
-        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        if after is None:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        else:
+            self.side.wait_event(after)
         self._forked = True
         with torch.cuda.stream(self.side):
             yield
+
+    def _fork_point(self):
+        """An event at the current end of the main stream (None without a side stream or with MVAE_MAIN_FIRST=0)."""
+        if self.side is None or not self.main_first:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        self._carry.setdefault('fork_events', []).append(ev)
+        return ev
 
     def _deferred(self):
         """The list a backward chain queues its weight-gradient launches in (None: launch inline).  Default:
@@ -697,9 +718,15 @@ class BimodalStep(_StepBase):
         n_up = 2  # each encoder is called twice per step in the reference
         # ---- encoders: label on the side stream, image on this one
         lbl_in = label if m.LABEL_KIND == 'class' else label.float().contiguous()
-        with self._branch():
-            heads_lbl, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
-            self._early_counter()
+
+        def encode_label(after=None):
+            with self._branch(after):
+                heads, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
+                self._early_counter()
+            return heads
+        fork = self._fork_point()
+        if fork is None:
+            heads_lbl = encode_label()
         if self.has_dropout:
             h, c['tape_trunk'] = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
             hd = torch.empty(2 * B, h.shape[1], dtype=torch.float32, device=self.dev)
@@ -709,6 +736,8 @@ class BimodalStep(_StepBase):
         else:
             heads_img, c['tape_img'] = L.forward_tape(m.image_encoder.plan(), image, bn_updates=n_up)
             img_experts = [heads_img]
+        if fork is not None:
+            heads_lbl = encode_label(fork)
         self._join()
         experts = img_experts + [heads_lbl]
         mus = [e[:, :D] for e in experts]
@@ -726,78 +755,93 @@ class BimodalStep(_StepBase):
             g_img, g_lbl, rows_img, rows_lbl, keep_dec = self._decoders_paired(z, image, label, lbl_in)
             rpg_img = rpg_lbl = B
         else:
-            # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
-            with self._branch():
-                zl = z[l0:l0 + nl].reshape(nl * B, D)
-                lbl_kind = 'class' if m.LABEL_KIND == 'class' else 'bce'
-                rpg_lbl = B
-                if self.fold_label and self._fold_plan(m.label_decoder.plan(), lbl_kind):
-                    logits_lbl = None
-                    dlog_lbl, tape_dl, rows_lbl, rpg_lbl = self._decode_with_loss(
-                        m.label_decoder.plan(), zl, nl, lbl_kind, label if lbl_kind == 'class' else lbl_in,
-                        self.coef[1, l0:l0 + nl], 'label')
-                else:
-                    logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
-                    rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
-                    dlog_lbl = torch.empty_like(logits_lbl)
-                    if m.LABEL_KIND == 'class':
-                        K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
-                                 rows_per_group=B, label_rows=B)
+            def label_branch(after=None):
+                # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
+                with self._branch(after):
+                    zl = z[l0:l0 + nl].reshape(nl * B, D)
+                    lbl_kind = 'class' if m.LABEL_KIND == 'class' else 'bce'
+                    rpg_lbl = B
+                    if self.fold_label and self._fold_plan(m.label_decoder.plan(), lbl_kind):
+                        logits_lbl = None
+                        dlog_lbl, tape_dl, rows_lbl, rpg_lbl = self._decode_with_loss(
+                            m.label_decoder.plan(), zl, nl, lbl_kind, label if lbl_kind == 'class' else lbl_in,
+                            self.coef[1, l0:l0 + nl], 'label')
                     else:
-                        K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
-                                         dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
-                wl = self._deferred()
-                if self.split_dz:
-                    # this decoder's latent gradient goes to its OWN buffer (terms l0 .. l0+nl-1), on this stream
-                    dz_lbl = torch.empty(nl * B, D, dtype=torch.float32, device=self.dev)
-                    L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl, need_input_grad=True,
-                                    input_grad_out=dz_lbl, deferred=wl)
-                    g_lbl = dz_lbl
+                        logits_lbl, tape_dl = L.forward_tape(m.label_decoder.plan(), zl, groups=nl)
+                        rows_lbl = torch.empty(nl * B, dtype=torch.float32, device=self.dev)
+                        dlog_lbl = torch.empty_like(logits_lbl)
+                        if m.LABEL_KIND == 'class':
+                            K.ce_fwd(logits_lbl, label, rows_lbl, drow=self.coef[1, l0:l0 + nl], dlogits=dlog_lbl,
+                                     rows_per_group=B, label_rows=B)
+                        else:
+                            K.bce_rowsum_fwd(logits_lbl, lbl_in, rows_lbl, drow=self.coef[1, l0:l0 + nl],
+                                             dlogits=dlog_lbl, rows_per_group=B, target_rows=B)
+                    wl = self._deferred()
+                    if self.split_dz:
+                        # this decoder's latent gradient goes to its OWN buffer (terms l0 .. l0+nl-1), on this stream
+                        dz_lbl = torch.empty(nl * B, D, dtype=torch.float32, device=self.dev)
+                        L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl, need_input_grad=True,
+                                        input_grad_out=dz_lbl, deferred=wl)
+                        g_lbl = dz_lbl
+                    else:
+                        g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
+                                                defer_input_grad=True, deferred=wl)
+                    ev_lbl = None
+                    # single-GPU step, or the one-graph data-parallel step (the communicator's launch is a stream
+                    # operation: bucket 0 can then go out from the side stream, behind the last decoder gradient)
+                    # (with three buckets phase B's first half must then not JOIN the streams before the second: _upper_done)
+                    dp_side = self._side_launch_ok() and self.n_buckets >= 2
+                    if self.wgrad_on_side and self.side is not None and isinstance(wl, L.WgradBatch) \
+                            and (dp_side or (self._comm is None and self.on_bucket_ready is None)):
+                        ev_lbl = torch.cuda.Event()
+                        ev_lbl.record()              # this decoder's latent gradient is final: the PoE backward may start
+                    self._launch_deferred(wl, self.wg_side)
+                return logits_lbl, tape_dl, dlog_lbl, rows_lbl, rpg_lbl, g_lbl, ev_lbl, dp_side
+
+            def image_branch():
+                # ---- image branch (this stream)
+                zi = z[i0:i0 + ni].reshape(ni * B, D)
+                fold_img = self.fold_image and self._fold_plan(m.image_decoder.plan(), 'bce')
+                rpg_img = B
+                if fold_img:
+                    logits_img = None
+                    dlog_img, tape_di, rows_img, rpg_img = self._decode_with_loss(
+                        m.image_decoder.plan(), zi, ni, 'bce', image, self.coef[0, i0:i0 + ni], 'image')
                 else:
-                    g_lbl = L.backward_tape(m.label_decoder.plan(), tape_dl, dlog_lbl, groups=nl,
-                                            defer_input_grad=True, deferred=wl)
-                ev_lbl = None
-                # single-GPU step, or the one-graph data-parallel step (the communicator's launch is a stream
-                # operation: bucket 0 can then go out from the side stream, behind the last decoder gradient)
-                # (with three buckets phase B's first half must then not JOIN the streams before the second: _upper_done)
-                dp_side = self._side_launch_ok() and self.n_buckets >= 2
-                if self.wgrad_on_side and self.side is not None and isinstance(wl, L.WgradBatch) \
-                        and (dp_side or (self._comm is None and self.on_bucket_ready is None)):
-                    ev_lbl = torch.cuda.Event()
-                    ev_lbl.record()              # this decoder's latent gradient is final: the PoE backward may start
-                self._launch_deferred(wl, self.wg_side)
-            # ---- image branch (this stream)
-            zi = z[i0:i0 + ni].reshape(ni * B, D)
-            fold_img = self.fold_image and self._fold_plan(m.image_decoder.plan(), 'bce')
-            rpg_img = B
-            if fold_img:
-                logits_img = None
-                dlog_img, tape_di, rows_img, rpg_img = self._decode_with_loss(
-                    m.image_decoder.plan(), zi, ni, 'bce', image, self.coef[0, i0:i0 + ni], 'image')
-            else:
-                logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
-            if self.has_bn and ni < T:
-                # the reference also decodes the image for the label-only call: no loss, but its
-                # BatchNorm running statistics advance (celeba/train.py:195)
-                L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni,
-                               stats_only=True)
-            if not fold_img:
-                P = logits_img[0].numel()
-                li = logits_img.reshape(ni * B, P)
-                rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
-                dlog_img = torch.empty_like(li)
-                K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
-                                 rows_per_group=B, target_rows=B)
-                dlog_img = dlog_img.reshape(logits_img.shape)
-            wi = self._deferred()
-            if self.split_dz:
-                dz_img = torch.empty(ni * B, D, dtype=torch.float32, device=self.dev)
-                L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img, groups=ni,
-                                need_input_grad=True, input_grad_out=dz_img, deferred=wi)
-                g_img = dz_img
-            else:
-                g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img,
-                                        groups=ni, defer_input_grad=True, deferred=wi)
+                    logits_img, tape_di = L.forward_tape(m.image_decoder.plan(), zi, groups=ni)
+                if self.has_bn and ni < T:
+                    # the reference also decodes the image for the label-only call: no loss, but its
+                    # BatchNorm running statistics advance (celeba/train.py:195)
+                    L.forward_tape(m.image_decoder.plan(), z[i0 + ni:].reshape((T - ni) * B, D), groups=T - ni,
+                                   stats_only=True)
+                if not fold_img:
+                    P = logits_img[0].numel()
+                    li = logits_img.reshape(ni * B, P)
+                    rows_img = torch.empty(ni * B, dtype=torch.float32, device=self.dev)
+                    dlog_img = torch.empty_like(li)
+                    K.bce_rowsum_fwd(li, image.reshape(B, P), rows_img, drow=self.coef[0, i0:i0 + ni], dlogits=dlog_img,
+                                     rows_per_group=B, target_rows=B)
+                    dlog_img = dlog_img.reshape(logits_img.shape)
+                wi = self._deferred()
+                if self.split_dz:
+                    dz_img = torch.empty(ni * B, D, dtype=torch.float32, device=self.dev)
+                    L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img, groups=ni,
+                                    need_input_grad=True, input_grad_out=dz_img, deferred=wi)
+                    g_img = dz_img
+                else:
+                    g_img = L.backward_tape(m.image_decoder.plan(), tape_di, dlog_img,
+                                            groups=ni, defer_input_grad=True, deferred=wi)
+                return logits_img, tape_di, dlog_img, rows_img, rpg_img, g_img, wi
+
+            # at the fork the main stream's continuation -- the longer chain -- is issued first (MVAE_MAIN_FIRST)
+            dec_first = self.main_first_dec == '1' or (self.main_first_dec == 'auto' and any(
+                op.kind in ('conv', 'convT') for op in m.image_decoder.plan()))
+            fork = self._fork_point() if dec_first else None
+            if fork is None:
+                logits_lbl, tape_dl, dlog_lbl, rows_lbl, rpg_lbl, g_lbl, ev_lbl, dp_side = label_branch()
+            logits_img, tape_di, dlog_img, rows_img, rpg_img, g_img, wi = image_branch()
+            if fork is not None:
+                logits_lbl, tape_dl, dlog_lbl, rows_lbl, rpg_lbl, g_lbl, ev_lbl, dp_side = label_branch(fork)
             if ev_lbl is not None and isinstance(wi, L.WgradBatch):
                 # The image side is the longer chain and the label side has slack (MNIST: ~225 vs ~150 us of kernels):
                 # the image decoder's weight-gradient batch -- nothing before the optimizer reads it -- goes to the
@@ -881,10 +925,15 @@ class BimodalStep(_StepBase):
             # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
             #      gradients spread over this stream and the two weight-gradient streams
             wl, wi = self._deferred(), self._deferred()
-            with self._branch():
-                L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
-                if isinstance(wl, L.WgradBatch):
-                    wl.flush()
+
+            def label_encoder_backward(after=None):
+                with self._branch(after):
+                    L.backward_tape(m.label_encoder.plan(), c['tape_lbl'], g_heads_lbl, deferred=wl)
+                    if isinstance(wl, L.WgradBatch):
+                        wl.flush()
+            fork = self._fork_point()
+            if fork is None:
+                label_encoder_backward()
             if self.has_dropout:
                 d_hd = L.backward_tape(self.head, c['tape_head'], g_heads_img, need_input_grad=True, deferred=wi)
                 d_h = torch.empty(B, d_hd.shape[1], dtype=torch.float32, device=self.dev)
@@ -895,6 +944,8 @@ class BimodalStep(_StepBase):
             if isinstance(wi, L.WgradBatch):
                 wi.flush()
                 wi = None
+            if fork is not None:
+                label_encoder_backward(fork)
             self._late_elbo()
             self._join()
             if wi is not None:
