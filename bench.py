@@ -366,13 +366,22 @@ def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True, threads=None):
         torch.set_num_threads(th)
         one_step()                                   # warm this thread count
         probed[th] = sorted(one_step() for _ in range(n_probe))
-    threads = min(cands, key=lambda th: probed[th][len(probed[th]) // 2])
+    # the probe picks two finalists; the figure reported is the better SUSTAINED rate of the two (each runs half of
+    # the budget): on a 256-CPU host a thread count can win three probe steps and then run 3x slower for 200
+    order = sorted(cands, key=lambda th: probed[th][len(probed[th]) // 2])
+    finalists = order[:2]
+    runs = {}
+    for th in finalists:
+        torch.set_num_threads(th)
+        times = []
+        while sum(times) < budget_s / len(finalists) or len(times) < 3:
+            times.append(one_step())
+            if len(times) >= 200:
+                break
+        runs[th] = times
+    threads = max(finalists, key=lambda th: len(runs[th]) / sum(runs[th]))
     torch.set_num_threads(threads)
-    times = []
-    while sum(times) < budget_s or len(times) < 3:
-        times.append(one_step())
-        if len(times) >= 200:
-            break
+    times = runs[threads]
     n, t_total = len(times), sum(times)
     ts = sorted(times)
     out = {'value': round(batch * n / t_total, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
@@ -380,8 +389,10 @@ def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True, threads=None):
            'best_step_images_per_sec': round(batch / ts[0], 2),
            'median_step_images_per_sec': round(batch / ts[n // 2], 2),
            'thread_probe_median_ms': {str(th): round(v[len(v) // 2] * 1e3, 2) for th, v in probed.items()},
+           'sustained_images_per_sec_by_threads': {str(th): round(batch * len(r) / sum(r), 2) for th, r in runs.items()},
            'sample': '%d full train steps (fwd+bwd+Adam) of the %s oracle at batch %d, torch %s CPU, '
-                     '%d intra-op threads (lowest median of %d steps each at %s) on a %d-CPU host' % (
+                     '%d intra-op threads (the better sustained rate of the two lowest probe medians, %d steps '
+                     'each, among %s) on a %d-CPU host' % (
                          n, kind, batch, torch.__version__, threads, n_probe, cands, host['nproc'])}
     if with_delta:
         out['elbo_delta'] = elbo_delta(kind, 8 if kind == 'celeba19' else 32)

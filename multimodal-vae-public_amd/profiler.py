@@ -90,6 +90,7 @@ GEMM_COSTS = {
     'linear_fwd_grouped': _lin_grouped_cost('fwd'), 'linear_dgrad_grouped': _lin_grouped_cost('dgrad'),
     'linear_wgrad_grouped': _lin_grouped_cost('wgrad'),
     'linear_fwd': _lin_cost('fwd'), 'linear_dgrad': _lin_cost('dgrad'), 'linear_wgrad': _lin_cost('wgrad'),
+    'linear_bce_fwd': _lin_cost('fwd'), 'linear_ce_fwd': _lin_cost('fwd'),      # (x, w, ...): the Linear's flops
     'conv2d_fwd': _conv_cost('conv2d_fwd'), 'conv2d_dgrad': _conv_cost('conv2d_dgrad'),
     'conv2d_wgrad': _conv_cost('conv2d_wgrad'), 'convT2d_fwd': _conv_cost('convT2d_fwd'),
     'convT2d_dgrad': _conv_cost('convT2d_dgrad'), 'convT2d_wgrad': _conv_cost('convT2d_wgrad'),
