@@ -161,3 +161,42 @@ def test_train_cli_has_the_reference_flags_and_defaults(kind):
     assert 'size of the latent embedding [default: %d]' % REF_DEFAULTS[kind]['n_latents'] in text
     assert ('learning rate [default: %s]' % ('1e-3' if kind in ('mnist', 'fashionmnist') else '1e-4')) in text
     assert ('--approx-m' in text) == (kind == 'celeba19')
+
+
+# ---------------------------------------------------------------- reconstruction term in the last Linear's launch
+def test_loss_fold_is_refused_where_the_stack_does_not_end_in_a_plain_linear():
+    """layers.forward_tape(loss_fold=...) (mnist/model.py:104 -> mnist/train.py:47-49 in one launch) is only defined
+    for a training-mode stack whose last op is a Linear without activation: everything else is refused on the host,
+    before any launch."""
+    calls = []
+
+    def fold(x, w, b, out, **kw):
+        calls.append(1)
+    mnist = mvae_amd.mnist.model.MVAE(64).train()
+    fashion = mvae_amd.fashionmnist.model.MVAE(64).train()
+    z = torch.zeros(4, 64)
+    with pytest.raises(RuntimeError, match='plain Linear'):      # ends in the paired mu / logvar heads
+        L.forward_tape(mnist.label_encoder.plan(), torch.zeros(4, dtype=torch.long), loss_fold=fold)
+    with pytest.raises(RuntimeError, match='plain Linear'):      # ends in a ConvTranspose2d
+        L.forward_tape(fashion.image_decoder.plan(), z, loss_fold=fold)
+    with pytest.raises(RuntimeError, match='plain Linear'):      # not in training mode
+        L.forward_tape(mnist.image_decoder.plan(), z, training=False, loss_fold=fold)
+    assert not calls
+
+
+def test_which_decoders_carry_their_loss():
+    """engine._fold_plan: a Bernoulli term rides any plain last Linear, a categorical one only up to 32 classes
+    (one half wavefront holds the row)."""
+    from mvae_amd.engine import BimodalStep
+    probe = BimodalStep.__new__(BimodalStep)      # the rule reads the plan only
+    mnist = mvae_amd.mnist.model.MVAE(64)
+    fashion = mvae_amd.fashionmnist.model.MVAE(64)
+    celeba = mvae_amd.celeba.model.MVAE(100)
+    assert probe._fold_plan(mnist.image_decoder.plan(), 'bce')
+    assert probe._fold_plan(mnist.label_decoder.plan(), 'class')
+    assert not probe._fold_plan(fashion.image_decoder.plan(), 'bce')
+    assert probe._fold_plan(fashion.label_decoder.plan(), 'class')
+    assert not probe._fold_plan(celeba.image_decoder.plan(), 'bce')
+    assert probe._fold_plan(celeba.label_decoder.plan(), 'bce')
+    wide = [L._Op('lin', torch.nn.Linear(8, 33))]
+    assert probe._fold_plan(wide, 'bce') and not probe._fold_plan(wide, 'class')
