@@ -25,6 +25,16 @@
 #ifndef MVAE_CONV_BK
 #define MVAE_CONV_BK 32
 #endif
+// XCD-aware launch-order re-mapping (round 4; each 0 = plain launch order, for A/B builds)
+#ifndef MVAE_CONV_XCD
+#define MVAE_CONV_XCD 1         // forward / dgrad forms: the channel bands of one column tile on one XCD (igemm_kernel, mode 3)
+#endif
+#ifndef MVAE_WGRAD_XCD
+#define MVAE_WGRAD_XCD 1        // weight-gradient form: the tiles of one k range on one XCD (igemm_kernel, mode 4)
+#endif
+#ifndef MVAE_S1_XCD
+#define MVAE_S1_XCD 1           // convT_s1_kernel: the channel groups of one image group on one XCD
+#endif
 
 namespace {
 
@@ -784,6 +794,7 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
         cdiv(I, 128) * cdiv(J, 64) >= 384)
         pl.wm = 2;
     if (K <= MVAE_MULTI_MAXK) pl.items = MVAE_MULTI_ITEMS;      // short reductions: pipeline across consecutive tiles
+    pl.xcd = MVAE_CONV_XCD ? 3 : 0;                             // the bands of one column tile on one XCD (igemm_kernel)
     EpNCHW e;
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
@@ -986,7 +997,22 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int P = g.OH * g.OW;                      // positions per image (<= 32)
-    const int n0 = blockIdx.y * NI, ci0 = blockIdx.x * 4;
+    // XCD-local image groups.  Workgroups go to the 8 XCDs round-robin in launch order, each XCD has its own L2, and
+    // the Cin / 4 channel-group blocks of one image group all read the same dy tile (NI * Cout * P floats: 128 KB for
+    // 5 images of 256 x 25) against a 64 KB weight slab each.  In (channel group, image group) launch order the
+    // blocks of an image group spread over all 8 XCDs and every L2 fetched every dy tile: FETCH 946 MB against
+    // 118 MB of dy at 4608 rows (profiles/r03_traffic.json) -- the XCD count.  Re-map so that XCD x owns image groups
+    // x, x + 8, ... with all their channel groups back to back: dy comes in once, the 2 MB of weights are resident
+    // in every L2 (the host pads gridDim.y to a multiple of 8; the padding blocks leave here).
+    int by = blockIdx.y, bx = blockIdx.x;
+    if (MVAE_S1_XCD) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+        const unsigned grp = slot / gridDim.x;
+        bx = (int)(slot - grp * gridDim.x);
+        by = (int)(xcd + 8u * grp);
+        if (by * NI >= g.B) return;
+    }
+    const int n0 = by * NI, ci0 = bx * 4;
     const int K = g.Cout, J = g.Cin * 16;
     // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass.  Buffer loads
     // (gemm_core.h): the lane part of the address -- image, position, k parity -- is a constant voffset (BUF_OOB
@@ -1115,6 +1141,7 @@ inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act,
                          hipStream_t st) {
     const int NI = S1_ROWS / (g.OH * g.OW);         // whole images per block
     dim3 grid(g.Cin / 4, (g.B + NI - 1) / NI);
+    if (MVAE_S1_XCD) grid.y = (grid.y + 7) / 8 * 8;   // XCD-local image groups (see the kernel)
     hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g, NI);
     return mvae_launch_status();
 }
@@ -1142,6 +1169,7 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     }
     Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
     if (K <= MVAE_MULTI_MAXK) pl.items = MVAE_MULTI_ITEMS;      // short reductions: pipeline across consecutive tiles / classes
+    pl.xcd = MVAE_CONV_XCD ? 3 : 0;
     const bool vec = (g.Cin % 4 == 0) && aligned16(wr);
     EpNCHW e;
     e.out = dx; e.act = act; e.dpre = dpre;
@@ -1381,6 +1409,7 @@ int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int 
         }
     }
     Plan pl = make_plan(I, J, K, true, PLAN_CONV_WGRAD);
+    pl.xcd = MVAE_WGRAD_XCD ? 4 : 0;                            // the tiles of one k range on one XCD (igemm_kernel)
     SplitSink sink = make_sink(ws, I, J, false);
     if (pl.splits > 1 && (!ws || ws_bytes < pl.splits * sink.stride * sizeof(float))) return MVAE_ERR_WS;
     auto mp = [&](auto &p) { p.dy = dy; p.g = g; };

@@ -50,6 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_MULTI_MINBLOCKS
 #define MVAE_MULTI_MINBLOCKS 1024   // a multi-item launch keeps at least this many column blocks (4 per CU)
 #endif
+#ifndef MVAE_WGRAD_TILE
+#define MVAE_WGRAD_TILE 128
+#endif
 #ifndef MVAE_XCD_ROWS
 #define MVAE_XCD_ROWS 0         // 1: Linear launches map XCDs to ROW BANDS of the output (experiment; see igemm_kernel)
 #endif
@@ -555,13 +558,31 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     const int wi = wq / WGN, wj = wq % WGN;
     const bool mover = (NT == NTHREADS) || t < NTHREADS;
     const int tiles_j = sink.tiles_j;
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (sink.xcd_map) {
         // Workgroups go to the 8 XCDs round-robin in launch order, and each XCD has its own L2: with the j tile on
         // blockIdx.x every XCD touches every row band of P (a 1024 x 512 x 512 Linear pulled 22 MB through the
         // fabric for 5 MB of operands).  Re-map the launch order so that XCD x owns a (tiles_i / 4) x (tiles_j / 2)
         // sub-grid of the output: P is fetched by 2 XCDs, Q by 4 (host checks divisibility, one class, no split).
-        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), xcd = lin & 7u, slot = lin >> 3;
+        if (sink.xcd_map == 4) {
+            // split reductions (the conv weight gradients: 16 .. 128 k ranges x a few output tiles).  In launch order
+            // the tiles of ONE k range -- which share its rows of both operands -- spread over all 8 XCDs, and every
+            // L2 fetched every k range: 122.7 MB for 30 MB of operands on ConvTranspose2d(256, 128)'s weight gradient
+            // (profiles/r03_traffic.json).  XCD x owns k ranges x, x + 8, ... with all their tiles back to back
+            // (the host pads gridDim.z to a multiple of 8; the padding blocks leave here).
+            const unsigned tiles = gridDim.x * gridDim.y, grp = slot / tiles, tile = slot - grp * tiles;
+            bz = (int)(xcd + 8u * grp);
+            by = (int)(tile / gridDim.x); bx = (int)(tile - (unsigned)by * gridDim.x);
+            if ((long)bz * klen >= K) return;
+        } else if (sink.xcd_map == 3) {
+            // one reduction range, gather-fed conv forms: the i tiles (output-channel bands) of one (class, j tile) item
+            // read the same gathered columns -- XCD x owns items x, x + 8, ..., their bands back to back (gridDim.x is
+            // padded to a multiple of 8)
+            const unsigned jl = slot / gridDim.y;
+            by = (int)(slot - jl * gridDim.y); bx = (int)(jl * 8u + xcd);
+            if ((long)bx * sink.items >= (long)sink.tiles_j * sink.ncls) return;
+        } else
 #if MVAE_XCD_ROWS
         if (sink.xcd_map == 2) {
             // row bands: XCD x owns rows [x * tiles_i / 8, (x + 1) * tiles_i / 8) x ALL column tiles -- the layer behind
@@ -594,7 +615,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     };
     int cls, jt0;
     item_of(bx, cls, jt0);
-    const int i0 = by * BM, split = blockIdx.z;
+    const int i0 = by * BM, split = bz;
     int j0 = jt0 * BN;
     const int kbeg = split * klen;
     const int kend = min(K, kbeg + klen);
@@ -1184,7 +1205,7 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; };   // xcd: XCD-local output sub-grids (Linear); items: (class, j tile) items per block (conv forms)
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; };   // xcd: launch-order re-mapping the host asks for (1 Linear sub-grids, 3 conv items, 4 split k ranges; see igemm_kernel); items: (class, j tile) items per block (conv forms)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
@@ -1230,8 +1251,10 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
     const bool narrow = (I <= 32 && J >= 128 && !forced);
     if (narrow) { p.wgm = 1; p.wgn = 4; }
     if (kind == PLAN_CONV_WGRAD && !narrow) {
-        if (J >= 128) p.wn = 2;
-        if (I >= 128 && J >= 128) p.wm = 2;
+        // MVAE_WGRAD_TILE (A/B builds): 128 = up to 128 x 128 tiles (default), 96 = 64 x 128, 64 = 64 x 64 -- smaller
+        // tiles reach the block target with fewer k ranges, i.e. fewer partial slabs for the finish launch to re-read
+        if (J >= 128 && MVAE_WGRAD_TILE >= 96) p.wn = 2;
+        if (I >= 128 && J >= 128 && MVAE_WGRAD_TILE >= 128) p.wm = 2;
     }
     // long reductions into a small output (FashionMNIST's 6272-wide layers: 1024 x 512 over K = 6272): 64 x 128
     // tiles, split over K, beat the k-grouped small layouts (86 -> 101, 91 -> 100 TFLOP/s)
@@ -1293,8 +1316,9 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         QLD<TN> q; make_q(q);                                                                    \
         dim3 grid(((J + TN - 1) / TN) * sink.ncls, (I + TM - 1) / TM, pl.splits);                \
         sink.tiles_j = (J + TN - 1) / TN;                                                        \
-        sink.xcd_map = (pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
-        if (MVAE_XCD_ROWS && pl.xcd && sink.ncls == 1 && pl.splits == 1 && grid.y % 8 == 0) sink.xcd_map = 2;     \
+        sink.xcd_map = (pl.xcd == 1 && sink.ncls == 1 && pl.splits == 1 && grid.x % 2 == 0 && grid.y % 4 == 0) ? 1 : 0; \
+        if (MVAE_XCD_ROWS && pl.xcd == 1 && sink.ncls == 1 && pl.splits == 1 && grid.y % 8 == 0) sink.xcd_map = 2; \
+        if (pl.xcd == 4 && pl.splits >= 8) { sink.xcd_map = 4; grid.z = (grid.z + 7) / 8 * 8; } /* k ranges XCD-local */ \
         sink.items = 1;                                                                          \
         if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \
             K >= 2 * PLD<TM>::BKV && PLD<TM>::PARTS && QLD<TN>::PARTS) {                         \
@@ -1302,6 +1326,9 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
             while (items > 1 && (int)grid.x / items < MVAE_MULTI_MINBLOCKS) items >>= 1;         \
             sink.items = items;                                                                  \
             grid.x = (grid.x + items - 1) / items;                                               \
+        }                                                                                        \
+        if (pl.xcd == 3 && pl.splits == 1 && grid.y > 1 && grid.x >= 64) {                      \
+            sink.xcd_map = 3; grid.x = (grid.x + 7) / 8 * 8;    /* (class, j tile) items XCD-local */ \
         }                                                                                        \
         constexpr size_t tile_b = 2 * (PLD<TM>::ROWS * PLD<TM>::PITCH + QLD<TN>::ROWS * QLD<TN>::PITCH) * sizeof(float); \
         constexpr size_t red_b = (WGM * WGN < 4 && KW > 1)                                       \

@@ -236,6 +236,404 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float *x, const floa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Single-launch forms (round 4): statistics + apply from ONE read of the slice.
+//
+// The two-launch path above costs a (group, channel) slice two reads and two launches per direction; for the layers
+// whose slice is small that is all launch latency and cold prologues (CelebA: 8 of the 14 BatchNorm layers hold
+// <= 16 K elements per slice -- the 8x8 and 5x5 maps and the five BatchNorm1d -- 32 of the step's 50 BatchNorm
+// launches).  Here a block owns ONE channel (or 16 BatchNorm1d columns) of ALL groups, keeps the elements in
+// registers between the statistics and the apply, and thread 0 advances the running statistics over the groups in
+// order, as the two-launch path does.  Mean and variance are a true two-pass (sum, then centred squares) over the
+// registers; reductions go wave -> LDS -> every thread in a fixed order: deterministic, no atomics, no hand-off
+// between blocks.
+// ------------------------------------------------------------------------------------------
+constexpr int BNF_THREADS = 1024;
+constexpr int BNF_WAVES = BNF_THREADS / 64;
+constexpr int BNF_MAX_N = 16384;            // elements per (group, channel) slice a block keeps in registers
+
+// totals[g] = sum over the block of part[g], g < GMAX; red: BNF_WAVES * GMAX floats of LDS.  Every thread gets them.
+template <int GMAX>
+__device__ __forceinline__ void bnf_block_sums(float (&part)[GMAX], float *red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) part[g] = wave_sum(part[g]);
+    __syncthreads();                        // the previous round's readers are done with `red`
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) red[wave * GMAX + g] = part[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BNF_WAVES; ++w) t += red[w * GMAX + g];
+        part[g] = t;
+    }
+}
+
+template <bool VEC> struct BnfVal { typedef float T; };
+template <> struct BnfVal<true> { typedef float4 T; };
+
+// thread t owns units t, t + 1024, ... of every group's slice (a unit = one aligned float4 of a row, or one element);
+// off[k] = offset of unit k inside a group's [B, C, HW] slab, ok[k] = the unit exists
+template <bool VEC, int KMAX>
+__device__ __forceinline__ void bnf_units(const BnShape &sh, int c, int (&off)[KMAX], bool (&ok)[KMAX]) {
+    const int units = VEC ? sh.n >> 2 : sh.n, per_row = VEC ? sh.HW >> 2 : sh.HW;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int u = threadIdx.x + k * BNF_THREADS;
+        ok[k] = u < units;
+        const int uu = ok[k] ? u : 0;       // loads are unconditional (an existing unit); ok[] masks the sums
+        const int b = uu / per_row, q = uu - b * per_row;
+        off[k] = (b * sh.C + c) * sh.HW + (VEC ? 4 * q : q);
+    }
+}
+
+template <bool VEC, int GMAX, int KMAX>
+__global__ __launch_bounds__(BNF_THREADS) void bn_fused_fwd_kernel(const float *__restrict__ x, const float *gamma,
+                                                                   const float *beta, float *__restrict__ y,
+                                                                   float *save_mean, float *save_invstd,
+                                                                   float *running_mean, float *running_var, BnShape sh,
+                                                                   float eps, float momentum, int n_updates,
+                                                                   const int *n_updates_dev, int swish) {
+    typedef typename BnfVal<VEC>::T V;
+    __shared__ float red[BNF_WAVES * GMAX];
+    const int c = blockIdx.x;
+    const size_t gstride = (size_t)sh.B * sh.C * sh.HW;
+    int off[KMAX];
+    bool ok[KMAX];
+    bnf_units<VEC, KMAX>(sh, c, off, ok);
+    V v[GMAX][KMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            v[g][k] = *reinterpret_cast<const V *>(x + (g < sh.G ? g : 0) * gstride + off[k]);
+    float s[GMAX], mean[GMAX], invstd[GMAX], var[GMAX];
+    auto sum_of = [](const V &a) { if constexpr (VEC) return (a.x + a.y) + (a.z + a.w); else return a; };
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        s[g] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) s[g] += ok[k] ? sum_of(v[g][k]) : 0.f;
+    }
+    bnf_block_sums<GMAX>(s, red);
+    const float inv_n = 1.f / (float)sh.n;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        mean[g] = s[g] * inv_n;
+        s[g] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            float q;
+            if constexpr (VEC) {
+                const float a = v[g][k].x - mean[g], b = v[g][k].y - mean[g], cc = v[g][k].z - mean[g], d = v[g][k].w - mean[g];
+                q = (a * a + b * b) + (cc * cc + d * d);
+            } else {
+                const float a = v[g][k] - mean[g];
+                q = a * a;
+            }
+            s[g] += ok[k] ? q : 0.f;
+        }
+    }
+    bnf_block_sums<GMAX>(s, red);
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        var[g] = s[g] * inv_n;
+        invstd[g] = rsqrtf(var[g] + eps);
+    }
+    if (threadIdx.x == 0) {
+        if (n_updates_dev) n_updates = *n_updates_dev;
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+        const float unb = sh.n > 1 ? (float)sh.n / (float)(sh.n - 1) : 1.f;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < sh.G) {
+                save_mean[g * sh.C + c] = mean[g];
+                save_invstd[g * sh.C + c] = invstd[g];
+                for (int u = 0; u < n_updates; ++u) {
+                    rm = (1.f - momentum) * rm + momentum * mean[g];
+                    rv = (1.f - momentum) * rv + momentum * (var[g] * unb);
+                }
+            }
+        }
+        if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+    }
+    if (!y) return;                                        // statistics-only call
+    const float ga = gamma[c], be = beta[c];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        if (g >= sh.G) break;
+        auto one = [&](float a) {
+            const float h = ga * ((a - mean[g]) * invstd[g]) + be;     // same expression as the backward's
+            return swish ? swishf_(h) : h;
+        };
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (!ok[k]) continue;
+            if constexpr (VEC) st4(y, g * gstride + off[k], make_float4(one(v[g][k].x), one(v[g][k].y), one(v[g][k].z), one(v[g][k].w)));
+            else y[g * gstride + off[k]] = one(v[g][k]);
+        }
+    }
+}
+
+template <bool VEC, int GMAX, int KMAX>
+__global__ __launch_bounds__(BNF_THREADS) void bn_fused_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                   const float *gamma, const float *beta,
+                                                                   const float *save_mean, const float *save_invstd,
+                                                                   float *__restrict__ dx, float *dgamma, float *dbeta,
+                                                                   BnShape sh, int swish, int accumulate) {
+    typedef typename BnfVal<VEC>::T V;
+    __shared__ float red[BNF_WAVES * 2 * GMAX];
+    const int c = blockIdx.x;
+    const size_t gstride = (size_t)sh.B * sh.C * sh.HW;
+    int off[KMAX];
+    bool ok[KMAX];
+    bnf_units<VEC, KMAX>(sh, c, off, ok);
+    V xh[GMAX][KMAX], dh[GMAX][KMAX];       // loaded as x / dy, turned into xhat / dy * swish'(h) in place
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const size_t o = (g < sh.G ? g : 0) * gstride + off[k];
+            xh[g][k] = *reinterpret_cast<const V *>(x + o);
+            dh[g][k] = *reinterpret_cast<const V *>(dy + o);
+        }
+    const float ga = gamma[c], be = beta[c];
+    float s[2 * GMAX];                      // (sum dh, sum dh * xhat) per group
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        const int gg = g < sh.G ? g : 0;
+        const float mean = save_mean[gg * sh.C + c], invstd = save_invstd[gg * sh.C + c];
+        float s1 = 0.f, s2 = 0.f;
+        auto one = [&](float &xv, float &d, bool live) {
+            xv = (xv - mean) * invstd;
+            if (swish) d *= swish_grad_(ga * xv + be);
+            s1 += live ? d : 0.f;
+            s2 += live ? d * xv : 0.f;
+        };
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if constexpr (VEC) {
+                one(xh[g][k].x, dh[g][k].x, ok[k]); one(xh[g][k].y, dh[g][k].y, ok[k]);
+                one(xh[g][k].z, dh[g][k].z, ok[k]); one(xh[g][k].w, dh[g][k].w, ok[k]);
+            } else {
+                one(xh[g][k], dh[g][k], ok[k]);
+            }
+        }
+        s[2 * g] = s1; s[2 * g + 1] = s2;
+    }
+    bnf_block_sums<2 * GMAX>(s, red);
+    if (threadIdx.x == 0) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+            if (g < sh.G) { t1 += s[2 * g]; t2 += s[2 * g + 1]; }
+        if (accumulate) { t1 += dbeta[c]; t2 += dgamma[c]; }
+        dbeta[c] = t1;
+        dgamma[c] = t2;
+    }
+    const float inv_n = 1.f / (float)sh.n;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        if (g >= sh.G) break;
+        const float kf = ga * save_invstd[g * sh.C + c];
+        const float m1 = s[2 * g] * inv_n, m2 = s[2 * g + 1] * inv_n;
+        auto one = [&](float xv, float d) { return kf * (d - m1 - xv * m2); };
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (!ok[k]) continue;
+            if constexpr (VEC) st4(dx, g * gstride + off[k], make_float4(one(xh[g][k].x, dh[g][k].x), one(xh[g][k].y, dh[g][k].y),
+                                                                         one(xh[g][k].z, dh[g][k].z), one(xh[g][k].w, dh[g][k].w)));
+            else dx[g * gstride + off[k]] = one(xh[g][k], dh[g][k]);
+        }
+    }
+}
+
+// ---- BatchNorm1d (HW = 1): x is [G*B, C] and a channel is a COLUMN.  A block owns 16 neighbouring columns of all
+//      groups: thread (tx = column, ty = row class) reads rows ty, ty + 64, ... (64-byte segments per row; the
+//      per-channel kernels read one float per 2-KB row and every block touched every line of x), column sums go
+//      through LDS over the 64 row classes in a fixed order.
+constexpr int BN1_COLS = 16, BN1_TY = BNF_THREADS / BN1_COLS, BN1_MAX_ROWS = 8;      // B <= 512 rows per group
+
+// totals of `NV` values per column: part[v] summed over the 64 row classes; red: NV * 64 * 16 floats
+template <int NV>
+__device__ __forceinline__ void bn1_col_sums(float (&part)[NV], float *red, float *tot) {
+    const int tx = threadIdx.x & (BN1_COLS - 1), ty = threadIdx.x / BN1_COLS;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[(v * BN1_TY + ty) * BN1_COLS + tx] = part[v];
+    __syncthreads();
+    if (ty < NV) {
+        float t = 0.f;
+        for (int r = 0; r < BN1_TY; ++r) t += red[(ty * BN1_TY + r) * BN1_COLS + tx];
+        tot[ty * BN1_COLS + tx] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) part[v] = tot[v * BN1_COLS + tx];
+}
+
+template <int GMAX>
+__global__ __launch_bounds__(BNF_THREADS) void bn1d_fused_fwd_kernel(const float *__restrict__ x, const float *gamma,
+                                                                     const float *beta, float *__restrict__ y,
+                                                                     float *save_mean, float *save_invstd,
+                                                                     float *running_mean, float *running_var, BnShape sh,
+                                                                     float eps, float momentum, int n_updates,
+                                                                     const int *n_updates_dev, int swish) {
+    __shared__ float red[GMAX * BN1_TY * BN1_COLS];
+    __shared__ float tot[GMAX * BN1_COLS];
+    const int tx = threadIdx.x & (BN1_COLS - 1), ty = threadIdx.x / BN1_COLS;
+    const int c = blockIdx.x * BN1_COLS + tx;
+    const bool cok = c < sh.C;
+    const int cc = cok ? c : sh.C - 1;
+    float v[GMAX][BN1_MAX_ROWS];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const int r = ty + k * BN1_TY;
+            v[g][k] = x[((size_t)(g < sh.G ? g : 0) * sh.B + (r < sh.B ? r : 0)) * sh.C + cc];
+        }
+    float s[GMAX], mean[GMAX], var[GMAX], invstd[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        s[g] = 0.f;
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) s[g] += (ty + k * BN1_TY < sh.B) ? v[g][k] : 0.f;
+    }
+    bn1_col_sums<GMAX>(s, red, tot);
+    const float inv_n = 1.f / (float)sh.B;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        mean[g] = s[g] * inv_n;
+        s[g] = 0.f;
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const float a = v[g][k] - mean[g];
+            s[g] += (ty + k * BN1_TY < sh.B) ? a * a : 0.f;
+        }
+    }
+    bn1_col_sums<GMAX>(s, red, tot);
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        var[g] = s[g] * inv_n;
+        invstd[g] = rsqrtf(var[g] + eps);
+    }
+    if (ty == 0 && cok) {
+        if (n_updates_dev) n_updates = *n_updates_dev;
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+        const float unb = sh.B > 1 ? (float)sh.B / (float)(sh.B - 1) : 1.f;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g < sh.G) {
+                save_mean[g * sh.C + c] = mean[g];
+                save_invstd[g * sh.C + c] = invstd[g];
+                for (int u = 0; u < n_updates; ++u) {
+                    rm = (1.f - momentum) * rm + momentum * mean[g];
+                    rv = (1.f - momentum) * rv + momentum * (var[g] * unb);
+                }
+            }
+        }
+        if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+    }
+    if (!y || !cok) return;
+    const float ga = gamma[c], be = beta[c];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        if (g >= sh.G) break;
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const int r = ty + k * BN1_TY;
+            if (r >= sh.B) continue;
+            const float h = ga * ((v[g][k] - mean[g]) * invstd[g]) + be;
+            y[((size_t)g * sh.B + r) * sh.C + c] = swish ? swishf_(h) : h;
+        }
+    }
+}
+
+template <int GMAX>
+__global__ __launch_bounds__(BNF_THREADS) void bn1d_fused_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                     const float *gamma, const float *beta,
+                                                                     const float *save_mean, const float *save_invstd,
+                                                                     float *__restrict__ dx, float *dgamma, float *dbeta,
+                                                                     BnShape sh, int swish, int accumulate) {
+    __shared__ float red[2 * GMAX * BN1_TY * BN1_COLS];
+    __shared__ float tot[2 * GMAX * BN1_COLS];
+    const int tx = threadIdx.x & (BN1_COLS - 1), ty = threadIdx.x / BN1_COLS;
+    const int c = blockIdx.x * BN1_COLS + tx;
+    const bool cok = c < sh.C;
+    const int cc = cok ? c : sh.C - 1;
+    float xh[GMAX][BN1_MAX_ROWS], dh[GMAX][BN1_MAX_ROWS];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const int r = ty + k * BN1_TY;
+            const size_t o = ((size_t)(g < sh.G ? g : 0) * sh.B + (r < sh.B ? r : 0)) * sh.C + cc;
+            xh[g][k] = x[o];
+            dh[g][k] = dy[o];
+        }
+    const float ga = gamma[cc], be = beta[cc];
+    float s[2 * GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        const int gg = g < sh.G ? g : 0;
+        const float mean = save_mean[gg * sh.C + cc], invstd = save_invstd[gg * sh.C + cc];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const bool live = ty + k * BN1_TY < sh.B;
+            xh[g][k] = (xh[g][k] - mean) * invstd;
+            if (swish) dh[g][k] *= swish_grad_(ga * xh[g][k] + be);
+            s1 += live ? dh[g][k] : 0.f;
+            s2 += live ? dh[g][k] * xh[g][k] : 0.f;
+        }
+        s[2 * g] = s1; s[2 * g + 1] = s2;
+    }
+    bn1_col_sums<2 * GMAX>(s, red, tot);
+    if (ty == 0 && cok) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g)
+            if (g < sh.G) { t1 += s[2 * g]; t2 += s[2 * g + 1]; }
+        if (accumulate) { t1 += dbeta[c]; t2 += dgamma[c]; }
+        dbeta[c] = t1;
+        dgamma[c] = t2;
+    }
+    if (!cok) return;
+    const float inv_n = 1.f / (float)sh.B;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+        if (g >= sh.G) break;
+        const float kf = ga * save_invstd[g * sh.C + c];
+        const float m1 = s[2 * g] * inv_n, m2 = s[2 * g + 1] * inv_n;
+#pragma unroll
+        for (int k = 0; k < BN1_MAX_ROWS; ++k) {
+            const int r = ty + k * BN1_TY;
+            if (r >= sh.B) continue;
+            dx[((size_t)g * sh.B + r) * sh.C + c] = kf * (dh[g][k] - m1 - xh[g][k] * m2);
+        }
+    }
+}
+
+#ifndef MVAE_BN_FUSED
+#define MVAE_BN_FUSED 1         // 0: every layer on the two-launch path (A/B builds)
+#endif
+constexpr int BNF_GMAX_FWD = 3, BNF_GMAX_BWD = 2, BN1_GMAX = 3;
+
+// which single-launch form takes the shape: 0 none, 1 spatial, 2 BatchNorm1d
+inline int bn_fused_kind(const BnShape &sh, bool bwd) {
+    if (!MVAE_BN_FUSED || (long)sh.B * sh.C * sh.HW >= (1L << 30)) return 0;
+    if (sh.HW == 1) return (sh.G <= BN1_GMAX && sh.B <= BN1_TY * BN1_MAX_ROWS) ? 2 : 0;
+    // (unaligned / odd-width maps keep one element per register: half the slice when several groups share the block)
+    const int max_n = (!sh.vec && sh.G > 1) ? BNF_MAX_N / 2 : BNF_MAX_N;
+    return (sh.n <= max_n && sh.G <= (bwd ? BNF_GMAX_BWD : BNF_GMAX_FWD)) ? 1 : 0;
+}
+
 inline bool bn_shape(int G, int B, int C, int HW, const void *a, const void *b, const void *c, BnShape *sh) {
     if (G <= 0 || B <= 0 || C <= 0 || HW <= 0) return false;
     if ((long)G * B * C * HW >= (1L << 40) || (long)B * HW >= (1L << 31)) return false;
@@ -267,8 +665,27 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !bn_shape(G, B, C, HW, x, y, nullptr, &sh))
         return MVAE_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
-    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     hipStream_t st = (hipStream_t)stream;
+    const int sw = (flags & MVAE_ACT_SWISH) ? 1 : 0;
+    if (const int kind = bn_fused_kind(sh, false)) {
+#define MVAE_BNF_FWD(KERN, GRID)                                                                                    \
+        hipLaunchKernelGGL(KERN, dim3(GRID), dim3(BNF_THREADS), 0, st, x, gamma, beta, y, save_mean, save_invstd,   \
+                           running_mean, running_var, sh, eps, momentum, n_updates, n_updates_dev, sw)
+        if (kind == 2) {
+            if (G == 1) MVAE_BNF_FWD((bn1d_fused_fwd_kernel<1>), (C + BN1_COLS - 1) / BN1_COLS);
+            else MVAE_BNF_FWD((bn1d_fused_fwd_kernel<BN1_GMAX>), (C + BN1_COLS - 1) / BN1_COLS);
+        } else if (sh.vec) {
+            if (G == 1) MVAE_BNF_FWD((bn_fused_fwd_kernel<true, 1, 4>), C);
+            else if (G == 2) MVAE_BNF_FWD((bn_fused_fwd_kernel<true, 2, 4>), C);
+            else MVAE_BNF_FWD((bn_fused_fwd_kernel<true, BNF_GMAX_FWD, 4>), C);
+        } else {
+            if (G == 1) MVAE_BNF_FWD((bn_fused_fwd_kernel<false, 1, 16>), C);
+            else MVAE_BNF_FWD((bn_fused_fwd_kernel<false, BNF_GMAX_FWD, 8>), C);
+        }
+#undef MVAE_BNF_FWD
+        return mvae_launch_status();
+    }
+    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     dim3 grid(sh.S, C, G);
     hipLaunchKernelGGL(bn_partial_stats_kernel, grid, dim3(BN_THREADS), 0, st, x, (float *)ws, sh);
     // y == NULL: only the (s = 0) block of each (channel, group) has work -- saved + running statistics
@@ -287,10 +704,28 @@ MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *
     if (!dy || !x || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta ||
         !bn_shape(G, B, C, HW, x, dy, dx, &sh))
         return MVAE_ERR_ARG;
-    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(sh.S, C, G);
     const int swish = (flags & MVAE_ACT_SWISH) ? 1 : 0;
+    if (const int kind = bn_fused_kind(sh, true)) {
+        const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
+#define MVAE_BNF_BWD(KERN, GRID)                                                                                    \
+        hipLaunchKernelGGL(KERN, dim3(GRID), dim3(BNF_THREADS), 0, st, dy, x, gamma, beta, save_mean, save_invstd,  \
+                           dx, dgamma, dbeta, sh, swish, acc)
+        if (kind == 2) {
+            if (G == 1) MVAE_BNF_BWD((bn1d_fused_bwd_kernel<1>), (C + BN1_COLS - 1) / BN1_COLS);
+            else MVAE_BNF_BWD((bn1d_fused_bwd_kernel<BN1_GMAX>), (C + BN1_COLS - 1) / BN1_COLS);
+        } else if (sh.vec) {
+            if (G == 1) MVAE_BNF_BWD((bn_fused_bwd_kernel<true, 1, 4>), C);
+            else MVAE_BNF_BWD((bn_fused_bwd_kernel<true, BNF_GMAX_BWD, 4>), C);
+        } else {
+            if (G == 1) MVAE_BNF_BWD((bn_fused_bwd_kernel<false, 1, 16>), C);
+            else MVAE_BNF_BWD((bn_fused_bwd_kernel<false, BNF_GMAX_BWD, 8>), C);
+        }
+#undef MVAE_BNF_BWD
+        return mvae_launch_status();
+    }
+    if (!ws || ws_bytes < mvae_bn_ws_bytes(G, C, sh.n)) return MVAE_ERR_WS;
+    dim3 grid(sh.S, C, G);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(BN_THREADS), 0, st, dy, x, gamma, beta, save_mean,
                        save_invstd, (float *)ws, sh, swish);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(BN_THREADS), 0, st, dy, x, gamma, beta, save_mean,

@@ -527,6 +527,11 @@ class BimodalStep(_StepBase):
         # on MI355X: 17 % fewer graph nodes but no gain (MNIST B=512 0.508 vs 0.493 ms/step) -- the two
         # decoders already overlap on two streams and a paired launch serialises them.
         self.pair_dec = self._pairable_decoder_layers() if os.environ.get('MVAE_PAIR', '0') == '1' else 0
+        # the two ENCODERS' trailing layers of equal shape (MNIST: 512 -> 512 and the 512 -> 2D heads, mnist/model.py:
+        # 76-78,117-119) as G = 2 launches on ONE stream: the encoder phases have no fork and no join (MVAE_PAIR_ENC=0:
+        # two branches).  Unlike the decoders (MVAE_PAIR) the label side here is three small kernels, not a chain
+        # that overlaps the image side's.
+        self.pair_enc = self._pairable_encoder_layers() if os.environ.get('MVAE_PAIR_ENC', '1') != '0' else 0
         # each decoder's backward runs to the latent on its own stream into its own buffer (poe_bwd_split adds
         # them); MVAE_SPLIT_DZ=0: one cleared dz both first layers accumulate into after the join
         self.split_dz = os.environ.get('MVAE_SPLIT_DZ', '1') != '0' 
@@ -553,6 +558,95 @@ class BimodalStep(_StepBase):
                 break
             n += 1
         return n if n < min(len(pi), len(pl)) else 0      # both stacks need a tail (their output layers)
+
+    def _pairable_encoder_layers(self):
+        """How many TRAILING layers of the image and the label encoder are the same Linear shape (MNIST: 2 --
+        fc2 and the fc31 | fc32 head pair) with nothing but ``View + Linear + Swish`` (image) and ``Embedding + Swish``
+        (label) in front of them.  0: the encoders run as two branches."""
+        if self.has_bn or self.has_dropout or self.side is None or not self.batch_wgrad or self.wg_main is not None:
+            return 0
+        pi, pl = self.model.image_encoder.plan(), self.model.label_encoder.plan()
+        n = 0
+        while n < min(len(pi), len(pl)):
+            a, b = pi[-1 - n], pl[-1 - n]
+            if not (a.kind == b.kind and a.kind in ('lin', 'lin2') and a.act == b.act and a.drop == 0 and b.drop == 0):
+                break
+            wa, ba = L._lin_weights(a)
+            wb, bb = L._lin_weights(b)
+            if wa.shape != wb.shape or (ba is None) != (bb is None):
+                break
+            n += 1
+        head_i = [op for op in pi[:len(pi) - n] if op.kind != 'view']
+        head_l = pl[:len(pl) - n]
+        ok = (n >= 1 and len(head_i) == 1 and head_i[0].kind == 'lin' and head_i[0].act and head_i[0].drop == 0
+              and len(head_l) == 1 and head_l[0].kind == 'emb')
+        return n if ok else 0
+
+    def _pair_enc_now(self):
+        return self.pair_enc and self.n_buckets != 3
+
+    def _encoders_paired_fwd(self, image, lbl_in):
+        """Both encoders on this stream: Embedding, the image side's first Linear, then the shared-shape layers as
+        paired launches.  Returns (image heads, label heads) [B, 2D]."""
+        m, B, P, dev, c = self.model, self.B, self.pair_enc, self.dev, self._carry
+        pi, pl = m.image_encoder.plan(), m.label_encoder.plan()
+        ni, nl = len(pi) - P, len(pl) - P
+        h_l, tape_l = L.forward_tape(pl[:nl], lbl_in)
+        h_i, tape_i = L.forward_tape(pi[:ni], image)
+        h, layers = (h_i, h_l), []
+        for j in range(P):
+            wbs = [L._lin_weights(pi[ni + j]), L._lin_weights(pl[nl + j])]
+            w = (wbs[0][0].detach(), wbs[1][0].detach())
+            b = (None, None) if wbs[0][1] is None else (wbs[0][1].detach(), wbs[1][1].detach())
+            N = w[0].shape[0]
+            pre = torch.empty(2, B, N, dtype=torch.float32, device=dev)
+            if pi[ni + j].act:
+                act = torch.empty(2, B, N, dtype=torch.float32, device=dev)
+                K.linear_fwd_pair(h, w, b, (pre[0], pre[1]), (act[0], act[1]))
+                layers.append((h, pre, w))
+                h = (act[0], act[1])
+            else:
+                K.linear_fwd_pair(h, w, b, (pre[0], pre[1]), (None, None))
+                layers.append((h, None, w))
+                h = (pre[0], pre[1])
+        c['enc_pair'] = (layers, tape_i, tape_l, ni, nl)
+        return h
+
+    def _encoders_paired_bwd(self, g_img, g_lbl):
+        """Backward of ``_encoders_paired_fwd``: paired data gradients, then ONE weight-gradient batch for both
+        encoders and the Embedding gradient -- no fork, no join."""
+        m, B, P, dev, c = self.model, self.B, self.pair_enc, self.dev, self._carry
+        pi, pl = m.image_encoder.plan(), m.label_encoder.plan()
+        layers, tape_i, tape_l, ni, nl = c['enc_pair']
+        wb = L.WgradBatch()
+        g = (g_img, g_lbl)
+        keep = [g]
+        first_i = [k for k, op in enumerate(pi[:ni]) if op.kind == 'lin'][0]
+        for j in range(P - 1, -1, -1):
+            x, _, w = layers[j]
+            wb.add_linear(pi[ni + j], g[0], x[0])
+            wb.add_linear(pl[nl + j], g[1], x[1])
+            K_in = w[0].shape[1]
+            dx = torch.empty(2, B, K_in, dtype=torch.float32, device=dev)
+            if j > 0:
+                pre_in = layers[j - 1][1]
+                pin = (pre_in[0], pre_in[1])
+            else:
+                # the image side's producer is an activated Linear (its Swish' rides this launch), the label side's is
+                # the Embedding, whose own backward applies Swish'.  A pair shares its epilogue: the label side reads a
+                # pre-activation whose Swish' is exactly 1.0f (sigmoid(1e4) == 1.0f: s * (1 + x * (1 - s)) == 1)
+                if getattr(self, '_unit_pre', None) is None or self._unit_pre.shape != (B, K_in):
+                    self._unit_pre = torch.full((B, K_in), 1e4, dtype=torch.float32, device=dev)
+                pin = (tape_i[first_i][1], self._unit_pre)
+            K.linear_dgrad_pair(g, w, (dx[0], dx[1]), pin)
+            g = (dx[0], dx[1])
+            keep.append(dx)
+        wb.add_linear(pi[first_i], g[0], tape_i[first_i][0])         # first layer: no data gradient
+        wb.flush()
+        emb = pl[0].mod
+        dw, acc = L.grad_target(emb.weight)
+        K.embedding_swish_bwd(tape_l[0][0], emb.weight.detach(), g[1].contiguous(), dw, accumulate=acc)
+        c['enc_pair_keep'] = (keep, wb)
 
     def _decoders_paired(self, z, image, label, lbl_in):
         """Decoder forward, reconstruction terms + gradients, decoder backward with the first
@@ -724,10 +818,16 @@ class BimodalStep(_StepBase):
                 heads, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
                 self._early_counter()
             return heads
-        fork = self._fork_point()
-        if fork is None:
+        paired = self._pair_enc_now()
+        fork = None if paired else self._fork_point()
+        if paired:
+            heads_img, heads_lbl = self._encoders_paired_fwd(image, lbl_in)
+            img_experts = [heads_img]
+        elif fork is None:
             heads_lbl = encode_label()
-        if self.has_dropout:
+        if paired:
+            pass
+        elif self.has_dropout:
             h, c['tape_trunk'] = L.forward_tape(self.trunk, image, groups=1, bn_updates=n_up)
             hd = torch.empty(2 * B, h.shape[1], dtype=torch.float32, device=self.dev)
             K.dropout_fanout_fwd(h, self.drop_masks, hd, 1.0 / KEEP)
@@ -758,6 +858,8 @@ class BimodalStep(_StepBase):
             def label_branch(after=None):
                 # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
                 with self._branch(after):
+                    if paired:
+                        self._early_counter()       # no encoder side branch in this mode: the step counter rides this one
                     zl = z[l0:l0 + nl].reshape(nl * B, D)
                     lbl_kind = 'class' if m.LABEL_KIND == 'class' else 'bce'
                     rpg_lbl = B
@@ -921,6 +1023,12 @@ class BimodalStep(_StepBase):
                           self.coef[2], [gg[:, :D] for gg in g_list], [gg[:, D:] for gg in g_list], m.POE_VARIANT,
                           dkl_per_term=True)
             c['keep_b'] = (g_heads_img, g_heads_lbl)
+        if part == 'all' and 'enc_pair' in c:
+            self._encoders_paired_bwd(*c['keep_b'])
+            self._late_elbo()
+            self._join()
+            self._join_wgrad()
+            return
         if part == 'all':
             # ---- encoders backward: data-gradient chains on the two branches, then ALL their weight
             #      gradients spread over this stream and the two weight-gradient streams

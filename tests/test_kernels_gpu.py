@@ -331,8 +331,14 @@ def test_conv_transpose2d(B, Cin, H, Cout, s, p):
 
 
 # ----------------------------------------------------------------------------- BatchNorm
+# the last three rows of the first line and all of the second: the single-launch forms of norm.hip (slices of <= 16 K
+# elements: the float4, the odd-width and the BatchNorm1d kernel) at CelebA's real layer shapes, their group limits
+# (forward 3 / backward 2 groups, then the two-launch path), a ragged column block and > 64 rows per thread class
 @pytest.mark.parametrize('G,B,C,spatial', [(1, 16, 64, (16, 16)), (3, 8, 32, (32, 32)), (2, 6, 256, (5, 5)),
-                                           (3, 32, 512, ()), (1, 256, 512, ()), (2, 64, 128, (8, 8))])
+                                           (3, 32, 512, ()), (1, 256, 512, ()), (2, 64, 128, (8, 8)),
+                                           (3, 256, 128, (8, 8)), (2, 256, 128, (8, 8)), (1, 256, 256, (5, 5)),
+                                           (1, 256, 64, (16, 16)), (4, 8, 32, (8, 8)), (2, 300, 40, ()),
+                                           (3, 256, 512, ()), (4, 16, 48, ()), (3, 40, 24, (5, 5)), (1, 3, 8, (2, 2))])
 @pytest.mark.parametrize('act', [True, False])
 def test_batchnorm_train(G, B, C, spatial, act):
     x = g(G * B, C, *spatial, seed=40) * 1.7 + 0.4
@@ -362,6 +368,12 @@ def test_batchnorm_train(G, B, C, spatial, act):
     assert_close(db, br.grad, 'bn dbeta')
     K.bn_train_bwd(dev(dy), dev(x), dev(gamma), dev(beta), sm, si, dx, dg, db, G, swish=act, accumulate=True)
     assert_close(dg, 2 * gr.grad, 'bn dgamma accumulate')
+    # statistics-only call (the decoder passes that exist for their running-statistics side effect): no output, same
+    # saved and running statistics
+    sm2 = torch.empty(G, C, device=DEV); si2 = torch.empty(G, C, device=DEV)
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    K.bn_train_fwd(dev(x), dev(gamma), dev(beta), None, sm2, si2, rm2, rv2, G, n_updates=2, swish=act)
+    assert torch.equal(sm2, sm) and torch.equal(si2, si) and torch.equal(rm2, rmd) and torch.equal(rv2, rvd)
 
 
 def test_batchnorm_eval():
