@@ -470,6 +470,10 @@ def main():
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
 
+    # multi-process GPU work on this driver needs dmabuf IPC (without it RCCL / cross-process tensor sharing fail with
+    # hipIpcGetMemHandle: invalid argument); the HSA runtime reads it when the process first touches the GPU
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # the documented command, no launcher: bring the N ranks up ourselves
         if args.backend == 'nccl' and torch.cuda.device_count() < args.gpus:
@@ -490,6 +494,25 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree' % (args.gpus, world))
+    from mvae_amd import launch
+    if world > 1 and launch.WORKER_ENV not in os.environ and os.environ.get('MVAE_BENCH_SUPERVISE', '1') != '0':
+        # A launched rank is a SUPERVISOR (mvae_amd/launch.py): it runs each gradient-exchange transport in a child
+        # process under a wall-clock budget -- a hung collective is killed with its process, not waited for -- and the
+        # ranks agree per attempt whether it succeeded everywhere.  The first transport that completes on every rank
+        # gives the line; `dist.fallbacks_tried` says what was given up on.  This process never touches the GPU.
+        line, tried = launch.supervise(os.path.abspath(__file__), sys.argv[1:])
+        if rank == 0:
+            if line is None:
+                line = {'metric': 'images/sec (MVAE train step)', 'value': None, 'unit': 'images/sec', 'n_gpus': world,
+                        'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak',
+                        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                        'config': {'workload': '%s MVAE train step' % args.workload, 'parallelism': 'dp%d' % world},
+                        'dist': {'world_size': world, 'transport': None, 'fallbacks_tried': tried},
+                        'note': 'every gradient-exchange transport failed or timed out on at least one rank'}
+            print(json.dumps(line))
+            sys.stdout.flush()
+        sys.exit(0 if (rank != 0 or line.get('value') is not None or args.dist_check) else 1)
+    transport = os.environ.get(launch.TRANSPORT_ENV)
     on_gpu = args.backend == 'nccl'
     if on_gpu:
         if torch.cuda.device_count() <= local:
@@ -509,6 +532,11 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group('gloo')
+        if transport == 'fake-raise':       # tests of the supervisor chain (tests/test_parallel_cpu.py)
+            raise SystemExit('fake-raise transport: this attempt fails on purpose')
+        if transport == 'fake-hang' and rank == world - 1:
+            while True:                     # one rank never arrives at the collective below: its peers block in it
+                time.sleep(1.0)
         dist_info = dist_check(args.backend, device)
         if dist_info['world_size'] != args.gpus or dist_info['allreduce_of_ones'] != float(args.gpus):
             raise SystemExit('--gpus %d but the process group has %d ranks (all-reduce of ones = %g)' % (

@@ -44,7 +44,10 @@ extern "C" {
 #define MVAE_POE_VARIANT_B 1   /* celeba/model.py:200-207, celeba19/model.py:219-226 */
 #define MVAE_POE_NO_PRIOR  4   /* OR-ed into `variant`: no built-in N(0,1) prior -- the caller's stack carries every expert,
                                   as when ProductOfExperts.forward is called on a [M,B,D] stack whose row 0 is what
-                                  prior_expert returned (mnist/model.py:50-63,156-163,172-185) */
+                                  prior_expert returned (mnist/model.py:50-63,156-163,172-185).  REQUIREMENT: every
+                                  term's mask must then select at least one of the E experts -- an empty product has
+                                  no precision (0/0: NaN mu, inf logvar) and the launch cannot see a device mask; the
+                                  Python binding checks host-built masks (kernels._check_no_prior_masks) */
 #define MVAE_MAX_EXPERTS  32
 
 typedef void *mvae_stream_t;   /* hipStream_t */

@@ -194,7 +194,7 @@ def lib():
             if fn is not None:
                 fn.restype = res
                 fn.argtypes = args
-        if handle.mvae_abi_version() != 2:
+        if handle.mvae_abi_version() != 3:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle
     return _lib

@@ -188,7 +188,7 @@ class MVAEBase(nn.Module):
         self.finalize()
         B = heads[0].shape[0]
         dev = heads[0].device
-        masks = torch.full((1,), (1 << len(heads)) - 1, dtype=torch.int32, device=dev)
+        masks = K.all_experts_mask(len(heads), dev)
         noise = None
         if want_z and self.training:
             noise = eps if eps is not None else self.device_randn(1, B, self.n_latents)

@@ -153,11 +153,22 @@ MVAE_EXPORT int mvae_comm_init(mvae_comm_t **comm_out, const void *id, size_t id
     mvae_comm *c = (mvae_comm *)calloc(1, sizeof(mvae_comm));
     if (!c) return MVAE_ERR_COMM;
     c->rank = rank; c->world = world; c->device = device; c->issued = 0;
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    int n_events = 0;               // events created so far (ready / done alternate): what a failure has to give back
+    bool have_stream = false;
     int rc = hip_check(c, hipSetDevice(device), "hipSetDevice");
-    if (rc == MVAE_OK) rc = hip_check(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (rc == MVAE_OK) {
+        rc = hip_check(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+        have_stream = rc == MVAE_OK;
+    }
     for (int i = 0; rc == MVAE_OK && i < COMM_SLOTS; ++i) {
         rc = hip_check(c, hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming), "hipEventCreate");
-        if (rc == MVAE_OK) rc = hip_check(c, hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming), "hipEventCreate");
+        if (rc == MVAE_OK) {
+            ++n_events;
+            rc = hip_check(c, hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming), "hipEventCreate");
+            if (rc == MVAE_OK) ++n_events;
+        }
     }
     if (rc == MVAE_OK) {
         ncclUniqueId uid;
@@ -166,6 +177,10 @@ MVAE_EXPORT int mvae_comm_init(mvae_comm_t **comm_out, const void *id, size_t id
     }
     if (rc != MVAE_OK) {
         fprintf(stderr, "[mvae_comm_init] rank %d/%d on device %d failed: %s\n", rank, world, device, c->last_error);
+        // give back what was created, and the caller's device
+        for (int i = 0; i < n_events; ++i) (void)hipEventDestroy((i & 1) ? c->done[i >> 1] : c->ready[i >> 1]);
+        if (have_stream) (void)hipStreamDestroy(c->stream);
+        if (prev_device >= 0 && prev_device != device) (void)hipSetDevice(prev_device);
         free(c);
         return rc;
     }
@@ -184,11 +199,21 @@ MVAE_EXPORT int mvae_comm_allreduce_async(mvae_comm_t *c, float *buf, size_t cou
     if (!api) return MVAE_ERR_COMM;
     const int slot = (int)(c->issued % COMM_SLOTS);
     int rc = hip_check(c, hipEventRecord(c->ready[slot], (hipStream_t)stream), "hipEventRecord(ready)");
-    if (rc == MVAE_OK) rc = hip_check(c, hipStreamWaitEvent(c->stream, c->ready[slot], 0), "hipStreamWaitEvent(comm)");
+    bool forked = false;            // the communication stream now depends on `stream` (under capture: it is part of the capture)
+    if (rc == MVAE_OK) {
+        rc = hip_check(c, hipStreamWaitEvent(c->stream, c->ready[slot], 0), "hipStreamWaitEvent(comm)");
+        forked = rc == MVAE_OK;
+    }
     if (rc == MVAE_OK)
         rc = nccl_check(c, api, api->AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->nccl, c->stream), "ncclAllReduce");
     if (rc == MVAE_OK) rc = hip_check(c, hipEventRecord(c->done[slot], c->stream), "hipEventRecord(done)");
-    if (rc != MVAE_OK) return rc;
+    if (rc != MVAE_OK) {
+        // a partial enqueue must not leave the communication stream forked into a capture with no way back: join it
+        // into the caller's stream (best effort; last_error keeps the first failure), so EndCapture sees one tail
+        if (forked && hipEventRecord(c->done[slot], c->stream) == hipSuccess)
+            (void)hipStreamWaitEvent((hipStream_t)stream, c->done[slot], 0);
+        return rc;
+    }
     *ticket = (int)c->issued;          // 2^31 collectives per process: ~10^8 steps at the deepest bucket plan
     c->issued++;
     return MVAE_OK;

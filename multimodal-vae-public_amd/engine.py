@@ -396,6 +396,8 @@ class _StepBase(object):
         comm = self._comm
         self._adam_counter = None
         self._bucket0_done = self._bucket1_done = False
+        if hasattr(comm, 'reset'):
+            comm.reset()            # tickets of a step that raised half-way must not poison this one
         try:
             self._body_a()
             if self.n_buckets > 1 and not self._bucket0_done:      # else: phase A sent it from the side stream
@@ -527,11 +529,13 @@ class BimodalStep(_StepBase):
         # on MI355X: 17 % fewer graph nodes but no gain (MNIST B=512 0.508 vs 0.493 ms/step) -- the two
         # decoders already overlap on two streams and a paired launch serialises them.
         self.pair_dec = self._pairable_decoder_layers() if os.environ.get('MVAE_PAIR', '0') == '1' else 0
-        # the two ENCODERS' trailing layers of equal shape (MNIST: 512 -> 512 and the 512 -> 2D heads, mnist/model.py:
-        # 76-78,117-119) as G = 2 launches on ONE stream: the encoder phases have no fork and no join (MVAE_PAIR_ENC=0:
-        # two branches).  Unlike the decoders (MVAE_PAIR) the label side here is three small kernels, not a chain
-        # that overlaps the image side's.
-        self.pair_enc = self._pairable_encoder_layers() if os.environ.get('MVAE_PAIR_ENC', '1') != '0' else 0
+        # MVAE_PAIR_ENC=1 (tuning aid, off): the two ENCODERS' trailing layers of equal shape (MNIST: 512 -> 512 and the
+        # 512 -> 2D heads, mnist/model.py:76-78,117-119) as G = 2 launches on ONE stream -- the encoder phases then have no
+        # fork and no join, 35 -> 30 launches per step.  Measured on MI355X (profiles/r04_xcd_bn_pair_ab.txt, three
+        # interleaved pairs): 0.2996 / 0.2968 / 0.2987 ms paired against 0.2967 / 0.2949 / 0.2960 on two branches --
+        # 1 % SLOWER.  The side branch is real parallel work (its kernels run beside the image side's on idle CUs); a
+        # G = 2 launch takes as long as the two it replaces and the fork/join edge it removes is cheaper than that.
+        self.pair_enc = self._pairable_encoder_layers() if os.environ.get('MVAE_PAIR_ENC', '0') == '1' else 0
         # each decoder's backward runs to the latent on its own stream into its own buffer (poe_bwd_split adds
         # them); MVAE_SPLIT_DZ=0: one cleared dz both first layers accumulate into after the join
         self.split_dz = os.environ.get('MVAE_SPLIT_DZ', '1') != '0' 

@@ -73,7 +73,7 @@ class PoEStackFn(torch.autograd.Function):
         mu_stack, lv_stack = mu_stack.contiguous(), lv_stack.contiguous()
         M, B, D = mu_stack.shape
         dev = mu_stack.device
-        masks = torch.full((1,), (1 << M) - 1, dtype=torch.int32, device=dev)
+        masks = K.all_experts_mask(M, dev)
         mu = torch.empty(1, B, D, dtype=torch.float32, device=dev)
         lv = torch.empty_like(mu)
         mus = [mu_stack[e] for e in range(M)]

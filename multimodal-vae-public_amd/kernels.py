@@ -521,12 +521,34 @@ def _expert_ld(mus, lvs):
     return ld
 
 
+def all_experts_mask(n_experts, device):
+    """Device mask [1] with the low ``n_experts`` bits set -- the kernel reads it as uint32, the tensor is int32 with
+    the same bits ((1 << 32) - 1 does not fit torch.int32: MVAE_MAX_EXPERTS = 32 experts is the all-ones word, -1)."""
+    if not 1 <= n_experts <= _lib.MAX_EXPERTS:
+        raise RuntimeError('1..%d experts, got %d' % (_lib.MAX_EXPERTS, n_experts))
+    bits = (1 << n_experts) - 1
+    return torch.full((1,), bits - (1 << 32) if bits >= (1 << 31) else bits, dtype=torch.int32, device=device)
+
+
+def _check_no_prior_masks(masks_dev, variant, n_experts):
+    """MVAE_POE_NO_PRIOR: a term whose mask selects no expert is an empty product (0 / 0 precision: NaN mu, inf
+    logvar, no error from the launch -- the C side cannot see a device mask).  Host-built masks are checked here;
+    masks that only exist on the device (a captured graph's tables) are the caller's to keep non-empty."""
+    if not str(variant).endswith('-noprior') or masks_dev.numel() > 64 or torch.cuda.is_current_stream_capturing():
+        return
+    live = (1 << n_experts) - 1
+    for t, m in enumerate(masks_dev.tolist()):
+        if (m & live) == 0:
+            raise RuntimeError('PoE without the built-in prior: term %d selects no expert (mask %#x)' % (t, m & 0xffffffff))
+
+
 def poe_fwd(mus, lvs, masks_dev, noise, mu, logvar, z, kl, variant):
     """mus/lvs: per-expert [B,D] (possibly column slices of a [B,2D] head); masks_dev int32/uint32 [T]."""
     ld = _expert_ld(mus, lvs)
     _need_gpu(masks_dev, noise, mu, logvar, z, kl); _f32c(noise, mu, logvar, z, kl)
     T, B, D = mu.shape
     ex = _experts(mus, lvs)
+    _check_no_prior_masks(masks_dev, variant, len(mus))
     check(_lib.lib().mvae_poe_fwd(ctypes.byref(ex), ld, len(mus), _ptr(masks_dev), T, _ptr(noise), _ptr(mu),
                                   _ptr(logvar), _ptr(z), _ptr(kl), B, D, _lib.POE_VARIANT[variant],
                                   _stream()), 'mvae_poe_fwd')

@@ -66,6 +66,11 @@ class GradBuckets(object):
             raise RuntimeError('bucket %d launched twice in one step' % k)
         self.pending[k] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def reset(self):
+        """Forget launches a step that raised left behind (the next step would otherwise fail with 'launched twice'
+        instead of the real error)."""
+        self.pending.clear()
+
     def wait(self, k=None):
         """Fence bucket ``k`` (all pending ones when None).  With the nccl (= RCCL) backend this makes the
         CURRENT STREAM wait for the collective -- the host does not block; gloo blocks the host."""
@@ -98,20 +103,67 @@ class RcclComm(object):
 
     @classmethod
     def from_process_group(cls, device, group=None):
-        """Collective over ``group``: rank 0 makes the unique id, torch.distributed carries it to the peers."""
+        """Collective over ``group``: rank 0 makes the unique id, torch.distributed carries it to the peers.
+
+        Failure-safe rendezvous: every step that can fail on ONE rank is followed by a vote of ALL ranks
+        before anyone enters the next collective, and every rank issues the same sequence of torch.distributed
+        collectives whatever happened locally --
+
+          1. each rank binds RCCL (dlopen + symbols + ncclGetVersion), rank 0 also creates the unique id; failures are
+             caught, not raised;
+          2. broadcast of [status byte | id] from rank 0 -- unconditional, also when rank 0 has no id to send;
+          3. MIN all-reduce of "my binding worked and rank 0 had an id": if anyone failed, NOBODY calls
+             ``ncclCommInitRank`` (a collective the failed rank would never join) and all raise the same error;
+          4. ``mvae_comm_init`` on all ranks; then a second MIN vote, so a rank whose init failed does not leave its peers
+             believing in a communicator it is not part of.
+        """
         from . import _lib
-        cls.bind_torch_rccl()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
+        why = None
+        try:
+            cls.bind_torch_rccl()
+            if _lib.lib().mvae_comm_rccl_version() <= 0:
+                why = 'RCCL could not be bound (dlopen / symbols / ncclGetVersion)'
+        except Exception as e:
+            why = '%s: %s' % (type(e).__name__, e)
+        msg = torch.zeros(1 + _lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0 and why is None:
             buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
-            _lib.check(_lib.lib().mvae_comm_unique_id(buf, _lib.COMM_ID_BYTES), 'mvae_comm_unique_id')
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
-        ident = ident.to(device)
-        dist.broadcast(ident, src=0, group=group)
-        raw = bytes(ident.cpu().tolist())
-        torch.cuda.synchronize(device)
-        return cls(rank, world, (ctypes.c_ubyte * len(raw)).from_buffer_copy(raw), device.index)
+            rc = _lib.lib().mvae_comm_unique_id(buf, _lib.COMM_ID_BYTES)
+            if rc == 0:
+                msg[0] = 1
+                msg[1:] = torch.tensor(list(buf), dtype=torch.uint8)
+            else:
+                why = 'mvae_comm_unique_id failed (%d)' % rc
+        msg = msg.to(device)
+        dist.broadcast(msg, src=0, group=group)
+        host = msg.cpu()
+        if why is None and int(host[0]) != 1:
+            why = 'rank 0 could not create a unique id'
+        cls._vote(why is None, device, group, why, 'binding RCCL / creating the unique id')
+        raw = bytes(host[1:].tolist())
+        if torch.device(device).type == 'cuda':
+            torch.cuda.synchronize(device)
+        comm, why = None, None
+        try:
+            comm = cls(rank, world, (ctypes.c_ubyte * len(raw)).from_buffer_copy(raw), torch.device(device).index or 0)
+        except Exception as e:
+            why = '%s: %s' % (type(e).__name__, e)
+        try:
+            cls._vote(why is None, device, group, why, 'mvae_comm_init')
+        except Exception:
+            if comm is not None:
+                comm.destroy()
+            raise
+        return comm
+
+    @staticmethod
+    def _vote(ok, device, group, why, what):
+        """All ranks agree (MIN) that a step worked everywhere; otherwise ALL raise."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            raise RuntimeError('%s failed on %s' % (what, ('this rank: %s' % why) if why else 'a peer'))
 
     @property
     def rccl_version(self):
@@ -191,6 +243,8 @@ class RcclBuckets(object):
             raise RuntimeError('bucket %d launched twice in one step' % k)
         self.pending[k] = self.comm.allreduce_async(self.flat[lo:hi])
 
+    reset = GradBuckets.reset
+
     def wait(self, k=None):
         keys = sorted(self.pending) if k is None else [k]
         for key in keys:
@@ -217,7 +271,13 @@ class DataParallel(object):
             dist.broadcast(b, src=0, group=group)
         ranges = bucket_ranges(model, arena)
         self.comm, self.transport = None, 'torch.distributed (%s)' % dist.get_backend(group)
-        want = os.environ.get('MVAE_COMM', 'rccl' if transport is None else transport)
+        # an explicit ``transport=`` wins; MVAE_COMM only fills in for a caller that did not choose
+        want = transport if transport is not None else os.environ.get('MVAE_COMM', 'rccl')
+        if self.world > 1 and arena.flat.is_cuda and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') != '0':
+            sys.stderr.write('[mvae parallel] HSA_ENABLE_IPC_MODE_LEGACY=%s: this driver only supports dmabuf IPC -- RCCL '
+                             'across processes is expected to fail with hipIpcGetMemHandle: invalid argument; export '
+                             'HSA_ENABLE_IPC_MODE_LEGACY=0 before the process first touches the GPU\n'
+                             % os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])
         if want == 'rccl' and dist.get_backend(group) == 'nccl' and arena.flat.is_cuda:
             why = None
             try:
@@ -259,6 +319,9 @@ class DataParallel(object):
     def launch(self, k):
         """Start the all-reduce of bucket k (called by the engine between captured graphs)."""
         self.buckets.launch(k)
+
+    def reset(self):
+        self.buckets.reset()
 
     def wait(self, k=None):
         self.buckets.wait(k)

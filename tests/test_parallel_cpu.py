@@ -169,3 +169,146 @@ def test_bench_refuses_a_launcher_that_disagrees_with_the_flag():
     rc, line, err = _run_bench(['--gpus', '4', '--backend', 'gloo'],
                                {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert rc != 0 and line is None and 'WORLD_SIZE=1' in err
+
+
+# ----------------------------------------------------------------------------- the time-boxed transport chain
+def test_transport_chain_survives_a_hang_and_a_crash():
+    """the first N > 1 run must not be able to return nothing.  Every launched rank is a supervisor
+    (mvae_amd/launch.py) that runs each transport in a child under a wall-clock budget.  Here the first transport
+    HANGS (one rank never reaches the collective, its peer blocks in it), the second RAISES, the third works: the line
+    comes from the third, within the budgets, and says what was given up on."""
+    import time
+    t0 = time.time()
+    rc, line, err = _run_bench(['--gpus', '2', '--backend', 'gloo'],
+                               {'MVAE_BENCH_CHAIN': 'fake-hang:8,fake-raise:60,default:120'}, timeout=300)
+    wall = time.time() - t0
+    assert rc == 0, err[-3000:]
+    assert line['n_gpus'] == 2 and line['dist']['allreduce_of_ones'] == 2.0
+    tried = line['dist']['fallbacks_tried']
+    assert [t['transport'] for t in tried] == ['fake-hang', 'fake-raise']
+    assert 'timeout' in tried[0]['ranks'] or 'peer-failed' in tried[0]['ranks']
+    assert any(v.startswith('rc=') for v in tried[1]['ranks'])
+    assert line['dist']['transport_attempt'] == 'default'
+    assert tried[0]['wall_s'] < 8 + 30 and wall < 200, (tried, wall)
+
+
+def test_transport_chain_reports_when_every_transport_fails():
+    rc, line, err = _run_bench(['--gpus', '2', '--backend', 'gloo'],
+                               {'MVAE_BENCH_CHAIN': 'fake-raise:60,fake-hang:6'}, timeout=300)
+    assert line is not None and line['value'] is None and line['n_gpus'] == 2
+    assert [t['transport'] for t in line['dist']['fallbacks_tried']] == ['fake-raise', 'fake-hang']
+
+
+def test_run_attempt_kills_the_whole_process_group_on_timeout(tmp_path):
+    """A child that spawns a grandchild and hangs: both are gone after the budget (the supervisor made the process
+    group itself, so killing it cannot touch anything else)."""
+    import sys
+    import time
+    import mvae_amd  # noqa: F401
+    from mvae_amd import launch
+    pidfile = tmp_path / 'pids'
+    code = ('import os, subprocess, sys, time\n'
+            'p = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])\n'
+            'open(%r, "w").write("%%d %%d" %% (os.getpid(), p.pid))\n'
+            'print("{\\"partial\\": 1}"); sys.stdout.flush()\n'
+            'time.sleep(600)\n' % str(pidfile))
+    t0 = time.time()
+    status, out = launch.run_attempt([sys.executable, '-c', code], dict(os.environ), 3.0)
+    assert status == 'timeout' and time.time() - t0 < 30
+    assert launch.last_json_line(out) == {'partial': 1}
+    for pid in (int(v) for v in pidfile.read_text().split()):
+        for _ in range(50):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                break
+            time.sleep(0.1)
+        else:
+            # a zombie still answers kill(0); it must at least not be running
+            assert open('/proc/%d/stat' % pid).read().split()[2] in ('Z', 'X'), 'pid %d survived' % pid
+    status, out = launch.run_attempt([sys.executable, '-c', 'print("{\\"a\\": 2}")'], dict(os.environ), 30.0)
+    assert status == 'ok' and launch.last_json_line(out) == {'a': 2}
+    status, _ = launch.run_attempt([sys.executable, '-c', 'raise SystemExit(7)'], dict(os.environ), 30.0)
+    assert status == 'rc=7'
+    assert [a.name for a in launch.parse_chain('fake-hang:2, default')] == ['fake-hang', 'default']
+    with pytest.raises(ValueError):
+        launch.parse_chain('no-such-transport')
+
+
+# ----------------------------------------------------------------------------- failure-safe communicator rendezvous
+class _FakeCommLib(object):
+    """Stands in for libmvae_hip.so's mvae_comm_* entry points: which step fails on which rank is the test's choice."""
+    def __init__(self, rank, scenario, log):
+        self.rank, self.scenario, self.log = rank, scenario, log
+
+    def mvae_comm_use_library(self, path):
+        return 0
+
+    def mvae_comm_rccl_version(self):
+        return -5 if (self.scenario == 'bind-fails-on-1' and self.rank == 1) else 22105
+
+    def mvae_comm_unique_id(self, buf, n):
+        if self.scenario == 'id-fails-on-0':
+            return -5
+        for i in range(n):
+            buf[i] = (i * 7 + 3) % 251
+        return 0
+
+    def mvae_comm_init(self, h, uid, n, rank, world, device):
+        self.log.append('init')
+        assert bytes(uid)[:4] == bytes([(i * 7 + 3) % 251 for i in range(4)])
+        return -5 if (self.scenario == 'init-fails-on-1' and self.rank == 1) else 0
+
+    def mvae_comm_destroy(self, h):
+        self.log.append('destroy')
+        return 0
+
+    def mvae_comm_last_error(self, h):
+        return b'fake'
+
+
+def _rendezvous_worker(rank, world, port, scenario, outdir):
+    import torch
+    import torch.distributed as dist
+    import mvae_amd  # noqa: F401
+    from mvae_amd import _lib, parallel
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    log = []
+    fake = _FakeCommLib(rank, scenario, log)
+    _lib.lib = lambda: fake
+    try:
+        comm = parallel.RcclComm.from_process_group(torch.device('cpu'))
+        outcome = 'comm rank %d/%d' % (comm.rank, comm.world)
+    except RuntimeError as e:
+        outcome = 'raised: %s' % e
+    # whatever happened, the ranks are still in step: one more collective completes
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    with open(os.path.join(outdir, 'r%d' % rank), 'w') as f:
+        f.write('%s | %s | %g' % (outcome, ','.join(log), t.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('scenario,expect', [
+    ('ok', ('comm rank 0/2', 'comm rank 1/2')),
+    ('bind-fails-on-1', ('raised: binding RCCL / creating the unique id failed on a peer',
+                         'raised: binding RCCL / creating the unique id failed on this rank')),
+    ('id-fails-on-0', ('raised: binding RCCL / creating the unique id failed on this rank',
+                       'raised: binding RCCL / creating the unique id failed on this rank')),
+    ('init-fails-on-1', ('raised: mvae_comm_init failed on a peer', 'raised: mvae_comm_init failed on this rank'))])
+def test_communicator_rendezvous_is_collective_safe(scenario, expect, tmp_path):
+    """a rank that cannot bind RCCL / make the id / init must not leave its peers in a different
+    collective.  All ranks raise together (or none), nobody enters ncclCommInitRank after a failed vote, and the process
+    group is still usable afterwards."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_rendezvous_worker, args=(world, port, scenario, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        outcome, log, total = open(os.path.join(str(tmp_path), 'r%d' % r)).read().split(' | ')
+        assert outcome.startswith(expect[r]), (r, outcome)
+        assert float(total) == 2.0
+        if scenario in ('bind-fails-on-1', 'id-fails-on-0'):
+            assert 'init' not in log          # nobody entered the collective init
+        if scenario == 'init-fails-on-1' and r == 0:
+            assert log == 'init,destroy'      # the healthy rank gave its communicator back
