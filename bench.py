@@ -59,7 +59,7 @@ def synthetic(kind, batch, seed, device):
     return image.to(device), label.to(device)
 
 
-def build(kind, batch, device, world, seed=0):
+def build(kind, batch, device, world, seed=0, faithful_bn_stats=True):
     import mvae_amd
     from mvae_amd.optim import FusedAdam
     torch.manual_seed(seed)
@@ -67,7 +67,8 @@ def build(kind, batch, device, world, seed=0):
     model.finalize()
     if kind == 'celeba19':
         from mvae_amd.engine import Celeba19Step
-        eng = Celeba19Step(model, batch, 1.0, LAMBDA_LABEL[kind], approx_m=1, seed=1234)
+        eng = Celeba19Step(model, batch, 1.0, LAMBDA_LABEL[kind], approx_m=1, seed=1234,
+                           faithful_bn_stats=faithful_bn_stats)
     else:
         from mvae_amd.engine import BimodalStep
         eng = BimodalStep(model, batch, 1.0, LAMBDA_LABEL[kind], seed=1234)
@@ -79,9 +80,9 @@ def annealing(step, total=2000):
     return min(1.0, float(step + 1) / total)
 
 
-def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, force_dp=False):
+def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, force_dp=False, faithful_bn_stats=True):
     import torch.distributed as dist
-    model, eng, opt = build(kind, batch, device, world)
+    model, eng, opt = build(kind, batch, device, world, faithful_bn_stats=faithful_bn_stats)
     dp = None
     if world > 1 or force_dp:
         from mvae_amd.parallel import DataParallel
@@ -125,6 +126,22 @@ def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, f
     for i in range(warmup):
         one(i)
     dt, elbo = timed(steps, warmup)
+    # per-step distribution (median of >= 50 steps): a SEPARATE pass with a HIP event between consecutive
+    # steps on the launch stream -- the events are not inside the region `value` is computed from
+    dist_steps = None
+    if device.type == 'cuda' and world == 1:
+        n = max(50, steps)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        torch.cuda.synchronize(device)
+        for i in range(n):
+            evs[i].record()
+            one(warmup + steps + i)
+        evs[n].record()
+        torch.cuda.synchronize(device)
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        dist_steps = {'steps': n, 'ms_per_step_median': round(per[n // 2], 4), 'ms_per_step_p10': round(per[n // 10], 4),
+                      'ms_per_step_p90': round(per[(n * 9) // 10], 4), 'ms_per_step_max': round(per[-1], 4),
+                      'how': 'separate pass after the timed region: one HIP event between consecutive steps on the launch stream'}
     info = None
     if dp is not None:
         # what the data-parallel exchange costs: the same launch path with the collectives switched off
@@ -141,7 +158,7 @@ def timed_run(kind, batch, steps, warmup, device, world, rank, use_graph=True, f
                 'ms_per_step_without_collectives': round(dt_off / n2 * 1e3, 4),
                 'exposed_comm_ms_per_step': round((dt / steps - dt_off / n2) * 1e3, 4)}
     loss = float(elbo[-1].item())
-    return dt, loss, (model, eng, opt, batches, info)
+    return dt, loss, (model, eng, opt, batches, info, dist_steps)
 
 
 def _spin_cycles_per_second():
@@ -154,7 +171,7 @@ def _spin_cycles_per_second():
     return 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
 
 
-def roofline_from_profile(eng, opt, batches, n_steps=3):
+def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
     """Which launches make up a step, and how fast each runs IN the step.
 
     Every launcher of kernels.py is bracketed by a pair of HIP events on the launch stream and tagged with
@@ -208,6 +225,9 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
         'achieved': round(dom['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic_for(dom['name'], dom['key']),
         'avg_launch_ms': round(dom['ms_avg'], 5), 'algorithmic_flops_per_launch': dom['flops'],
+        # the same call in the committed rocprofv3 kernel trace of one eager step (tools/step_by_shape.py: kernel
+        # durations only, no launch boundary) and the fraction that gives -- the figure a reader can recompute from profiles/
+        'rocprof_avg_us': rocprof_us_for(kind, dom['name'], dom['key']),
         'calls_per_step': dom['calls'] / n_steps,
         'timing': 'in-situ: HIP event pairs on the launch stream around every call of %d eager single-stream '
                   'steps enqueued behind a spin kernel (queue full, no host gap inside an interval; an interval '
@@ -220,6 +240,8 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
                              'frac': round(flops_step / (ms_gemm * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                              'ms_per_step': round(ms_gemm, 4), 'gflop_per_step': round(flops_step / 1e9, 3)},
     }
+    if roof['rocprof_avg_us']:
+        roof['rocprof_frac'] = round(dom['flops'] / (roof['rocprof_avg_us'] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
     conv = [r for r in gemm if r['name'].startswith('conv')]
     if conv:
         fl = sum(r['flops'] * r['calls'] for r in conv) / n_steps
@@ -228,8 +250,11 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
                                 'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 'ms_per_step': round(ms, 4), 'gflop_per_step': round(fl / 1e9, 3)}
     if top is not None:
-        roof['top_hbm_kernel'] = {'kernel': top['name'], 'gbs': round(top['gbs'], 1),
-                                  'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5)}
+        roof['top_hbm_kernel'] = {'kernel': ('%s %s' % (top['name'], top['key'])).strip(), 'gbs': round(top['gbs'], 1),
+                                  'frac': round(top['gbs'] / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(top['ms_avg'], 5),
+                                  'algorithmic_bytes_per_launch': top['bytes'],
+                                  'bytes': 'SURVEY 8(d): Adam 28 B/param, BatchNorm fwd 3 / bwd 5 transfers, BCE 2*rows*P*4 (+ the '
+                                           'gradient written), PoE per its formula (mvae_amd/profiler.py HBM_COSTS)'}
     roof['queue_full_during_enqueue'] = bool(queue_was_full)
     roof['launches_per_step'] = sum(r['calls'] for r in rows) / n_steps
     roof['top_kernels'] = [{'kernel': '%s %s' % (r['name'], r['key']), 'ms_per_step': round(r['ms_total'] / n_steps, 4),
@@ -237,7 +262,66 @@ def roofline_from_profile(eng, opt, batches, n_steps=3):
     return roof
 
 
-TRAFFIC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_traffic.json', 'r02_traffic.json')]
+TRAFFIC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json')]
+BY_SHAPE_FILE = os.path.join(ROOT, 'profiles', 'r04_by_shape.json')
+
+
+def rocprof_us_for(kind, name, key):
+    """Average rocprofv3 duration (us) of the call's kernels in the committed per-(call, shape) table of this workload's
+    step (profiles/r04_by_shape.json, made by tools/step_by_shape.py on the GPU box); None if not traced."""
+    try:
+        with open(BY_SHAPE_FILE) as f:
+            ent = json.load(f).get(kind, {}).get('%s %s' % (name, key))
+    except (IOError, ValueError):
+        return None
+    return None if ent is None else ent['rocprof_avg_us']
+
+
+def module_surface(kind, batch, device, steps=20, warmup=5):
+    """The loop a reference user keeps (mnist/train.py:197-219, celeba/train.py:190-212): three ``model()`` calls, three
+    ``elbo_loss`` calls, ``backward()``, ``optimizer.step()`` on the drop-in nn.Modules -- eager, autograd, no fused engine,
+    no graph -- with torch.optim.Adam and with FusedAdam.  Not `value`: how far the module surface is from the headline."""
+    import mvae_amd
+    import mvae_amd.functional as MF
+    from mvae_amd.optim import FusedAdam
+    out = {'what': 'reference-shaped loop on the drop-in modules: 3 model() + 3 elbo_loss + backward + optimizer.step(), eager',
+           'steps': steps, 'batch': batch}
+    image, label = synthetic(kind, batch, 4321, device)
+    for opt_name in ('torch.optim.Adam', 'FusedAdam'):
+        torch.manual_seed(0)
+        model = getattr(mvae_amd, kind).model.MVAE(N_LATENTS[kind]).to(device).train()
+        model.finalize()
+        opt = (torch.optim.Adam if opt_name == 'torch.optim.Adam' else FusedAdam)(model.parameters(), lr=LR[kind])
+        lam = LAMBDA_LABEL[kind]
+
+        def step(i):
+            opt.zero_grad()
+            beta = annealing(i)
+            if kind == 'celeba':
+                r1, r2, r3 = model(image, label), model(image), model(attrs=label)
+                kw = dict(lambda_image=1.0, lambda_attrs=lam, annealing_factor=beta)
+                elbo = MF.elbo_loss_attrs
+            else:
+                r1, r2, r3 = model(image, label), model(image), model(text=label)
+                kw = dict(lambda_image=1.0, lambda_text=lam, annealing_factor=beta)
+                elbo = MF.elbo_loss_label
+            loss = (elbo(r1[0], image, r1[1], label, r1[2], r1[3], **kw) + elbo(r2[0], image, None, None, r2[2], r2[3], **kw)
+                    + elbo(None, None, r3[1], label, r3[2], r3[3], **kw))
+            loss.backward()
+            opt.step()
+            return loss
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(warmup + i)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[opt_name] = {'ms_per_step': round(dt / steps * 1e3, 3), 'images_per_sec': round(batch * steps / dt, 1),
+                         'final_loss': round(float(loss.item()), 3)}
+        del model, opt
+    return out
 
 
 def traffic_for(name, key):
@@ -394,6 +478,8 @@ def cpu_baseline(kind, batch, budget_s=15.0, with_delta=True, threads=None):
                      '%d intra-op threads (the better sustained rate of the two lowest probe medians, %d steps '
                      'each, among %s) on a %d-CPU host' % (
                          n, kind, batch, torch.__version__, threads, n_probe, cands, host['nproc'])}
+    out['note'] = ('the hosts of this pool are shared 256-CPU boxes: the same code has read 8.3 K and 15.2 K images/sec on '
+                   'MNIST in two runs -- a stated baseline beside the GPU figure, never the target')
     if with_delta:
         out['elbo_delta'] = elbo_delta(kind, 8 if kind == 'celeba19' else 32)
     return out
@@ -439,8 +525,23 @@ def extra_workload(kind, batch, steps, warmup, device, use_graph, cpu_budget_s):
     ent = {'workload': '%s MVAE train step, n-latents %d, batch %d, 1 GPU' % (kind, N_LATENTS[kind], batch),
            'value': round(batch * steps / dt, 1), 'unit': 'images/sec', 'steps': steps, 'warmup': warmup,
            'ms_per_step': round(dt / steps * 1e3, 3), 'final_loss': round(loss, 3),
-           'roofline': roofline_from_profile(st[1], st[2], st[3]),
+           'step_distribution': st[5],
+           'roofline': roofline_from_profile(st[1], st[2], st[3], kind=kind),
            'cpu_baseline': cpu_baseline(kind, batch, budget_s=cpu_budget_s)}
+    if kind == 'celeba':
+        ent['module_surface'] = module_surface(kind, batch, device)
+    if kind == 'celeba19':
+        # SURVEY Appendix B-4 made explicit: what reproducing the reference's BatchNorm side effects costs.  The line
+        # above (and every parity test) is the 'reference' mode; this is `celeba19/train.py --bn-stats loss-bearing`
+        # (the 18 image decodes nobody reads are skipped; ELBO and gradients unchanged, running statistics differ).
+        del st
+        gc.collect()
+        torch.cuda.empty_cache()
+        dt2, loss2, st = timed_run(kind, batch, steps, warmup, device, 1, 0, use_graph=use_graph, faithful_bn_stats=False)
+        ent['bn_stats_loss_bearing'] = {
+            'ms_per_step': round(dt2 / steps * 1e3, 3), 'value': round(batch * steps / dt2, 1), 'unit': 'images/sec',
+            'what': "celeba19/train.py --bn-stats loss-bearing: image decoder run for the 2 + M terms with an image loss only; "
+                    "NOT the reference's BatchNorm running statistics -- never the headline"}
     del st
     gc.collect()
     torch.cuda.empty_cache()
@@ -571,14 +672,21 @@ def main():
                                  out['dist']['world_size'], out['dist']['backend'], out['dist'].get('rccl_version'),
                                  out['dist']['allreduce_of_ones'], out['dist']['bucket_bytes'],
                                  out['dist']['exposed_comm_ms_per_step']))
+    if state[5] is not None:
+        out.update({k: state[5][k] for k in ('ms_per_step_median', 'ms_per_step_p90')})
+        out['step_distribution'] = state[5]
     if rank == 0 and world == 1 and not args.no_extras and not args.force_dp:
         model, eng, opt, batches = state[:4]
-        out['roofline'] = roofline_from_profile(eng, opt, batches)
+        out['roofline'] = roofline_from_profile(eng, opt, batches, kind=kind)
         out['cpu_baseline'] = cpu_baseline(kind, batch)
+        if kind in ('mnist', 'celeba'):
+            out['module_surface'] = module_surface(kind, batch, device)
         if kind == 'mnist':
-            # BASELINE.json configs[0]: the reference's own CPU-runnable case, mnist batch 128
+            # BASELINE.json configs[0]: the reference's own CPU-runnable case, mnist batch 128 -- the CPU rate and the
+            # ELBO / gradient delta of the HIP engine against it at that exact batch
             out['cpu_baseline']['cfg0_mnist_b128'] = cpu_baseline('mnist', 128, budget_s=6.0, with_delta=False,
                                                                    threads=out['cpu_baseline']['threads'])
+            out['cpu_baseline']['cfg0_mnist_b128']['elbo_delta'] = elbo_delta('mnist', 128)
         if kind == 'mnist' and args.batch is None:
             # the other three GPU configurations of BASELINE.json at their per-GPU batch, bounded: configs[2]
             # FashionMNIST 1024, configs[3] CelebA 256 (the conv stack north_star's 40 % MFMA target is about),

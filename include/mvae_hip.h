@@ -390,6 +390,12 @@ int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *e
                        size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                        const int64_t *step_dev, int64_t step_add, mvae_stream_t stream);
 int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
+
+/* Measurement aid (no reference counterpart): an EMPTY kernel on `stream`.  A profiling host launches one in front of
+ * every call of a single-stream step; in the rocprofv3 kernel trace the k-th marker dispatch then separates the kernels
+ * of call k - 1 from those of call k (tools/step_by_shape.py -> profiles/r04_*_by_shape.txt, the per-(call, shape)
+ * table bench.py's roofline.rocprof_avg_us is read from).  `tag` is not interpreted. */
+int mvae_trace_marker(int tag, mvae_stream_t stream);
 int mvae_fill(float *out, size_t n, float value, mvae_stream_t stream);
 /* One launch that puts a step's inputs where a captured graph reads them -- what `image.cuda()`, `text.cuda()`
  * (mnist/train.py:188-190) and the per-step scalars (annealing factor :180-186) amount to for a replayed step:

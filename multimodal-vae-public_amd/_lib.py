@@ -125,6 +125,7 @@ _SIGNATURES = {
     'mvae_adam_apply_at': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P,
                                    ctypes.c_int64, P]),
     'mvae_counter_add': (c_int, [P, ctypes.c_int64, P]),
+    'mvae_trace_marker': (c_int, [c_int, P]),
     'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
     'mvae_ingest': (c_int, [P, P, c_size_t, P, P, c_size_t, P, P, c_size_t, P]),
     'mvae_reparam_fwd': (c_int, [P, P, P, P, c_size_t, P]),

@@ -77,7 +77,8 @@ def _make_engine(model, args, rank, batch_size):
         np.random.seed(681307)
         _make_engine.seeded = True
     return Celeba19Step(model, batch_size, args.lambda_image, args.lambda_attrs,
-                        approx_m=args.approx_m, seed=1 + rank, rng=np.random)
+                        approx_m=args.approx_m, seed=1 + rank, rng=np.random,
+                        faithful_bn_stats=getattr(args, 'bn_stats', 'reference') == 'reference')
 
 
 if __name__ == "__main__":

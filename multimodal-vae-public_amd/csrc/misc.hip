@@ -322,6 +322,16 @@ MVAE_EXPORT int mvae_adam_apply_at(float *param, const float *grad, float *exp_a
     return mvae_launch_status();
 }
 
+// An empty kernel a profiling host puts between two calls: in a rocprofv3 kernel trace of ONE stream the k-th
+// `trace_marker_kernel` dispatch separates the kernels of call k - 1 from those of call k, which is how
+// tools/step_by_shape.py attributes dispatches (GEMM + finish launch + ...) to the launcher call and its shape.
+__global__ void trace_marker_kernel(int tag) { (void)tag; }
+
+MVAE_EXPORT int mvae_trace_marker(int tag, mvae_stream_t stream) {
+    hipLaunchKernelGGL(trace_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, tag);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream) {
     if (!counter_dev) return MVAE_ERR_ARG;
     hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, delta);

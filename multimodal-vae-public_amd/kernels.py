@@ -736,6 +736,11 @@ def adam_apply_at(param, grad, exp_avg, exp_avg_sq, step_dev, step_add, lr, beta
           'mvae_adam_apply_at')
 
 
+def trace_marker(tag=0):
+    """An empty kernel on the current stream (tools/step_by_shape.py splits a rocprofv3 kernel trace at these)."""
+    check(_lib.lib().mvae_trace_marker(int(tag), _stream()), 'mvae_trace_marker')
+
+
 def counter_add(counter_dev, delta):
     _need_gpu(counter_dev)
     check(_lib.lib().mvae_counter_add(_ptr(counter_dev), int(delta), _stream()), 'mvae_counter_add')

@@ -3,7 +3,9 @@
 ``with KernelProfile() as prof:`` wraps every launcher of ``kernels.py`` in a pair of
 ``torch.cuda.Event`` records on ``torch.cuda.current_stream()`` -- the same stream the C ABI
 receives -- and tags it with the ALGORITHMIC work of the call (2*M*N*K flops for the GEMM-shaped
-ops, bytes of the tensor arguments for the HBM-bound ones).  ``bench.py`` uses it for the
+ops; for the HBM-bound ones the bytes SURVEY.md section 8(d) prescribes -- ``HBM_COSTS`` -- and the bytes of the
+tensor arguments for the small plumbing kernels it does not list).  ``marker=True`` also launches an empty
+``trace_marker_kernel`` in front of every call and keeps the call sequence (tools/step_by_shape.py).  ``bench.py`` uses it for the
 ``roofline`` object (live, in the same process as the timed run); the rocprofv3 kernel trace
 committed under ``profiles/`` is the cross-check.
 """
@@ -95,6 +97,54 @@ GEMM_COSTS = {
     'conv2d_wgrad': _conv_cost('conv2d_wgrad'), 'convT2d_fwd': _conv_cost('convT2d_fwd'),
     'convT2d_dgrad': _conv_cost('convT2d_dgrad'), 'convT2d_wgrad': _conv_cost('convT2d_wgrad'),
 }
+# ---- ALGORITHMIC bytes of the HBM-bound ops, SURVEY.md section 8(d) (what the OP must move, whatever kernel runs it):
+#      Adam 28 B / parameter (read p, g, m, v; write p, m, v); BatchNorm forward 3 transfers of the activation (the
+#      statistics need x before the apply reads it again: read, read, write), backward 5 (dy and x for the two sums,
+#      dy and x again for the apply, dx written) -- the single-launch kernels of norm.hip move 2 / 3 for small slices
+#      and can read above 1.0 of this figure's rate; BCE rows: read logits + target, write the row sums (+ d loss /
+#      d logits when the launch also produces it); PoE + reparameterise + KL: read the experts' (mu, logvar) and eps,
+#      write mu, logvar, z and the KL rows.
+def _bn_fwd_bytes(x, gamma, beta, y, *a, **kw):
+    return (3 if y is not None else 1) * x.numel() * 4
+
+
+def _bn_bwd_bytes(dy, x, *a, **kw):
+    return 5 * x.numel() * 4
+
+
+def _adam_bytes(param, *a, **kw):
+    return 28 * param.numel()
+
+
+def _bce_rows_bytes(logits, target, rowsum, colw=None, drow=None, dlogits=None, *a, **kw):
+    return 2 * logits.numel() * 4 + rowsum.numel() * 4 + (logits.numel() * 4 if dlogits is not None else 0)
+
+
+def _poe_fwd_bytes(mus, lvs, masks_dev, noise, mu, logvar, z, kl, *a, **kw):
+    T, B, D = mu.shape
+    E = len(mus)
+    return (2 * E + (T if noise is not None else 0)) * B * D * 4 + 3 * T * B * D * 4 + T * B * 4
+
+
+def _poe_draw_bytes(mus, lvs, masks_dev, noise_out, seed, counter_dev, counter_offset, mu, logvar, z, kl, *a, **kw):
+    T, B, D = mu.shape
+    return 2 * len(mus) * B * D * 4 + 4 * T * B * D * 4 + T * B * 4       # eps is written, not read
+
+
+def _poe_bwd_bytes(mus, lvs, masks_dev, noise, mu, logvar, *a, **kw):
+    T, B, D = mu.shape
+    E = len(mus)
+    # read the experts, eps, the fused (mu, logvar) and dz per term; write the experts' gradients
+    return (2 * E + 4 * T) * B * D * 4 + 2 * E * B * D * 4
+
+
+HBM_COSTS = {
+    'bn_train_fwd': _bn_fwd_bytes, 'bn_train_bwd': _bn_bwd_bytes,
+    'adam_step': _adam_bytes, 'adam_apply': _adam_bytes, 'adam_apply_at': _adam_bytes,
+    'bce_rowsum_fwd': _bce_rows_bytes,
+    'poe_fwd': _poe_fwd_bytes, 'poe_fwd_draw': _poe_draw_bytes, 'poe_bwd': _poe_bwd_bytes, 'poe_bwd_split': _poe_bwd_bytes,
+}
+
 HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bwd', 'embedding_swish_fwd',
            'embedding_swish_bwd', 'poe_fwd', 'poe_bwd', 'kl_rows_fwd', 'kl_rows_bwd', 'bce_rowsum_fwd',
            'bce_rowsum_bwd', 'ce_fwd', 'ce_bwd', 'group_sums', 'randn_', 'bernoulli_', 'adam_step', 'fill_',
@@ -105,23 +155,38 @@ HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bw
 
 
 class KernelProfile(object):
-    def __init__(self):
+    def __init__(self, marker=False, timed=True):
+        self.marker = marker                 # an empty kernel in front of every call + the call sequence
+        self.timed = timed                   # False: no event pairs (a rocprofv3 trace supplies the durations)
+        self.sequence = []                   # [(name, key)] in launch order
         self.records = []
         self.last_call = {}      # (name, key) -> (launcher, args, kwargs) of the most recent call
         self._saved = {}
 
     def _wrap(self, name, fn, cost):
         def wrapped(*a, **kw):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+            if self.marker:
+                K.trace_marker(len(self.sequence))
+            e0 = e1 = None
+            if self.timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             out = fn(*a, **kw)
-            e1.record()
+            if self.timed:
+                e1.record()
             if cost is not None:
                 flops, key = cost(*a, **kw)
                 nbytes = 0
             else:
-                flops, key, nbytes = 0.0, '', _numel_bytes(a, kw)
+                by = HBM_COSTS.get(name)
+                flops, key, nbytes = 0.0, '', (by(*a, **kw) if by is not None else _numel_bytes(a, kw))
+                if by is not None:       # the listed ops are reported per shape (a step has BatchNorms of 14 sizes)
+                    first = next((t for t in a if torch.is_tensor(t)), None)
+                    key = 'x'.join(str(s) for s in first.shape) if first is not None else '%d B' % nbytes
+            self.sequence.append((name, key, flops, nbytes))
+            if not self.timed:
+                return out
             self.records.append((name, key, flops, nbytes, e0, e1))
             self.last_call[(name, key)] = (fn, a, kw)
             return out

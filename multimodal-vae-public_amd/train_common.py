@@ -93,6 +93,16 @@ def reference_parser(kind):
         parser.add_argument(flag, **kw)
     parser.add_argument('--cuda', action='store_true', default=False, help='enables CUDA training [default: False]')
     add_extra_flags(parser)
+    if kind == 'celeba19':
+        # SURVEY Appendix B-4, decided explicitly: every model() call of the reference runs the image decoder
+        # (celeba19/model.py:52-61), also for the 18 attribute-only terms whose image output nobody reads
+        # (celeba19/train.py:278-283) -- their only effect is 18 more BatchNorm running-statistics updates per step.
+        parser.add_argument('--bn-stats', choices=('reference', 'loss-bearing'), default='reference',
+                            help="'reference': the image decoder's BatchNorm running statistics advance for all 20 + M "
+                                 "terms, as in the reference (18 decodes whose output is unused). 'loss-bearing': only the "
+                                 "2 + M terms with an image loss are decoded -- same ELBO and gradients, faster step, "
+                                 "running_mean / running_var (eval-mode behaviour, checkpoints) differ from the reference "
+                                 "[default: reference]")
     return parser
 
 

@@ -192,3 +192,39 @@ def test_constructing_an_engine_draws_nothing_from_the_subset_generator():
     image, attrs = OS.synthetic_batch('celeba19', 4, seed=86)
     eng.step(image.to(DEV), attrs.to(DEV), 0.5)
     assert np.array_equal(eng.combos, expect)
+
+
+def test_loss_bearing_bn_stats_mode_keeps_elbo_and_gradients():
+    """SURVEY Appendix B-4 decided explicitly (``celeba19/train.py --bn-stats loss-bearing`` -> ``faithful_bn_stats=False``):
+    the 18 attribute-only terms' image decodes -- whose output the reference never reads (celeba19/train.py:278-283)
+    -- are skipped.  ELBO terms and every gradient still equal the reference's (1e-4); what changes, and is the
+    documented divergence, is the image decoder's BatchNorm state: 2 + M running-statistics updates instead of
+    20 + M, so running_mean / running_var / num_batches_tracked differ; the image ENCODER's state does not."""
+    approx_m, batch = 1, 6
+    oracle, model, d = build_pair('celeba19', weight_seed=29)
+    image, attrs = OS.synthetic_batch('celeba19', batch, seed=83)
+    combos = sample_subsets(np.random.RandomState(11), 19, approx_m)
+    terms = OS.celeba19_terms(combos)
+    torch.manual_seed(10)
+    noise = OS.draw_celeba19_noise(batch, d, terms)
+    total, elbos, _ = OS.celeba19_step(oracle, image, attrs, terms, noise, 1.0, 10.0, 0.3)
+    total.backward()
+    eng = Celeba19Step(model, batch, 1.0, 10.0, approx_m=approx_m, faithful_bn_stats=False)
+    elbo = eng.step(image.to(DEV), attrs.to(DEV), 0.3, noise=noise, combos=combos).cpu()
+    T = len(terms)
+    assert_close(elbo[:T], torch.stack(elbos).detach(), 'ELBO terms')
+    assert_close(elbo[T], total.detach(), 'total')
+    check_grads_vs_oracle(model, oracle)
+    ref = oracle.state_dict()
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    enc = [k for k in ref if k.startswith('image_encoder') and 'running_' in k]
+    dec = [k for k in ref if k.startswith('image_decoder') and 'running_mean' in k]
+    assert enc and dec
+    for k in enc:
+        assert_close(got[k], ref[k], k, tol=1e-5)
+    for k in dec:       # fewer momentum updates: visibly not the reference's state
+        assert (got[k] - ref[k]).abs().max().item() > 1e-3 * ref[k].abs().max().item(), k
+    nbt = [k for k in ref if k.startswith('image_decoder') and k.endswith('num_batches_tracked')]
+    n_img_terms = 2 + int(combos[:, 0].sum())
+    for k in nbt:
+        assert int(ref[k]) == 20 + approx_m and int(got[k]) == n_img_terms, (k, int(ref[k]), int(got[k]))

@@ -200,3 +200,16 @@ def test_which_decoders_carry_their_loss():
     assert probe._fold_plan(celeba.label_decoder.plan(), 'bce')
     wide = [L._Op('lin', torch.nn.Linear(8, 33))]
     assert probe._fold_plan(wide, 'bce') and not probe._fold_plan(wide, 'class')
+
+
+def test_celeba19_bn_stats_flag_defaults_to_the_reference_behaviour():
+    """the switch exists, is opt-in, and only celeba19's train.py has it."""
+    import mvae_amd  # noqa: F401
+    from mvae_amd.train_common import reference_parser
+    p = reference_parser('celeba19')
+    assert p.parse_args([]).bn_stats == 'reference'
+    assert p.parse_args(['--bn-stats', 'loss-bearing']).bn_stats == 'loss-bearing'
+    with pytest.raises(SystemExit):
+        p.parse_args(['--bn-stats', 'fast'])
+    with pytest.raises(SystemExit):
+        reference_parser('celeba').parse_args(['--bn-stats', 'loss-bearing'])

@@ -164,6 +164,7 @@ def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch
     _check_adam(kind, model, oracle, w0, g_hip, w1)
     print('%s B=%d %s: replayed step vs oracle, worst gradient rel err %.2e, %d input re-draw(s) for an exact-zero '
           'logit' % (kind, batch, 'dp (collectives in the graph)' if use_dp else 'one graph', worst, redraws))
+    assert redraws <= 1, '%d re-draws for exactly-zero logits: a kernel manufacturing zeros must fail, not be retried away' % redraws
 
 
 def test_replay_noise_is_fresh_every_step_and_standard_normal():
