@@ -32,6 +32,9 @@
 #ifndef MVAE_WGRAD_XCD
 #define MVAE_WGRAD_XCD 1        // weight-gradient form: the tiles of one k range on one XCD (igemm_kernel, mode 4)
 #endif
+#ifndef MVAE_DY_KEEP
+#define MVAE_DY_KEEP 1          // 32-row transposed-conv form: the column decode of a tile kept across its parity classes (0: A/B)
+#endif
 #ifndef MVAE_S1_XCD
 #define MVAE_S1_XCD 1           // convT_s1_kernel: the channel groups of one image group on one XCD
 #endif
@@ -270,25 +273,40 @@ struct LdDgradDyT {
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
     BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
+    // The column -> (image, row', col') decode of a tile (two run-time divisions per thread) is the same for every
+    // parity class of that tile, and a multi-item block walks the classes of ONE tile back to back (class-minor
+    // order): kept across init() calls.  The (stride, pad) pair is the template's: 4x4 convs here are (2, 1) or (1, 0).
+    // Only the 32-row layout (128-column tiles, 8 k-steps per item) keeps it: there the set-up is as long as the loop;
+    // the 64-row kernels sit at 127 registers and the three extra ones would cost them an occupancy step.
+    static constexpr int S = (TLOG == 1) ? 2 : 1, PD = (TLOG == 1) ? 1 : 0;
+    static constexpr bool KEEP = (TILE_ == 128) && MVAE_DY_KEEP;
+    int c_tile0 = -1, c_n = 0, c_n0 = 0, c_ih2 = 0, c_iw2 = 0;
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int cls) {
-        const int ph = cls / g.stride, pw = cls % g.stride;
-        const int kh0 = (ph + g.pad) % g.stride, kw0 = (pw + g.pad) % g.stride;
+        const int ph = cls / S, pw = cls % S;
+        const int kh0 = (ph + PD) % S, kw0 = (pw + PD) % S;
         const int m = tile0 + (t % TILE);
         kq = t / TILE;
         const int aq = (kq >> TLOG) & TMASK, bq = kq & TMASK;     // thread-constant tap fields
         unsigned vh = 0, vw = 0;
         base = 0;
         const int hw2 = H2 * W2, ohw = g.OH * g.OW;
-        const int n0 = tile0 / hw2;                   // block-uniform
+        if (!KEEP || tile0 != c_tile0) {              // block-uniform
+            c_tile0 = tile0;
+            c_n0 = tile0 / hw2;
+            const int mm = m < Mtot ? m : 0;
+            c_n = mm / hw2;
+            const int rem = mm - c_n * hw2;
+            c_ih2 = rem / W2; c_iw2 = rem - c_ih2 * W2;
+        }
+        const int n0 = c_n0;
         blk = buf_base(dy + (size_t)n0 * g.Cout * ohw);
         int rel = 0;
         if (m < Mtot) {
-            const int n = m / hw2, rem = m - n * hw2;
-            const int ih2 = rem / W2, iw2 = rem - ih2 * W2;
-            const int ohb = (ih2 * g.stride + ph + g.pad - kh0) / g.stride;
-            const int owb = (iw2 * g.stride + pw + g.pad - kw0) / g.stride;
+            const int n = c_n, ih2 = c_ih2, iw2 = c_iw2;
+            const int ohb = (ih2 * S + ph + PD - kh0) / S;
+            const int owb = (iw2 * S + pw + PD - kw0) / S;
             base = (n * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
             rel = ((n - n0) * g.Cout * g.OH + ohb - aq) * g.OW + owb - bq;
 #pragma unroll
