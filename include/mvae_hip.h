@@ -169,6 +169,25 @@ size_t mvae_conv_k4_repack_floats(int transposed, const float *w, int B, int Cin
                                   int stride, int pad);
 int mvae_conv_k4_repack_batched(const mvae_repack_item *items, int n_items, mvae_stream_t stream);
 
+/* Statistics-only ConvTranspose2d forward: the transposed conv in FRONT OF THE LAST BatchNorm of a decoder pass whose
+ * output the reference never reads -- celeba19/train.py:278-283 runs the image decoder for the 18 attribute-only terms
+ * too (celeba19/model.py:52-61), celeba/train.py:195 for the attribute-only term; the only effect is the BatchNorm
+ * running-statistics update (reproduced by default).  The launch computes the layer but STORES
+ * NOTHING: each block leaves one (mean, M2) record per output channel over MVAE_STATS_TILE_ELEMS elements,
+ *     part[tile][Cout][2],   tiles of one image -- hence of one batch group -- contiguous,
+ * and mvae_bn_stats_merge turns the records of each group into that BatchNorm's saved + running statistics exactly
+ * as mvae_bn_train_fwd(y = NULL) would from the activations (equal-count merge: mean = avg(mean_i),
+ * M2 = sum(M2_i) + n * sum((mean_i - mean)^2); groups in order, n_updates times each).
+ *   mvae_convT2d_k4_stats_tiles  number of records the launch writes, or 0 if the shape is not covered (covered:
+ *                                stride 2, pad 1, <= 32 output channels, B*H*W a multiple of 128) -- the caller then
+ *                                uses mvae_convT2d_k4_fwd + mvae_bn_train_fwd(y = NULL).
+ *   w / ws                       as in mvae_convT2d_k4_fwd (w = NULL: ws holds the repacked copy). */
+#define MVAE_STATS_TILE_ELEMS 512
+size_t mvae_convT2d_k4_stats_tiles(int B, int Cin, int H, int W, int Cout, int stride, int pad);
+int mvae_convT2d_k4_fwd_stats(const float *x, const float *w, float *part, size_t part_floats,
+                              int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                              void *ws, size_t ws_bytes, mvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K4  BatchNorm2d / BatchNorm1d (training mode, eps 1e-5, momentum 0.1) + fused Swish:
  *     celeba/model.py:80,83,86,118,121,124,149,152,176,179,182; celeba19/model.py:106,109,
@@ -194,6 +213,11 @@ int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const
                       float *dx, float *dgamma, float *dbeta,
                       int G, int B, int C, int HW, int flags,
                       void *ws, size_t ws_bytes, mvae_stream_t stream);
+/* saved + running statistics of G groups from the records of mvae_convT2d_k4_fwd_stats (`tiles` records of
+ * `elems_per_tile` elements per channel; tiles % G == 0, a group's tiles contiguous).  save_* may be NULL. */
+int mvae_bn_stats_merge(const float *part, int tiles, int elems_per_tile, int G, int C,
+                        float *save_mean, float *save_invstd, float *running_mean, float *running_var,
+                        float eps, float momentum, int n_updates, const int *n_updates_dev, mvae_stream_t stream);
 int mvae_bn_eval_fwd(const float *x, const float *gamma, const float *beta, float *y,
                      const float *running_mean, const float *running_var,
                      int N, int C, int HW, float eps, int flags, mvae_stream_t stream);

@@ -23,6 +23,7 @@ ACCUMULATE = 2
 POE_NO_PRIOR = 4     # MVAE_POE_NO_PRIOR
 POE_VARIANT = {'A': 0, 'B': 1, 'A-noprior': 0 | POE_NO_PRIOR, 'B-noprior': 1 | POE_NO_PRIOR}
 MAX_EXPERTS = 32
+STATS_TILE_ELEMS = 512   # MVAE_STATS_TILE_ELEMS
 MAX_TERMS = 40
 
 
@@ -115,6 +116,9 @@ _SIGNATURES = {
     'mvae_group_sums': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'mvae_conv_k4_repack_floats': (c_size_t, [c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'mvae_conv_k4_repack_batched': (c_int, [ctypes.POINTER(RepackItem), c_int, P]),
+    'mvae_convT2d_k4_stats_tiles': (c_size_t, [c_int] * 7),
+    'mvae_convT2d_k4_fwd_stats': (c_int, [P, P, P, c_size_t] + [c_int] * 7 + [P, c_size_t, P]),
+    'mvae_bn_stats_merge': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_float, c_int, P, P]),
     'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),

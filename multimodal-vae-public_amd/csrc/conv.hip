@@ -1232,6 +1232,49 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     return launch_igemm<LdRowsMNSC, LdDgradDyS1, EpNCHW, false>(pl, mp, mq, e, I, J, K, sink, st);
 }
 
+// ---- statistics-only form of the stride-2 dgrad-form launch (EpStats, gemm_core.h): the transposed conv in front of a
+//      decoder pass's LAST BatchNorm when the pass exists only for the running statistics.  Supported: stride 2, <= 32
+//      output channels (the 32-row layout), whole column tiles, a reduction of >= 2 full k-tiles; one block = the four
+//      parity classes of one 128-column tile = 512 elements per channel.  Returns the number of records (column
+//      tiles), 0 if the shape is not covered (the caller then runs the storing launch + the statistics sweep).
+constexpr int STATS_TILE = 128;
+inline long conv_dgrad_stats_tiles(const ConvGeom &g) {
+    const int s = g.stride;
+    if (s != 2 || g.pad != 1 || g.Cin > 32 || g.Cin % 4 != 0) return 0;
+    const long J = (long)g.B * (g.H / s) * (g.W / s);
+    const int K = g.Cout << 2;
+    if (J % STATS_TILE != 0 || K % MVAE_CONV_BK != 0 || K < 2 * MVAE_CONV_BK || J * 4 >= (1L << 31)) return 0;
+    return J / STATS_TILE;
+}
+
+int conv_dgrad_stats_impl(const float *dy, const float *w, float *part, ConvGeom g, void *ws, size_t ws_bytes,
+                          hipStream_t st) {
+    const int s = g.stride;
+    const int H2 = g.H / s, W2 = g.W / s;
+    const int I = g.Cin, J = g.B * H2 * W2, K = g.Cout << 2;
+    if (!conv_dgrad_stats_tiles(g)) return MVAE_ERR_ARG;
+    if (!ws || ws_bytes < dgrad_ws_floats(g) * sizeof(float)) return MVAE_ERR_WS;
+    float *wr = (float *)ws;
+    if (!aligned16(wr)) return MVAE_ERR_ARG;
+    if (w) {
+        const int total = s * s * K * g.Cin;
+        int blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(repack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wr, g.Cout, g.Cin, s, g.pad);
+    }
+    Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
+    if (!(pl.wgn == 4 && pl.wm == 1 && pl.wn == 1 && pl.kw == 1 && pl.splits == 1)) return MVAE_ERR_ARG;   // the 32-row layout
+    pl.items = s * s; pl.force_items = 1;               // a block = the four classes of one column tile
+    EpStats e;
+    e.part = part; e.C = g.Cin; e.J = J;
+    auto mp = [&](auto &p) { p.src = wr; p.ld = g.Cin; p.R = g.Cin; p.Klen = K; p.cls_stride = (size_t)K * g.Cin; };
+    auto mq = [&](auto &q) { q.dy = dy; q.g = g; q.Mtot = J; q.H2 = H2; q.W2 = W2; };
+    SplitSink sink = make_sink(nullptr, I, J, false);
+    sink.ncls = s * s;
+    sink.cls_minor = 1;
+    return launch_igemm<LdRowsMNC, LdDgradDyS2, EpStats, false>(pl, mp, mq, e, I, J, K, sink, st);
+}
+
 // ---- weight gradient of the <= 4-input-channel convs (Conv2d(3,32) / ConvTranspose2d(32,3) of CelebA,
 //      Conv2d(1,64) / ConvTranspose2d(64,1) of FashionMNIST; stride 2, pad 1).  The output is 32..64 x
 //      16..48 values over a reduction of B*OH*OW ~ 10^5..10^6: as an implicit GEMM that is ONE
@@ -1542,6 +1585,22 @@ MVAE_EXPORT int mvae_convT2d_k4_fwd(const float *x, const float *w, float *pre, 
     ConvGeom g;
     if (!x || (!w && !ws) || (!pre && !act) || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
     return conv_dgrad_impl(x, w, pre, act, nullptr, g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+MVAE_EXPORT size_t mvae_convT2d_k4_stats_tiles(int B, int Cin, int H, int W, int Cout, int stride, int pad) {
+    ConvGeom g;
+    if (B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return 0;
+    return (size_t)conv_dgrad_stats_tiles(g);
+}
+
+MVAE_EXPORT int mvae_convT2d_k4_fwd_stats(const float *x, const float *w, float *part, size_t part_floats, int B, int Cin,
+                                          int H, int W, int Cout, int stride, int pad, void *ws, size_t ws_bytes,
+                                          mvae_stream_t stream) {
+    ConvGeom g;
+    if (!x || (!w && !ws) || !part || B <= 0 || !convT_geom(B, Cin, H, W, Cout, stride, pad, &g)) return MVAE_ERR_ARG;
+    const long tiles = conv_dgrad_stats_tiles(g);
+    if (tiles <= 0 || part_floats < (size_t)tiles * Cout * 2) return MVAE_ERR_ARG;
+    return conv_dgrad_stats_impl(x, w, part, g, ws, ws_bytes, (hipStream_t)stream);
 }
 
 MVAE_EXPORT int mvae_convT2d_k4_dgrad(const float *dy, const float *w, float *dx, const float *pre_in, int B,

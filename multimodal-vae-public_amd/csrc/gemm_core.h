@@ -480,6 +480,26 @@ struct EpNCHWPair : EpNCHW {
     static constexpr bool PAIR = true;
 };
 
+// Statistics-only destination: the last conv of a decoder pass that exists only for its BatchNorm running-statistics
+// side effect (celeba19/train.py:278-283: 18 of the 21 model() calls decode an image nobody reads; SURVEY Appendix
+// B-4).  NOTHING is stored: every lane adds its accumulators (v, v^2) up over the items of its multi-item block, and
+// the block leaves one (mean, M2) record per output row over the n_items * BN columns it covered -- part[jt][C][2],
+// jt = the block's column tile; mvae_bn_stats_merge combines the records of a group.  The 32-row transposed-conv
+// launch it replaces spent as long on its 600 MB of stride-2 stores as on its matrix work, and the statistics sweep
+// behind it read them all back (profiles/r04_celeba19_by_shape.txt: 825 + 240 us of a 7.1-ms step).  Two vector
+// instructions per accumulator register per item; one cross-lane reduction per block.
+struct EpStats {
+    static constexpr bool MULTI = true, PAIR = false, ROWRED = false, STATS = true;
+    __device__ bool pair_ok() const { return false; }
+    __device__ void put2(int, float, float) const {}
+    float *part; int C, J;
+    __device__ void set_class(int) const {}
+    __device__ bool col(int j) const { return j < J; }
+    __device__ void put(int, int, float) const {}
+};
+template <class T, class = void> struct ep_stats : std::false_type {};
+template <class T> struct ep_stats<T, std::void_t<decltype(T::STATS)>> : std::integral_constant<bool, T::STATS> {};
+
 // Where the raw partial tiles of a split reduction go (row-major [I][J] per split), plus the
 // optional row sums of P (bias gradient of a Linear wgrad).
 struct SplitSink {
@@ -771,8 +791,59 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             // ... the 32-row (1 x 4 waves) and 64-row (2 x 2 waves) layouts: 146 and 127 VGPRs, same occupancy as without
             constexpr bool PAIRK = E::PAIR && WM * WN == 1 && loader_pairable<Q>::value;
             std::conditional_t<PAIRK, f32x16, char> hold;
+            // statistics-only destination (EpStats; one-tile waves): per-lane sums of v and v^2 over the block's items
+            constexpr bool STATK = ep_stats<E>::value && WM * WN == 1;
+            std::conditional_t<STATK, f32x16, char> st1, st2;
+            if constexpr (STATK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st1[r] = 0.f; st2[r] = 0.f; }
+            }
+            auto stats_flush = [&]() {
+                if constexpr (STATK) {
+                    // lanes of one half wave hold the 32 columns of rows (r & 3) + 8 * (r >> 2) + 4 * lrow
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { st1[r] = half_wave_sum(st1[r]); st2[r] = half_wave_sum(st2[r]); }
+                    __syncthreads();                    // the tile buffers are free
+                    float *red = lds_raw;               // [wave][32 rows][2]
+                    if (lcol == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                            red[(wq * 32 + row) * 2 + 0] = st1[r];
+                            red[(wq * 32 + row) * 2 + 1] = st2[r];
+                        }
+                    }
+                    __syncthreads();
+                    if (t < BM) {                       // row t of the block tile: its WGN column waves, in order
+                        const int band = t >> 5, row = t & 31;
+                        float a = 0.f, b = 0.f;
+#pragma unroll
+                        for (int w2 = 0; w2 < WGN; ++w2) {
+                            a += red[((band * WGN + w2) * 32 + row) * 2 + 0];
+                            b += red[((band * WGN + w2) * 32 + row) * 2 + 1];
+                        }
+                        const float n = (float)(n_items * BN);
+                        const float mean = a / n;
+                        if (i0 + t < e.C) {
+                            float *dst = e.part + ((size_t)(first_item / sink.ncls) * e.C + i0 + t) * 2;
+                            dst[0] = mean;
+                            dst[1] = fmaxf(b - a * mean, 0.f);
+                        }
+                    }
+                }
+            };
             auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
                 int c, jt; item_tile(w, c, jt);
+                if constexpr (STATK) {                  // every column is real (host: J % BN == 0)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[0][0][r];
+                        st1[r] += v;
+                        st2[r] = fmaf(v, v, st2[r]);
+                        acc[0][0][r] = 0.f;
+                    }
+                    return;
+                }
                 if constexpr (PAIRK) {
                     // the host only launches this type with an even number of items per block in class-minor order:
                     // item w even = class (py, 0), item w + 1 = (py, 1) of the same j tile
@@ -829,6 +900,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 }
                 compute((G - 1) & 1, no_hook);
                 finish_item(n_items - 1);
+                stats_flush();
                 return;
             }
             // one tile per wave: two tiles in flight in registers (see the single-item loop below)
@@ -873,6 +945,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 compute(0, no_hook);
             }
             finish_item(n_items - 1);
+            stats_flush();
             return;
         }
     }
@@ -1205,7 +1278,7 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
-struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; };   // xcd: launch-order re-mapping the host asks for (1 Linear sub-grids, 3 conv items, 4 split k ranges; see igemm_kernel); items: (class, j tile) items per block (conv forms)
+struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; int force_items = 0; };   // xcd: launch-order re-mapping the host asks for (1 Linear sub-grids, 3 conv items, 4 split k ranges; see igemm_kernel); items: (class, j tile) items per block (conv forms)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
@@ -1323,7 +1396,7 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         if (pl.items > 1 && E::MULTI && KW == 1 && !ROWSUM && pl.splits == 1 && NT == NTHREADS && K % PLD<TM>::BKV == 0 && \
             K >= 2 * PLD<TM>::BKV && PLD<TM>::PARTS && QLD<TN>::PARTS) {                         \
             int items = pl.items;                      /* keep >= MVAE_MULTI_MINBLOCKS column blocks */ \
-            while (items > 1 && (int)grid.x / items < MVAE_MULTI_MINBLOCKS) items >>= 1;         \
+            while (!pl.force_items && items > 1 && (int)grid.x / items < MVAE_MULTI_MINBLOCKS) items >>= 1; \
             sink.items = items;                                                                  \
             grid.x = (grid.x + items - 1) / items;                                               \
         }                                                                                        \

@@ -620,8 +620,189 @@ __global__ __launch_bounds__(BNF_THREADS) void bn1d_fused_bwd_kernel(const float
     }
 }
 
+// ---- slices of up to 64 K elements with MANY groups, or too large for the all-groups form above (the 16x16 maps at
+//      batch 256: 65,536 elements per (group, channel); celeba19's 18- and 21-group decoder passes): grid (C, G), block
+//      (c, g) keeps ITS slice in registers between the statistics and the apply -- one launch, one read -- and leaves
+//      (mean, variance) / the two backward sums in the workspace; what couples the groups of a channel (running
+//      statistics in group order, dgamma / dbeta summed over the groups) is a one-thread-per-channel launch behind it.
+//      The backward keeps dh = dy * swish'(h) and re-reads x (still in L2 / MALL from its own first pass) for x-hat:
+//      four transfers in one launch instead of five in two.
+constexpr int BNS_KMAX = 16;                // float4 per thread: 1024 threads x 16 x 4 = 65,536 elements
+constexpr int BNS_MAX_N = BNF_THREADS * BNS_KMAX * 4;
+
+__global__ __launch_bounds__(BNF_THREADS) void bn_slice_fwd_kernel(const float *__restrict__ x, const float *gamma,
+                                                                   const float *beta, float *__restrict__ y,
+                                                                   float *save_mean, float *save_invstd, float *stats,
+                                                                   BnShape sh, float eps, int swish) {
+    __shared__ float red[BNF_WAVES];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const size_t gbase = (size_t)g * sh.B * sh.C * sh.HW;
+    // HW / 4 divides the block (host check): thread t owns float4 t % (HW/4) of rows t / (HW/4) + k * rows_per_pass --
+    // offsets advance by a constant, nothing to keep per unit
+    const int hw4 = sh.HW >> 2, rpp = BNF_THREADS / hw4, b0 = threadIdx.x / hw4;
+    const int off0 = (b0 * sh.C + c) * sh.HW + 4 * (threadIdx.x - b0 * hw4), dk = rpp * sh.C * sh.HW;
+#define BNS_OK(k) (b0 + (k) * rpp < sh.B)
+#define BNS_OFF(k) (gbase + (BNS_OK(k) ? off0 + (k) * dk : off0))
+    float4 v[BNS_KMAX];
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k) v[k] = ld4(x, BNS_OFF(k));
+    float s[1] = {0.f};
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k) s[0] += BNS_OK(k) ? (v[k].x + v[k].y) + (v[k].z + v[k].w) : 0.f;
+    bnf_block_sums<1>(s, red);
+    const float inv_n = 1.f / (float)sh.n;
+    const float mean = s[0] * inv_n;
+    s[0] = 0.f;
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k) {
+        const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+        s[0] += BNS_OK(k) ? (a * a + b * b) + (cc * cc + d * d) : 0.f;
+    }
+    bnf_block_sums<1>(s, red);
+    const float var = s[0] * inv_n, invstd = rsqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        save_mean[g * sh.C + c] = mean;
+        save_invstd[g * sh.C + c] = invstd;
+        stats[(g * sh.C + c) * 2] = mean;
+        stats[(g * sh.C + c) * 2 + 1] = var;
+    }
+    if (!y) return;
+    const float ga = gamma[c], be = beta[c];
+    auto one = [&](float a) {
+        const float h = ga * ((a - mean) * invstd) + be;
+        return swish ? swishf_(h) : h;
+    };
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k)
+        if (BNS_OK(k)) st4(y, BNS_OFF(k), make_float4(one(v[k].x), one(v[k].y), one(v[k].z), one(v[k].w)));
+}
+
+// running statistics of every channel from stats[G][C][2], groups in order, n_updates times each
+__global__ __launch_bounds__(256) void bn_running_kernel(const float *stats, int G, int C, int n, float *running_mean,
+                                                         float *running_var, float momentum, int n_updates,
+                                                         const int *n_updates_dev) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (n_updates_dev) n_updates = *n_updates_dev;
+    const float unb = n > 1 ? (float)n / (float)(n - 1) : 1.f;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < G; ++g) {
+        const float mean = stats[(g * C + c) * 2], var = stats[(g * C + c) * 2 + 1];
+        for (int u = 0; u < n_updates; ++u) {
+            rm = (1.f - momentum) * rm + momentum * mean;
+            rv = (1.f - momentum) * rv + momentum * (var * unb);
+        }
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+}
+
+__global__ __launch_bounds__(BNF_THREADS) void bn_slice_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                   const float *gamma, const float *beta,
+                                                                   const float *save_mean, const float *save_invstd,
+                                                                   float *__restrict__ dx, float *sums, BnShape sh, int swish) {
+    __shared__ float red[BNF_WAVES * 2];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const size_t gbase = (size_t)g * sh.B * sh.C * sh.HW;
+    const int hw4 = sh.HW >> 2, rpp = BNF_THREADS / hw4, b0 = threadIdx.x / hw4;
+    const int off0 = (b0 * sh.C + c) * sh.HW + 4 * (threadIdx.x - b0 * hw4), dk = rpp * sh.C * sh.HW;
+    const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
+    const float ga = gamma[c], be = beta[c];
+    float4 dh[BNS_KMAX];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k) {
+        // four units' loads in flight at a time: with all 16 x loads hoisted next to the 64 registers of dh the kernel spilled
+        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        const float4 xv = ld4(x, BNS_OFF(k));
+        dh[k] = ld4(dy, BNS_OFF(k));
+        auto one = [&](float xe, float &d) {
+            const float xh = (xe - mean) * invstd;
+            if (swish) d *= swish_grad_(ga * xh + be);
+            s[0] += BNS_OK(k) ? d : 0.f;
+            s[1] += BNS_OK(k) ? d * xh : 0.f;
+        };
+        one(xv.x, dh[k].x); one(xv.y, dh[k].y); one(xv.z, dh[k].z); one(xv.w, dh[k].w);
+    }
+    bnf_block_sums<2>(s, red);
+    if (threadIdx.x == 0) {
+        sums[(g * sh.C + c) * 2] = s[0];
+        sums[(g * sh.C + c) * 2 + 1] = s[1];
+    }
+    const float inv_n = 1.f / (float)sh.n;
+    const float kf = ga * invstd, m1 = s[0] * inv_n, m2 = s[1] * inv_n;
+#pragma unroll
+    for (int k = 0; k < BNS_KMAX; ++k) {
+        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (!BNS_OK(k)) continue;
+        const float4 xv = ld4(x, BNS_OFF(k));          // second read: this block's own lines, L2 / MALL
+        auto one = [&](float xe, float d) { return kf * (d - m1 - ((xe - mean) * invstd) * m2); };
+        st4(dx, BNS_OFF(k), make_float4(one(xv.x, dh[k].x), one(xv.y, dh[k].y), one(xv.z, dh[k].z), one(xv.w, dh[k].w)));
+    }
+}
+#undef BNS_OK
+#undef BNS_OFF
+
+// dbeta[c] = sum_g sums[g][c][0], dgamma[c] = sum_g sums[g][c][1]  (+ what is there with `accumulate`)
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const float *sums, int G, int C, float *dgamma, float *dbeta,
+                                                             int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float t1 = 0.f, t2 = 0.f;
+    for (int g = 0; g < G; ++g) { t1 += sums[(g * C + c) * 2]; t2 += sums[(g * C + c) * 2 + 1]; }
+    if (accumulate) { t1 += dbeta[c]; t2 += dgamma[c]; }
+    dbeta[c] = t1;
+    dgamma[c] = t2;
+}
+
+// ---- statistics from the records a statistics-only conv launch left (mvae_convT2d_k4_fwd_stats: (mean, M2) per
+//      column tile and channel over `elems` elements each, tiles of a group contiguous): per (group, channel) the
+//      equal-count merge  mean = avg(mean_i),  M2 = sum(M2_i) + elems * sum((mean_i - mean)^2);  then the running
+//      statistics advance over the groups in order -- what mvae_bn_train_fwd(y = NULL) does from a sweep of the
+//      activations that are no longer written.  One block per channel, a wave per group (in turns).
+__global__ __launch_bounds__(BNF_THREADS) void bn_stats_merge_kernel(const float *__restrict__ part, int tiles_per_group,
+                                                                     int elems, int G, int C, float *save_mean,
+                                                                     float *save_invstd, float *running_mean,
+                                                                     float *running_var, float eps, float momentum,
+                                                                     int n_updates, const int *n_updates_dev) {
+    extern __shared__ float gm[];                      // [G][2]: mean, biased variance
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int g = wave; g < G; g += BNF_WAVES) {
+        const float *p = part + ((size_t)g * tiles_per_group * C + c) * 2;
+        float s = 0.f;
+        for (int i = lane; i < tiles_per_group; i += 64) s += p[(size_t)i * C * 2];
+        const float mean = wave_sum(s) / (float)tiles_per_group;
+        float m2 = 0.f;
+        for (int i = lane; i < tiles_per_group; i += 64) {
+            const float d = p[(size_t)i * C * 2] - mean;
+            m2 += p[(size_t)i * C * 2 + 1] + (float)elems * d * d;
+        }
+        m2 = wave_sum(m2);
+        if (lane == 0) { gm[g * 2] = mean; gm[g * 2 + 1] = m2 / ((float)tiles_per_group * (float)elems); }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (n_updates_dev) n_updates = *n_updates_dev;
+    const float n = (float)tiles_per_group * (float)elems;
+    const float unb = n > 1.f ? n / (n - 1.f) : 1.f;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float mean = gm[g * 2], var = gm[g * 2 + 1];
+        if (save_mean) save_mean[g * C + c] = mean;
+        if (save_invstd) save_invstd[g * C + c] = rsqrtf(var + eps);
+        for (int u = 0; u < n_updates; ++u) {
+            rm = (1.f - momentum) * rm + momentum * mean;
+            rv = (1.f - momentum) * rv + momentum * (var * unb);
+        }
+    }
+    if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
 #ifndef MVAE_BN_FUSED
 #define MVAE_BN_FUSED 1         // 0: every layer on the two-launch path (A/B builds)
+#endif
+#ifndef MVAE_BN_SLICE
+#define MVAE_BN_SLICE 1         // 0: slices of 16 K .. 64 K elements / many groups stay on the two-launch path (A/B builds)
 #endif
 constexpr int BNF_GMAX_FWD = 3, BNF_GMAX_BWD = 2, BN1_GMAX = 3;
 
@@ -631,7 +812,10 @@ inline int bn_fused_kind(const BnShape &sh, bool bwd) {
     if (sh.HW == 1) return (sh.G <= BN1_GMAX && sh.B <= BN1_TY * BN1_MAX_ROWS) ? 2 : 0;
     // (unaligned / odd-width maps keep one element per register: half the slice when several groups share the block)
     const int max_n = (!sh.vec && sh.G > 1) ? BNF_MAX_N / 2 : BNF_MAX_N;
-    return (sh.n <= max_n && sh.G <= (bwd ? BNF_GMAX_BWD : BNF_GMAX_FWD)) ? 1 : 0;
+    if (sh.n <= max_n && sh.G <= (bwd ? BNF_GMAX_BWD : BNF_GMAX_FWD)) return 1;
+    // 3: one block per (channel, group) slice + a per-channel launch for what couples the groups
+    return (MVAE_BN_SLICE && sh.vec && sh.n <= BNS_MAX_N && sh.G <= 65535 && (sh.HW >> 2) <= BNF_THREADS &&
+            BNF_THREADS % (sh.HW >> 2) == 0) ? 3 : 0;
 }
 
 inline bool bn_shape(int G, int B, int C, int HW, const void *a, const void *b, const void *c, BnShape *sh) {
@@ -667,6 +851,15 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
     if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int sw = (flags & MVAE_ACT_SWISH) ? 1 : 0;
+    if (bn_fused_kind(sh, false) == 3) {
+        if (!ws || ws_bytes < (size_t)G * C * 2 * sizeof(float)) return MVAE_ERR_WS;
+        hipLaunchKernelGGL(bn_slice_fwd_kernel, dim3(C, G), dim3(BNF_THREADS), 0, st, x, gamma, beta, y, save_mean,
+                           save_invstd, (float *)ws, sh, eps, sw);
+        if (running_mean)
+            hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)ws, G, C, sh.n,
+                               running_mean, running_var, momentum, n_updates, n_updates_dev);
+        return mvae_launch_status();
+    }
     if (const int kind = bn_fused_kind(sh, false)) {
 #define MVAE_BNF_FWD(KERN, GRID)                                                                                    \
         hipLaunchKernelGGL(KERN, dim3(GRID), dim3(BNF_THREADS), 0, st, x, gamma, beta, y, save_mean, save_invstd,   \
@@ -696,6 +889,17 @@ MVAE_EXPORT int mvae_bn_train_fwd(const float *x, const float *gamma, const floa
     return mvae_launch_status();
 }
 
+MVAE_EXPORT int mvae_bn_stats_merge(const float *part, int tiles, int elems_per_tile, int G, int C, float *save_mean,
+                                    float *save_invstd, float *running_mean, float *running_var, float eps,
+                                    float momentum, int n_updates, const int *n_updates_dev, mvae_stream_t stream) {
+    if (!part || tiles <= 0 || elems_per_tile <= 0 || G <= 0 || C <= 0 || tiles % G != 0 || G > 4096) return MVAE_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(C), dim3(BNF_THREADS), (size_t)G * 2 * sizeof(float), (hipStream_t)stream,
+                       part, tiles / G, elems_per_tile, G, C, save_mean, save_invstd, running_mean, running_var, eps,
+                       momentum, n_updates, n_updates_dev);
+    return mvae_launch_status();
+}
+
 MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
                                   const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
                                   float *dbeta, int G, int B, int C, int HW, int flags, void *ws,
@@ -706,6 +910,14 @@ MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *
         return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int swish = (flags & MVAE_ACT_SWISH) ? 1 : 0;
+    if (bn_fused_kind(sh, true) == 3) {
+        if (!ws || ws_bytes < (size_t)G * C * 2 * sizeof(float)) return MVAE_ERR_WS;
+        hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3(C, G), dim3(BNF_THREADS), 0, st, dy, x, gamma, beta, save_mean,
+                           save_invstd, dx, (float *)ws, sh, swish);
+        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)ws, G, C, dgamma,
+                           dbeta, (flags & MVAE_ACCUMULATE) ? 1 : 0);
+        return mvae_launch_status();
+    }
     if (const int kind = bn_fused_kind(sh, true)) {
         const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
 #define MVAE_BNF_BWD(KERN, GRID)                                                                                    \

@@ -22,6 +22,10 @@ struct PoeArgs {
     mvae_experts_t ex;
     int ld, E, T, B, D, variant;      // variant: MVAE_POE_VARIANT_A / _B (the NO_PRIOR bit is split off into no_prior)
     int no_prior;
+    // many-term steps (celeba19: 21 terms x 21 experts): blockIdx.y owns `chunk` consecutive TERMS of the forward /
+    // EXPERTS of the backward, so the launch is (rows / 2) x (T / chunk) blocks instead of one wave per batch row
+    // walking all of them in sequence (62 / 106 us for 2.5 MB of tensors: a latency chain, one wave per CU)
+    int chunk;
     // draw mode (mvae_poe_fwd_draw): eps is generated here -- element o of the Philox stream (seed, *counter +
     // counter_offset), the values mvae_philox_fill would have written -- and stored to `noise` for the backward
     uint64_t seed; const uint64_t *counter; uint64_t counter_offset; int draw;
@@ -45,20 +49,22 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
     const int b = blockIdx.x * (POE_THREADS / 64) + (threadIdx.x >> 6);
     if (b >= a.B) return;                              // whole waves exit together; no block barrier below
     float *mine = lds + threadIdx.x;
-    float *klacc = lds + (size_t)a.E * 2 * POE_THREADS + threadIdx.x;      // this lane's KL partial per term
+    float *klacc = lds + (size_t)a.E * 2 * POE_THREADS + threadIdx.x;      // this lane's KL partial per term of the chunk
     // the N(0,1) prior: mu = 0, logvar = 0 (MVAE_POE_NO_PRIOR: the caller's experts are the whole stack)
     const float t0 = a.no_prior ? 0.f : poe_precision(0.f, a.variant);
-    for (int t = 0; t < a.T; ++t) klacc[t * POE_THREADS] = 0.f;
+    const int t_lo = blockIdx.y * a.chunk, t_hi = min(a.T, t_lo + a.chunk);
+    uint32_t used = 0;                                 // experts any term of this chunk contains (block-uniform)
+    for (int t = t_lo; t < t_hi; ++t) { klacc[(t - t_lo) * POE_THREADS] = 0.f; used |= masks[t]; }
     const uint64_t launch = a.draw ? *a.counter + a.counter_offset : 0;
     for (int d = lane; d < a.D; d += 64) {
         const size_t oe = (size_t)b * a.ld + d;
-#pragma unroll 4
         for (int e = 0; e < a.E; ++e) {
+            if (!((used >> e) & 1u)) continue;
             const float te = poe_precision(a.ex.logvar[e][oe], a.variant);
             mine[(e * 2 + 0) * POE_THREADS] = te;
             mine[(e * 2 + 1) * POE_THREADS] = a.ex.mu[e][oe] * te;
         }
-        for (int t = 0; t < a.T; ++t) {
+        for (int t = t_lo; t < t_hi; ++t) {
             uint32_t mask = masks[t];
             float sum_t = t0, sum_mt = 0.f * t0;
             for (int e = 0; mask; ++e, mask >>= 1) {  // wave-uniform walk over the experts of the term, in order
@@ -79,12 +85,12 @@ __global__ __launch_bounds__(POE_THREADS) void poe_fwd_kernel(PoeArgs a, const u
             } else if (z) {
                 z[o] = noise ? noise[o] * expf(0.5f * plv) + pmu : pmu;
             }
-            klacc[t * POE_THREADS] += 1.0f + plv - pmu * pmu - expf(plv);
+            klacc[(t - t_lo) * POE_THREADS] += 1.0f + plv - pmu * pmu - expf(plv);
         }
     }
     if (kl) {                                          // all 64 lanes are here again: wave sums per term
-        for (int t = 0; t < a.T; ++t) {
-            const float s = wave_sum(klacc[t * POE_THREADS]);
+        for (int t = t_lo; t < t_hi; ++t) {
+            const float s = wave_sum(klacc[(t - t_lo) * POE_THREADS]);
             if (lane == 0) kl[(size_t)t * a.B + b] = -0.5f * s;
         }
     }
@@ -110,9 +116,12 @@ __global__ __launch_bounds__(POE_THREADS) void poe_bwd_kernel(PoeArgs a, const u
     const int b = blockIdx.x * (POE_THREADS / 64) + (threadIdx.x >> 6);
     if (b >= a.B) return;            // whole waves exit together; no block barrier is used below
     float *mine = lds + threadIdx.x;
+    const int e_lo = blockIdx.y * a.chunk, e_hi = min(a.E, e_lo + a.chunk);
+    // the experts of this block, as a mask: phase 1 is only needed for the terms that contain one of them
+    const uint32_t own = (e_hi - e_lo >= 32 ? 0xffffffffu : ((1u << (e_hi - e_lo)) - 1u)) << e_lo;
     for (int d = lane; d < a.D; d += 64) {
-#pragma unroll 3
         for (int t = 0; t < a.T; ++t) {
+            if (!(masks[t] & own)) continue;
             const size_t o = ((size_t)t * a.B + b) * a.D + d;
             const float pmu = mu[o], plv = logvar[o];
             float gmu = dmu ? dmu[o] : 0.f;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(POE_THREADS) void poe_bwd_kernel(PoeArgs a, const u
             mine[(t * 3 + 1) * POE_THREADS] = glv * dlv_ds;
             mine[(t * 3 + 2) * POE_THREADS] = pmu;
         }
-        for (int e = 0; e < a.E; ++e) {
+        for (int e = e_lo; e < e_hi; ++e) {
             const size_t o = (size_t)b * a.ld + d;
             const float me = a.ex.mu[e][o], lve = a.ex.logvar[e][o];
             const float ex = expf(lve);
@@ -195,6 +204,12 @@ __global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float *mu, const
     }
 }
 
+#ifndef MVAE_POE_CHUNK
+#define MVAE_POE_CHUNK 3        // terms (forward) / experts (backward) per block of a many-term launch; 0: one block walks all
+#endif
+// up to 4 terms / experts (the bimodal steps: 3 and 2-3) stay one block per two rows
+inline int poe_chunk(int n) { return (n <= 4 || MVAE_POE_CHUNK <= 0) ? (n > 0 ? n : 1) : MVAE_POE_CHUNK; }
+
 inline bool poe_args_ok(const mvae_experts_t *ex, int ld, int E, int T, int B, int D, int variant) {
     if (!ex || E < 0 || E > MVAE_MAX_EXPERTS || T <= 0 || T > POE_MAX_TERMS || B <= 0 || D <= 0 || ld < D)
         return false;
@@ -217,8 +232,9 @@ MVAE_EXPORT int mvae_poe_fwd(const mvae_experts_t *experts, int ld, int E, const
     a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
     a.seed = 0; a.counter = nullptr; a.counter_offset = 0; a.draw = 0;
     const int rows = POE_THREADS / 64;
-    const size_t lds_bytes = ((size_t)E * 2 + T) * POE_THREADS * sizeof(float);
-    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
+    a.chunk = poe_chunk(T);
+    const size_t lds_bytes = ((size_t)E * 2 + a.chunk) * POE_THREADS * sizeof(float);
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows, (T + a.chunk - 1) / a.chunk), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
                        masks_dev, const_cast<float *>(noise), mu, logvar, z, kl);
     return mvae_launch_status();
 }
@@ -238,8 +254,9 @@ MVAE_EXPORT int mvae_poe_fwd_draw(const mvae_experts_t *experts, int ld, int E, 
     a.variant = variant & ~MVAE_POE_NO_PRIOR; a.no_prior = (variant & MVAE_POE_NO_PRIOR) ? 1 : 0;
     a.seed = seed; a.counter = counter_dev; a.counter_offset = counter_offset; a.draw = 1;
     const int rows = POE_THREADS / 64;
-    const size_t lds_bytes = ((size_t)E * 2 + T) * POE_THREADS * sizeof(float);
-    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
+    a.chunk = poe_chunk(T);
+    const size_t lds_bytes = ((size_t)E * 2 + a.chunk) * POE_THREADS * sizeof(float);
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3((B + rows - 1) / rows, (T + a.chunk - 1) / a.chunk), dim3(POE_THREADS), lds_bytes, (hipStream_t)stream, a,
                        masks_dev, noise_out, mu, logvar, z, kl);
     return mvae_launch_status();
 }
@@ -262,7 +279,8 @@ MVAE_EXPORT int mvae_poe_bwd(const mvae_experts_t *experts, int ld, int E, const
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
     PoeDzMap none = {};
-    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,
+    a.chunk = poe_chunk(E);
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows, E ? (E + a.chunk - 1) / a.chunk : 1), dim3(POE_THREADS), lds_bytes,
                        (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz, (const float *)nullptr, none, dmu,
                        dlogvar, dkl, dkl_stride, *grads, ldg);
     return mvae_launch_status();
@@ -290,7 +308,8 @@ MVAE_EXPORT int mvae_poe_bwd_split(const mvae_experts_t *experts, int ld, int E,
     a.seed = 0; a.counter = nullptr; a.counter_offset = 0; a.draw = 0;
     const int rows = POE_THREADS / 64;
     const size_t lds_bytes = (size_t)T * 3 * POE_THREADS * sizeof(float);
-    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows), dim3(POE_THREADS), lds_bytes,
+    a.chunk = poe_chunk(E);
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3((B + rows - 1) / rows, E ? (E + a.chunk - 1) / a.chunk : 1), dim3(POE_THREADS), lds_bytes,
                        (hipStream_t)stream, a, masks_dev, noise, mu, logvar, dz_a, dz_b, m, (const float *)nullptr,
                        (const float *)nullptr, dkl, dkl_stride, *grads, ldg);
     return mvae_launch_status();

@@ -359,6 +359,44 @@ def convT2d_fwd(x, w, pre, act, stride, pad, wr=None):
     _conv_call('mvae_convT2d_k4_fwd', x, w, pre, act, B, Cin, H, W, w.shape[1], stride, pad, repack=True, wr=wr)
 
 
+def convT2d_stats_tiles(x, w, stride, pad):
+    """Records the statistics-only launch would write for ConvTranspose2d(w)(x), 0 if the shape is not covered."""
+    B, Cin, H, W = x.shape
+    return int(_lib.lib().mvae_convT2d_k4_stats_tiles(B, Cin, H, W, w.shape[1], stride, pad))
+
+
+def convT2d_fwd_stats(x, w, stride, pad, wr=None):
+    """ConvTranspose2d(w)(x) WITHOUT storing it: returns part [tiles, Cout, 2] = (mean, M2) of every 512-element
+    column tile per output channel (mvae_convT2d_k4_fwd_stats), for ``bn_stats_merge``.  ``wr``: the repacked
+    weight copy made ahead (conv_repack_batched)."""
+    _need_gpu(x, w, wr); _f32c(x, w, wr)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    tiles = convT2d_stats_tiles(x, w, stride, pad)
+    if tiles <= 0:
+        raise RuntimeError('statistics-only transposed conv: shape %s -> %d channels not covered' % (tuple(x.shape), Cout))
+    part = torch.empty(tiles, Cout, 2, dtype=torch.float32, device=x.device)
+    if wr is not None:
+        ws, wsb, wp = _ptr(wr), wr.numel() * 4, None
+    else:
+        ws, wsb = _ws_args(Cin * Cout * 16 * 4, x.device)
+        wp = _ptr(w)
+    check(_lib.lib().mvae_convT2d_k4_fwd_stats(_ptr(x), wp, _ptr(part), part.numel(), B, Cin, H, W, Cout, stride, pad,
+                                               ws, wsb, _stream()), 'mvae_convT2d_k4_fwd_stats')
+    return part
+
+
+def bn_stats_merge(part, G, save_mean, save_invstd, running_mean, running_var, eps=1e-5, momentum=0.1, n_updates=1,
+                   n_updates_dev=None):
+    """Saved + running BatchNorm statistics of G groups from the records of ``convT2d_fwd_stats``."""
+    _need_gpu(part, save_mean, save_invstd, running_mean, running_var)
+    _f32c(part, save_mean, save_invstd, running_mean, running_var)
+    tiles, C = part.shape[0], part.shape[1]
+    check(_lib.lib().mvae_bn_stats_merge(_ptr(part), tiles, _lib.STATS_TILE_ELEMS, G, C, _ptr(save_mean), _ptr(save_invstd),
+                                         _ptr(running_mean), _ptr(running_var), eps, momentum, n_updates,
+                                         _ptr(n_updates_dev), _stream()), 'mvae_bn_stats_merge')
+
+
 def convT2d_dgrad(dy, w, dx, pre_in, stride, pad):
     _need_gpu(dy, w, dx, pre_in); _f32c(dy, w, dx, pre_in)
     B, Cin, H, W = dx.shape

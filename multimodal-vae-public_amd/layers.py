@@ -19,6 +19,8 @@ A stack may process ``G`` groups of ``B`` rows at once (``groups=G``): BatchNorm
 per group, so the G separate ``model()`` calls of the reference's train step become one launch
 per layer with identical results.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -239,6 +241,11 @@ def n_dropout(plan):
 
 
 # ----------------------------------------------------------------------------- executor
+# statistics-only decoder passes: the conv in front of the last BatchNorm leaves statistics records instead of its
+# output (MVAE_STATS_CONV=0: the storing launch + the statistics sweep over what it stored)
+STATS_CONV = os.environ.get('MVAE_STATS_CONV', '1') != '0'
+
+
 def _lin_weights(op):
     """(weight [N,K], bias [N] or None) -- for a HeadPair the joined arena views."""
     if op.kind == 'lin':
@@ -286,7 +293,9 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
                     raise RuntimeError('stack has a Dropout but no keep-mask was supplied')
                 mask = masks.pop(0)
             if op.act:
-                pre = torch.empty(M, N, dtype=torch.float32, device=h.device) if training else None
+                # the pre-activation is only kept for a backward pass (a statistics-only pass has none: 118 MB less to
+                # write for celeba19's 4608-row Linear(100, 6400))
+                pre = torch.empty(M, N, dtype=torch.float32, device=h.device) if (training and not stats_only) else None
                 act = torch.empty(M, N, dtype=torch.float32, device=h.device)
                 K.linear_fwd(h, w.detach(), None if b is None else b.detach(), pre, act, mask,
                              1.0 / (1.0 - op.drop) if mask is not None else 1.0)
@@ -312,8 +321,21 @@ def forward_tape(plan, x, groups=1, masks=None, bn_updates=1, training=True, fin
                 Cout, OH, OW = m.out_channels, (H + 2 * p - 4) // s + 1, (W + 2 * p - 4) // s + 1
             else:
                 Cout, OH, OW = m.out_channels, (H - 1) * s - 2 * p + 4, (W - 1) * s - 2 * p + 4
+            if op.kind == 'convT' and stats_only and STATS_CONV and op_index + 1 == last_bn and not op.act and training:
+                tiles = K.convT2d_stats_tiles(h, m.weight, s, p)
+                if tiles > 0 and Bn % groups == 0 and tiles % groups == 0:
+                    # the pass ends at the BatchNorm behind this layer and only its statistics are wanted: the launch
+                    # computes the layer, stores nothing and leaves per-tile (mean, M2) records; the merge launch turns
+                    # them into the BatchNorm's running statistics (kernels.convT2d_fwd_stats / bn_stats_merge)
+                    wr = _fresh_repack(m, _probe_repack(m, True, Bn, h.shape[1], H, W, Cout, s, p))
+                    part = K.convT2d_fwd_stats(h, m.weight.detach(), s, p, wr=wr)
+                    bn = plan[last_bn].mod
+                    K.bn_stats_merge(part, groups, None, None, bn.running_mean, bn.running_var, eps=bn.eps,
+                                     momentum=bn.momentum, n_updates=bn_updates, n_updates_dev=bn_updates_dev)
+                    bn._nbt_pending += groups * bn_updates
+                    return None, None
             pre = act = None
-            if (not op.act) or training:
+            if (not op.act) or (training and not stats_only):
                 pre = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)
             if op.act:
                 act = torch.empty(Bn, Cout, OH, OW, dtype=torch.float32, device=h.device)

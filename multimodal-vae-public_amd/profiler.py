@@ -87,7 +87,15 @@ def _wgrad_batched_cost(items, *a, **kw):
     return fl, '%d layers' % len(items)
 
 
+def _convT_stats_cost(x, w, stride, pad, *a, **kw):
+    # the layer's flops; the shape names the output it would have stored
+    B, Cin, H, W = x.shape
+    OH, OW = (H - 1) * stride - 2 * pad + 4, (W - 1) * stride - 2 * pad + 4
+    return 2.0 * x.numel() * w.shape[1] * 16, '%dx%dx%dx%d' % (B, w.shape[1], OH, OW)
+
+
 GEMM_COSTS = {
+    'convT2d_fwd_stats': _convT_stats_cost,
     'linear_wgrad_batched': _wgrad_batched_cost,
     'linear_fwd_grouped': _lin_grouped_cost('fwd'), 'linear_dgrad_grouped': _lin_grouped_cost('dgrad'),
     'linear_wgrad_grouped': _lin_grouped_cost('wgrad'),
@@ -151,7 +159,7 @@ HBM_OPS = ['bn_train_fwd', 'bn_train_bwd', 'bn_eval_fwd', 'swish_fwd', 'swish_bw
            'dropout_fanout_fwd', 'dropout_fanin_bwd', 'bce_elem_fwd', 'bce_elem_bwd', 'embedding_swish_fwd_grouped',
            'embedding_swish_bwd_grouped', 'block_gather', 'block_scatter_add', 'elbo_reduce', 'philox_fill',
            'adam_apply', 'sigmoid_fwd', 'affine_fwd', 'scatter_sums', 'poe_fwd_draw', 'poe_bwd_split', 'adam_apply_at',
-           'counter_add', 'conv_repack_batched']
+           'counter_add', 'conv_repack_batched', 'bn_stats_merge']
 
 
 class KernelProfile(object):

@@ -338,7 +338,11 @@ def test_conv_transpose2d(B, Cin, H, Cout, s, p):
                                            (3, 32, 512, ()), (1, 256, 512, ()), (2, 64, 128, (8, 8)),
                                            (3, 256, 128, (8, 8)), (2, 256, 128, (8, 8)), (1, 256, 256, (5, 5)),
                                            (1, 256, 64, (16, 16)), (4, 8, 32, (8, 8)), (2, 300, 40, ()),
-                                           (3, 256, 512, ()), (4, 16, 48, ()), (3, 40, 24, (5, 5)), (1, 3, 8, (2, 2))])
+                                           (3, 256, 512, ()), (4, 16, 48, ()), (3, 40, 24, (5, 5)), (1, 3, 8, (2, 2)),
+                                           # one block per (channel, group) slice + a per-channel launch (norm.hip, kind 3):
+                                           # 16 K .. 64 K elements per slice, or more groups than the all-groups form takes
+                                           (1, 256, 64, (16, 16)), (2, 256, 16, (16, 16)), (5, 64, 32, (8, 8)),
+                                           (18, 32, 16, (16, 16)), (3, 50, 8, (32, 32)), (2, 70, 8, (32, 32))])
 @pytest.mark.parametrize('act', [True, False])
 def test_batchnorm_train(G, B, C, spatial, act):
     x = g(G * B, C, *spatial, seed=40) * 1.7 + 0.4
@@ -427,6 +431,11 @@ def test_dropout_fan():
     ('A', 64, 37, 2, [0b01, 0b11, 0b10]),
     ('B', 100, 16, 3, [0b101, 0b010, 0b100]),
     ('B', 100, 9, 19, [(1 << 19) - 1, 1, 2, 1 << 18, 0b1010101, 0b110]),
+    # celeba19's step: 3 image draws + 18 attributes = 21 experts, 21 terms (complete, image only, 18 single attributes,
+    # one sampled subset) -- the launch is cut into blocks of 3 terms / 3 experts (poe.hip, MVAE_POE_CHUNK); expert 2
+    # (the sampled term's image draw) is in no term here: its gradient must come out zero
+    ('B', 100, 10, 21, [1 | (((1 << 18) - 1) << 3), 2] + [1 << (3 + i) for i in range(18)] + [0b1011 << 5]),
+    ('A', 64, 5, 7, [0b1111111, 0b1, 0b10, 0b1000000, 0b0101010]),
 ])
 def test_poe(variant, D, B, E, masks):
     T = len(masks)
@@ -806,3 +815,53 @@ def test_ingest_one_launch_for_batch_and_tables():
     assert not K.ingest_ok(image[:, :, :, :27], s_img[:, :, :, :27], label, s_lbl)       # not contiguous
     with pytest.raises(RuntimeError, match='pinned'):
         K.ingest(image, s_img, label, s_lbl, torch.arange(57, dtype=torch.int32), s_tbl)
+
+
+# ----------------------------------------------------------------------------- statistics-only transposed conv
+@pytest.mark.parametrize('G,B,Cin,H,Cout', [(3, 8, 64, 16, 32), (1, 2, 64, 16, 32), (18, 16, 64, 16, 32), (2, 4, 16, 8, 8)])
+def test_convT_stats_only_matches_conv_then_batchnorm(G, B, Cin, H, Cout):
+    """mvae_convT2d_k4_fwd_stats + mvae_bn_stats_merge (the last layer of a decoder pass that exists only for its
+    BatchNorm running statistics: nothing stored) == ConvTranspose2d then training-mode BatchNorm statistics, per group,
+    n_updates times each: 1e-5 on the running statistics, like the storing launch + statistics sweep it replaces."""
+    x = g(G * B, Cin, H, H, seed=60) * 0.8 + 0.3
+    w = g(Cin, Cout, 4, 4, seed=61, scale=(Cin * 4) ** -0.5)
+    y = F.conv_transpose2d(x, w, None, 2, 1)
+    rm, rv = 0.05 * g(Cout, seed=62), 1 + 0.1 * torch.rand(Cout, generator=torch.Generator().manual_seed(63))
+    rm0, rv0 = rm.clone(), rv.clone()
+    means, invstds = [], []
+    for gi in range(G):
+        yg = y[gi * B:(gi + 1) * B]
+        for _ in range(2):
+            F.batch_norm(yg, rm, rv, None, None, True, 0.1, 1e-5)
+        means.append(yg.mean(dim=(0, 2, 3)))
+        invstds.append((yg.var(dim=(0, 2, 3), unbiased=False) + 1e-5).rsqrt())
+    xd, wd = dev(x), dev(w)
+    tiles = K.convT2d_stats_tiles(xd, wd, 2, 1)
+    assert tiles == G * B * H * H // 128 and tiles % G == 0
+    part = K.convT2d_fwd_stats(xd, wd, 2, 1)
+    assert part.shape == (tiles, Cout, 2)
+    sm = torch.empty(G, Cout, device=DEV); si = torch.empty(G, Cout, device=DEV)
+    rmd, rvd = dev(rm0), dev(rv0)
+    K.bn_stats_merge(part, G, sm, si, rmd, rvd, n_updates=2)
+    assert_close(sm, torch.stack(means), 'group means', tol=1e-5)
+    assert_close(si, torch.stack(invstds), 'group invstd', tol=1e-5)
+    assert_close(rmd, rm, 'running_mean', tol=1e-5)
+    assert_close(rvd, rv, 'running_var', tol=1e-5)
+    # ... and the route it replaces: the storing launch, then the statistics-only BatchNorm sweep
+    pre = torch.empty(*y.shape, device=DEV)
+    K.convT2d_fwd(xd, wd, pre, None, 2, 1)
+    rm2, rv2 = dev(rm0), dev(rv0)
+    sm2 = torch.empty(G, Cout, device=DEV); si2 = torch.empty(G, Cout, device=DEV)
+    K.bn_train_fwd(pre, torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV), None, sm2, si2, rm2, rv2, G,
+                   n_updates=2, swish=False)
+    assert_close(rmd, rm2, 'running_mean vs sweep', tol=1e-5)
+    assert_close(rvd, rv2, 'running_var vs sweep', tol=1e-5)
+
+
+def test_convT_stats_only_refuses_what_it_does_not_cover():
+    xd = torch.zeros(4, 64, 16, 16, device=DEV)
+    assert K.convT2d_stats_tiles(xd, torch.zeros(64, 64, 4, 4, device=DEV), 2, 1) == 0       # 64 output channels
+    assert K.convT2d_stats_tiles(torch.zeros(3, 64, 5, 5, device=DEV), torch.zeros(64, 32, 4, 4, device=DEV), 2, 1) == 0
+    assert K.convT2d_stats_tiles(torch.zeros(4, 256, 5, 5, device=DEV), torch.zeros(256, 32, 4, 4, device=DEV), 1, 0) == 0
+    with pytest.raises(RuntimeError):
+        K.convT2d_fwd_stats(xd, torch.zeros(64, 64, 4, 4, device=DEV), 2, 1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build experiment variants of the tuning library: tools/build_variants.sh name "-DFLAG=..." [name flags ...]
 # -> multimodal-vae-public_amd/libmvae_hip_tuning_<name>.so (used with MVAE_HIP_LIB=... tools/gemm_bench.py, bench.py,
-# tools/ab_matrix.sh).  linear.hip, conv.hip and norm.hip are rebuilt with the flags; the other objects are shared.
+# tools/ab_matrix.sh).  linear.hip, conv.hip, norm.hip and poe.hip are rebuilt with the flags; the other objects are shared.
 set -e
 cd "$(dirname "$0")/../multimodal-vae-public_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -13,8 +13,9 @@ while [ $# -ge 2 ]; do
     ( $HIPCC $FLAGS $extra -c linear.hip -o variants/$name/linear.o 2>/dev/null ) &
     ( $HIPCC $FLAGS $extra -c conv.hip -o variants/$name/conv.o 2>/dev/null ) &
     ( $HIPCC $FLAGS $extra -c norm.hip -o variants/$name/norm.o 2>/dev/null ) &
+    ( $HIPCC $FLAGS $extra -c poe.hip -o variants/$name/poe.o 2>/dev/null ) &
     wait
     $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmvae_hip_tuning_$name.so variants/$name/linear.o variants/$name/conv.o \
-        variants/$name/norm.o poe.o loss.o misc.o reparam.o gather.o preprocess.o comm.o gru.o -ldl
+        variants/$name/norm.o variants/$name/poe.o loss.o misc.o reparam.o gather.o preprocess.o comm.o gru.o -ldl
     echo built libmvae_hip_tuning_$name.so
 done
