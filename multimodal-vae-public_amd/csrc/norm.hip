@@ -641,8 +641,9 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_slice_fwd_kernel(const float *
     // offsets advance by a constant, nothing to keep per unit
     const int hw4 = sh.HW >> 2, rpp = BNF_THREADS / hw4, b0 = threadIdx.x / hw4;
     const int off0 = (b0 * sh.C + c) * sh.HW + 4 * (threadIdx.x - b0 * hw4), dk = rpp * sh.C * sh.HW;
+    const int safe = c * sh.HW + 4 * (threadIdx.x - b0 * hw4);   // row 0 of the slice: where a unit past the batch reads (masked out of the sums)
 #define BNS_OK(k) (b0 + (k) * rpp < sh.B)
-#define BNS_OFF(k) (gbase + (BNS_OK(k) ? off0 + (k) * dk : off0))
+#define BNS_OFF(k) (gbase + (BNS_OK(k) ? off0 + (k) * dk : safe))
     float4 v[BNS_KMAX];
 #pragma unroll
     for (int k = 0; k < BNS_KMAX; ++k) v[k] = ld4(x, BNS_OFF(k));
@@ -706,6 +707,7 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_slice_bwd_kernel(const float *
     const size_t gbase = (size_t)g * sh.B * sh.C * sh.HW;
     const int hw4 = sh.HW >> 2, rpp = BNF_THREADS / hw4, b0 = threadIdx.x / hw4;
     const int off0 = (b0 * sh.C + c) * sh.HW + 4 * (threadIdx.x - b0 * hw4), dk = rpp * sh.C * sh.HW;
+    const int safe = c * sh.HW + 4 * (threadIdx.x - b0 * hw4);
     const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
     const float ga = gamma[c], be = beta[c];
     float4 dh[BNS_KMAX];

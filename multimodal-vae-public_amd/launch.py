@@ -31,9 +31,11 @@ CHAIN_ENV = 'MVAE_BENCH_CHAIN'
 
 # name -> (environment of the child, extra argv, default budget in seconds)
 TRANSPORTS = {
-    'mvae_comm-one-graph': ({'MVAE_COMM': 'rccl'}, [], 240.0),
-    'torch-three-graphs': ({'MVAE_COMM': 'torch'}, [], 200.0),
-    'torch-eager': ({'MVAE_COMM': 'torch'}, ['--no-graph'], 200.0),
+    # budgets: a healthy 8-rank run (RCCL bring-up, capture, warm-up, timed steps, the collectives-off re-measure) takes
+    # well under a minute once the supervisor's own `import torch` has paged the libraries in
+    'mvae_comm-one-graph': ({'MVAE_COMM': 'rccl'}, [], 180.0),
+    'torch-three-graphs': ({'MVAE_COMM': 'torch'}, [], 150.0),
+    'torch-eager': ({'MVAE_COMM': 'torch'}, ['--no-graph'], 150.0),
     # CPU tests of the chain itself
     'fake-hang': ({}, [], 5.0),
     'fake-raise': ({}, [], 60.0),
