@@ -1005,10 +1005,14 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
 //      fragments; k loop over Cout; the finished 128 x 64 tile is parked in LDS and every thread gathers the
 //      <= 16 taps of its output pixels. ----
 constexpr int S1_ROWS = 128, S1_COLS = 64;
+#ifndef MVAE_S1_BK
+#define MVAE_S1_BK 32           // k-tile depth of convT_s1_kernel (16: 33 KB of LDS, four blocks per CU instead of three -- A/B builds)
+#endif
+constexpr int S1_BK = MVAE_S1_BK;
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
                                                           const float *dpre, ConvGeom g, int NI) {
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
-    constexpr int P_FL = BK * PP, Q_FL = BK * QP;
+    constexpr int P_FL = S1_BK * PP, Q_FL = S1_BK * QP;
     __shared__ __attribute__((aligned(16))) float s1_lds[2 * P_FL + 2 * Q_FL > S1_ROWS * TP ? 2 * P_FL + 2 * Q_FL : S1_ROWS * TP];
     auto Ps = [&](int b2) { return reinterpret_cast<float (*)[PP]>(s1_lds + b2 * P_FL); };
     auto Qs = [&](int b2) { return reinterpret_cast<float (*)[QP]>(s1_lds + 2 * P_FL + b2 * Q_FL); };
@@ -1043,26 +1047,27 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     const BufBase pblk = buf_base(dy + (size_t)n0 * K * P);
     // Q loader: weight rows are contiguous in (ci, tap): 16 float4 per k row, 2 per thread
     const BufBase qblk = buf_base(w + (size_t)ci0 * 16);
-    int qvoff[2];
+    constexpr int S1_NP = S1_BK / 2, S1_NQ = S1_BK / 16;    // dwords of dy / float4 of w a thread moves per k-step
+    int qvoff[S1_NQ];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < S1_NQ; ++v) {
         const int f = t + 256 * v;
         qvoff[v] = ((f >> 4) * J + (f & 15) * 4) * 4;
     }
-    float pr[16];
-    float4 qr[2];
+    float pr[S1_NP];
+    float4 qr[S1_NQ];
     auto load = [&](int k0) {
         const i32x4_t prs = buf_rsrc(pblk, 0), qrs = buf_rsrc(qblk, (size_t)k0 * J);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) pr[v] = llvm_raw_buffer_load_f32(prs, pvoff, (k0 + 2 * v) * P * 4, 0);
+        for (int v = 0; v < S1_NP; ++v) pr[v] = llvm_raw_buffer_load_f32(prs, pvoff, (k0 + 2 * v) * P * 4, 0);
 #pragma unroll
-        for (int v = 0; v < 2; ++v) qr[v] = buf_load4(qrs, qvoff[v]);
+        for (int v = 0; v < S1_NQ; ++v) qr[v] = buf_load4(qrs, qvoff[v]);
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) Ps(buf)[pkq + 2 * v][pr_] = pr[v];
+        for (int v = 0; v < S1_NP; ++v) Ps(buf)[pkq + 2 * v][pr_] = pr[v];
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < S1_NQ; ++v) {
             const int f = t + 256 * v;
             *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) = qr[v];
         }
@@ -1073,20 +1078,20 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
-    const int nsteps = (K + BK - 1) / BK;
+    const int nsteps = (K + S1_BK - 1) / S1_BK;
     load(0);
     store(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        load(min(s + 1, nsteps - 1) * BK);          // unconditional (the last trip re-reads its own tile): no branch
+        load(min(s + 1, nsteps - 1) * S1_BK);          // unconditional (the last trip re-reads its own tile): no branch
         float a0[2], b0;
         a0[0] = Ps(buf)[lrow][wi * 64 + lcol]; a0[1] = Ps(buf)[lrow][wi * 64 + 32 + lcol];
         b0 = Qs(buf)[lrow][wj * 32 + lcol];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int kk = 0; kk < S1_BK / 2; ++kk) {
             float a1[2] = {0.f, 0.f}, b1 = 0.f;
-            if (kk + 1 < BK / 2) {
+            if (kk + 1 < S1_BK / 2) {
                 a1[0] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + lcol];
                 a1[1] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + 32 + lcol];
                 b1 = Qs(buf)[(kk + 1) * 2 + lrow][wj * 32 + lcol];
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
 }
 
 inline bool conv_dgrad_s1_ok(const ConvGeom &g, const float *w) {
-    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && g.Cout % BK == 0 && aligned16(w) &&
+    return g.stride == 1 && g.pad == 0 && g.OH * g.OW <= 32 && g.Cin % 4 == 0 && g.Cout % S1_BK == 0 && aligned16(w) &&
            (size_t)128 * g.Cout * g.OH * g.OW * 4 < (1ull << 31);
 }
 

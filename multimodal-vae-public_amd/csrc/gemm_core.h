@@ -50,6 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_MULTI_MINBLOCKS
 #define MVAE_MULTI_MINBLOCKS 1024   // a multi-item launch keeps at least this many column blocks (4 per CU)
 #endif
+#ifndef MVAE_WGRAD_TARGET
+#define MVAE_WGRAD_TARGET 512   // blocks a split conv weight gradient aims for (two per CU); fewer = fewer partial slabs (A/B builds)
+#endif
 #ifndef MVAE_WGRAD_TILE
 #define MVAE_WGRAD_TILE 128
 #endif
@@ -1352,7 +1355,7 @@ inline Plan make_plan(int I, int J, int K, bool allow_split, PlanKind kind = PLA
         const long target_tune = MVAE_TUNE(split_target);
         long target_blocks = 1024 / p.kw;
         if (kind == PLAN_FWD) target_blocks = (p.kw == 1) ? 512 : 256;
-        if (kind == PLAN_CONV_WGRAD && p.wm * p.wn >= 2) target_blocks = 512;
+        if (kind == PLAN_CONV_WGRAD && p.wm * p.wn >= 2) target_blocks = MVAE_WGRAD_TARGET;
         if (target_tune > 0) target_blocks = target_tune / p.kw;
         want = (target_blocks + tiles / 2) / tiles;         // nearest: 800 tiles against 1024 is one round, not two
         const long maxs = (K + 2 * BK - 1) / (2 * BK);
