@@ -1009,9 +1009,6 @@ constexpr int S1_ROWS = 128, S1_COLS = 64;
 #define MVAE_S1_BK 16           // k-tile depth of convT_s1_kernel: 16 = 33 KB of LDS (the col2im tile), FOUR blocks per CU; 32 = 51 KB, three (round 3).  More co-resident blocks hide the cold prologue + col2im epilogue of each: CelebA-19 6.67 -> 6.55 ms, CelebA 2.453 -> 2.425 (profiles/r04_s1bk_wgt_ab.txt)
 #endif
 constexpr int S1_BK = MVAE_S1_BK;
-#ifndef MVAE_S1_COALESCE
-#define MVAE_S1_COALESCE 0      // 1: dy fetched as contiguous per-image runs (A/B builds; see the kernel)
-#endif
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
                                                           const float *dpre, ConvGeom g, int NI) {
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
@@ -1042,7 +1039,9 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass.  Buffer loads
     // (gemm_core.h): the lane part of the address -- image, position, k parity -- is a constant voffset (BUF_OOB
     // for the 3 pad rows / images past the batch: zero fill), the k-step part rides the scalar soffset; nothing
-    // on the vector ALU (K % BK == 0 is a launch condition).
+    // on the vector ALU (K % BK == 0 is a launch condition).  (Measured and not kept, round 4: lanes walking the
+    // contiguous S1_BK * P run of each image -- 256 contiguous bytes per wave load instead of ~7 lines -- with the LDS
+    // places as thread constants: 16 more registers, CelebA-19 6.63 -> 6.76 ms, profiles/r04_s1bk_wgt_ab.txt.)
     const int pr_ = t & 127, pkq = t >> 7;
     const int pimg = pr_ / P, ppos = pr_ - pimg * P;
     const bool pok = pimg < NI && n0 + pimg < g.B;
@@ -1059,47 +1058,6 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     }
     float pr[S1_NP];
     float4 qr[S1_NQ];
-#if MVAE_S1_COALESCE
-    // dy of one image and one k-tile is ONE contiguous run of S1_BK * P floats (all positions of S1_BK consecutive
-    // channels).  Lanes walk it element by element: a wave's load is 256 contiguous bytes (2-3 lines) where the
-    // (row, k-parity) mapping above touches ~7 lines per instruction, and the element's place in LDS -- (k, image * P +
-    // position) -- is a thread constant like its offset.  The pad rows of the 128-row tile are never written: cleared once.
-    const int chunk = S1_BK * P, total = NI * chunk;
-    int cvoff[S1_NP], clds[S1_NP];
-#pragma unroll
-    for (int v = 0; v < S1_NP; ++v) {
-        const int e = t + 256 * v;
-        const int img = e / chunk, r = e - img * chunk;
-        const int kk = r / P, pos = r - kk * P;
-        const bool live = e < total;
-        cvoff[v] = (live && n0 + img < g.B) ? (img * K * P + r) * 4 : BUF_OOB;
-        clds[v] = live ? kk * PP + img * P + pos : -1;
-    }
-    {
-        const int pad = S1_ROWS - NI * P;               // 3 rows for 5 images of 25 positions
-        for (int i = t; i < 2 * S1_BK * pad; i += 256) {
-            const int row = i / pad;                    // (buffer, k) row of the two P tiles
-            s1_lds[row * PP + NI * P + (i - row * pad)] = 0.f;
-        }
-    }
-    auto load = [&](int k0) {
-        const i32x4_t prs = buf_rsrc(pblk, (size_t)k0 * P), qrs = buf_rsrc(qblk, (size_t)k0 * J);
-#pragma unroll
-        for (int v = 0; v < S1_NP; ++v) pr[v] = buf_load1(prs, cvoff[v]);
-#pragma unroll
-        for (int v = 0; v < S1_NQ; ++v) qr[v] = buf_load4(qrs, qvoff[v]);
-    };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int v = 0; v < S1_NP; ++v)
-            if (clds[v] >= 0) s1_lds[buf * P_FL + clds[v]] = pr[v];
-#pragma unroll
-        for (int v = 0; v < S1_NQ; ++v) {
-            const int f = t + 256 * v;
-            *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) = qr[v];
-        }
-    };
-#else
     auto load = [&](int k0) {
         const i32x4_t prs = buf_rsrc(pblk, 0), qrs = buf_rsrc(qblk, (size_t)k0 * J);
 #pragma unroll
@@ -1116,7 +1074,6 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) = qr[v];
         }
     };
-#endif
     f32x16 acc[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
