@@ -620,13 +620,10 @@ __global__ __launch_bounds__(BNF_THREADS) void bn1d_fused_bwd_kernel(const float
     }
 }
 
-// ---- slices of up to 64 K elements with MANY groups, or too large for the all-groups form above (the 16x16 maps at
-//      batch 256: 65,536 elements per (group, channel); celeba19's 18- and 21-group decoder passes): grid (C, G), block
-//      (c, g) keeps ITS slice in registers between the statistics and the apply -- one launch, one read -- and leaves
-//      (mean, variance) / the two backward sums in the workspace; what couples the groups of a channel (running
-//      statistics in group order, dgamma / dbeta summed over the groups) is a one-thread-per-channel launch behind it.
-//      The backward keeps dh = dy * swish'(h) and re-reads x (still in L2 / MALL from its own first pass) for x-hat:
-//      four transfers in one launch instead of five in two.
+// ---- slices of 16 K .. 64 K elements in MANY groups (celeba19's 18-group statistics-only pass over the 16x16 maps):
+//      grid (C, G), block (c, g) keeps ITS slice in registers between the statistics and the apply -- one launch, one
+//      read -- and leaves (mean, variance) in the workspace; the running statistics (which couple the groups of a
+//      channel, in group order) are a one-thread-per-channel launch behind it.
 constexpr int BNS_KMAX = 16;                // float4 per thread: 1024 threads x 16 x 4 = 65,536 elements
 constexpr int BNS_MAX_N = BNF_THREADS * BNS_KMAX * 4;
 
@@ -698,64 +695,8 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float *stats, int
     running_var[c] = rv;
 }
 
-__global__ __launch_bounds__(BNF_THREADS) void bn_slice_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                                   const float *gamma, const float *beta,
-                                                                   const float *save_mean, const float *save_invstd,
-                                                                   float *__restrict__ dx, float *sums, BnShape sh, int swish) {
-    __shared__ float red[BNF_WAVES * 2];
-    const int c = blockIdx.x, g = blockIdx.y;
-    const size_t gbase = (size_t)g * sh.B * sh.C * sh.HW;
-    const int hw4 = sh.HW >> 2, rpp = BNF_THREADS / hw4, b0 = threadIdx.x / hw4;
-    const int off0 = (b0 * sh.C + c) * sh.HW + 4 * (threadIdx.x - b0 * hw4), dk = rpp * sh.C * sh.HW;
-    const int safe = c * sh.HW + 4 * (threadIdx.x - b0 * hw4);
-    const float mean = save_mean[g * sh.C + c], invstd = save_invstd[g * sh.C + c];
-    const float ga = gamma[c], be = beta[c];
-    float4 dh[BNS_KMAX];
-    float s[2] = {0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < BNS_KMAX; ++k) {
-        // four units' loads in flight at a time: with all 16 x loads hoisted next to the 64 registers of dh the kernel spilled
-        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        const float4 xv = ld4(x, BNS_OFF(k));
-        dh[k] = ld4(dy, BNS_OFF(k));
-        auto one = [&](float xe, float &d) {
-            const float xh = (xe - mean) * invstd;
-            if (swish) d *= swish_grad_(ga * xh + be);
-            s[0] += BNS_OK(k) ? d : 0.f;
-            s[1] += BNS_OK(k) ? d * xh : 0.f;
-        };
-        one(xv.x, dh[k].x); one(xv.y, dh[k].y); one(xv.z, dh[k].z); one(xv.w, dh[k].w);
-    }
-    bnf_block_sums<2>(s, red);
-    if (threadIdx.x == 0) {
-        sums[(g * sh.C + c) * 2] = s[0];
-        sums[(g * sh.C + c) * 2 + 1] = s[1];
-    }
-    const float inv_n = 1.f / (float)sh.n;
-    const float kf = ga * invstd, m1 = s[0] * inv_n, m2 = s[1] * inv_n;
-#pragma unroll
-    for (int k = 0; k < BNS_KMAX; ++k) {
-        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        if (!BNS_OK(k)) continue;
-        const float4 xv = ld4(x, BNS_OFF(k));          // second read: this block's own lines, L2 / MALL
-        auto one = [&](float xe, float d) { return kf * (d - m1 - ((xe - mean) * invstd) * m2); };
-        st4(dx, BNS_OFF(k), make_float4(one(xv.x, dh[k].x), one(xv.y, dh[k].y), one(xv.z, dh[k].z), one(xv.w, dh[k].w)));
-    }
-}
 #undef BNS_OK
 #undef BNS_OFF
-
-// dbeta[c] = sum_g sums[g][c][0], dgamma[c] = sum_g sums[g][c][1]  (+ what is there with `accumulate`)
-__global__ __launch_bounds__(256) void bn_param_grads_kernel(const float *sums, int G, int C, float *dgamma, float *dbeta,
-                                                             int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float t1 = 0.f, t2 = 0.f;
-    for (int g = 0; g < G; ++g) { t1 += sums[(g * C + c) * 2]; t2 += sums[(g * C + c) * 2 + 1]; }
-    if (accumulate) { t1 += dbeta[c]; t2 += dgamma[c]; }
-    dbeta[c] = t1;
-    dgamma[c] = t2;
-}
 
 // ---- statistics from the records a statistics-only conv launch left (mvae_convT2d_k4_fwd_stats: (mean, M2) per
 //      column tile and channel over `elems` elements each, tiles of a group contiguous): per (group, channel) the
@@ -815,9 +756,14 @@ inline int bn_fused_kind(const BnShape &sh, bool bwd) {
     // (unaligned / odd-width maps keep one element per register: half the slice when several groups share the block)
     const int max_n = (!sh.vec && sh.G > 1) ? BNF_MAX_N / 2 : BNF_MAX_N;
     if (sh.n <= max_n && sh.G <= (bwd ? BNF_GMAX_BWD : BNF_GMAX_FWD)) return 1;
-    // 3: one block per (channel, group) slice + a per-channel launch for what couples the groups
-    return (MVAE_BN_SLICE && sh.vec && sh.n <= BNS_MAX_N && sh.G <= 65535 && (sh.HW >> 2) <= BNF_THREADS &&
-            BNF_THREADS % (sh.HW >> 2) == 0) ? 3 : 0;
+    // 3 (forward only): one block per (channel, group) slice + a per-channel launch for the running statistics.  Only
+    // where it measured faster than the two-launch path (profiles/r04_*_by_shape.txt, session 2 vs final): slices of
+    // 16 K .. 64 K elements with >= 512 of them -- celeba19's 18-group pass over the 16x16 maps, 181 -> 129 us.  With
+    // 64 .. 128 slices (CelebA's own 16x16 layers) the 1024-thread blocks leave most CUs idle (13.8 -> 19.4 us), at
+    // 16 K elements the two-launch path is already at 6 TB/s (75 -> 86 us), and the backward form (dh kept, x re-read)
+    // lost everywhere it was tried (18.4 -> 34.4 us at 64 slices) and was removed.
+    return (!bwd && MVAE_BN_SLICE && sh.vec && sh.n > BNF_MAX_N && sh.n <= BNS_MAX_N && (long)sh.C * sh.G >= 512 &&
+            sh.G <= 65535 && (sh.HW >> 2) <= BNF_THREADS && BNF_THREADS % (sh.HW >> 2) == 0) ? 3 : 0;
 }
 
 inline bool bn_shape(int G, int B, int C, int HW, const void *a, const void *b, const void *c, BnShape *sh) {
@@ -912,14 +858,6 @@ MVAE_EXPORT int mvae_bn_train_bwd(const float *dy, const float *x, const float *
         return MVAE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int swish = (flags & MVAE_ACT_SWISH) ? 1 : 0;
-    if (bn_fused_kind(sh, true) == 3) {
-        if (!ws || ws_bytes < (size_t)G * C * 2 * sizeof(float)) return MVAE_ERR_WS;
-        hipLaunchKernelGGL(bn_slice_bwd_kernel, dim3(C, G), dim3(BNF_THREADS), 0, st, dy, x, gamma, beta, save_mean,
-                           save_invstd, dx, (float *)ws, sh, swish);
-        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)ws, G, C, dgamma,
-                           dbeta, (flags & MVAE_ACCUMULATE) ? 1 : 0);
-        return mvae_launch_status();
-    }
     if (const int kind = bn_fused_kind(sh, true)) {
         const int acc = (flags & MVAE_ACCUMULATE) ? 1 : 0;
 #define MVAE_BNF_BWD(KERN, GRID)                                                                                    \

@@ -339,11 +339,12 @@ def test_conv_transpose2d(B, Cin, H, Cout, s, p):
                                            (3, 256, 128, (8, 8)), (2, 256, 128, (8, 8)), (1, 256, 256, (5, 5)),
                                            (1, 256, 64, (16, 16)), (4, 8, 32, (8, 8)), (2, 300, 40, ()),
                                            (3, 256, 512, ()), (4, 16, 48, ()), (3, 40, 24, (5, 5)), (1, 3, 8, (2, 2)),
-                                           # one block per (channel, group) slice + a per-channel launch (norm.hip, kind 3):
-                                           # 16 K .. 64 K elements per slice, or more groups than the all-groups form takes
+                                           # more groups / larger slices than the all-groups form takes (two-launch path), and
+                                           # the per-slice forward form (norm.hip kind 3: 16 K .. 64 K elements, >= 512 slices)
                                            (1, 256, 64, (16, 16)), (2, 256, 16, (16, 16)), (5, 64, 32, (8, 8)),
                                            (18, 32, 16, (16, 16)), (3, 50, 8, (32, 32)), (2, 70, 8, (32, 32)),
-                                           (3, 4, 128, (8, 8)), (18, 4, 64, (16, 16)), (4, 2, 16, (4, 4))])
+                                           (3, 4, 128, (8, 8)), (18, 4, 64, (16, 16)), (4, 2, 16, (4, 4)),
+                                           (32, 68, 16, (16, 16)), (18, 128, 32, (16, 16)), (16, 20, 32, (32, 32))])
 @pytest.mark.parametrize('act', [True, False])
 def test_batchnorm_train(G, B, C, spatial, act):
     x = g(G * B, C, *spatial, seed=40) * 1.7 + 0.4
