@@ -258,6 +258,10 @@ def run(kind, mvae_cls, test_total, args, lambda_label, annealing_epoch_offset=0
     from .optim import FusedAdam
     from .parallel import DataParallel
 
+    # N ranks on one node exchange gradients through RCCL: this platform's driver only supports dmabuf IPC, and the
+    # HSA runtime reads the switch when the process first touches the GPU (the is_available() call below) -- without
+    # it RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     args.cuda = args.cuda and torch.cuda.is_available()
     if not args.cuda:
         raise SystemExit('this drop-in runs the MVAE step as HIP kernels: pass --cuda on a ROCm GPU box '
