@@ -596,7 +596,9 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree' % (args.gpus, world))
     from mvae_amd import launch
-    if world > 1 and launch.WORKER_ENV not in os.environ and os.environ.get('MVAE_BENCH_SUPERVISE', '1') != '0':
+    supervise = os.environ.get('MVAE_BENCH_SUPERVISE', '1')      # '0': ranks run directly; 'force': also at world size 1 (tests)
+    if (world > 1 or (supervise == 'force' and 'WORLD_SIZE' in os.environ)) and launch.WORKER_ENV not in os.environ \
+            and supervise != '0':
         # A launched rank is a SUPERVISOR (mvae_amd/launch.py): it runs each gradient-exchange transport in a child
         # process under a wall-clock budget -- a hung collective is killed with its process, not waited for -- and the
         # ranks agree per attempt whether it succeeded everywhere.  The first transport that completes on every rank

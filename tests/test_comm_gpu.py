@@ -109,3 +109,32 @@ def test_one_graph_data_parallel_step_equals_single_gpu_graph(world1, kind, batc
     assert_close(torch.tensor(runs['rccl'][0]), torch.tensor(runs['single'][0]), 'losses one-graph dp vs single', tol=1e-6)
     assert_close(runs['rccl'][1], runs['single'][1], 'parameters one-graph dp vs single', tol=1e-6)
     assert torch.equal(runs['rccl'][1], runs['torch'][1]), 'the two transports must give the same bits at world 1'
+
+
+def test_rank_supervisor_on_the_gpu_kills_a_hung_attempt_and_the_next_one_gets_the_gpu():
+    """The transport chain of ``bench.py --gpus N`` (mvae_amd/launch.py) end to end on a GPU, at the only world size a
+    one-GPU box offers: under the real launcher the rank is a supervisor; its first child hangs (after it has a GPU context
+    and an RCCL process group) and is killed with its process group when the budget is spent; the second child -- the
+    library's communicator, collectives inside the step graph -- must find the GPU usable and deliver the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'MVAE_COMM'):
+        env.pop(k, None)
+    env.update(MVAE_BENCH_SUPERVISE='force', MVAE_BENCH_CHAIN='fake-hang:25,mvae_comm-one-graph:200')
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dp', '--no-extras',
+           '--steps', '10', '--warmup', '3']
+    r = subprocess.run(cmd, env=env, timeout=400, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and lines, r.stderr[-3000:]
+    line = json.loads(lines[-1])
+    assert line['value'] and line['n_gpus'] == 1
+    d = line['dist']
+    assert d['transport_attempt'] == 'mvae_comm-one-graph' and 'mvae_comm' in d['transport']
+    assert [t['transport'] for t in d['fallbacks_tried']] == ['fake-hang'] and d['fallbacks_tried'][0]['ranks'] == ['timeout']
