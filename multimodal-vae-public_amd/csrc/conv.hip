@@ -1009,18 +1009,15 @@ constexpr int S1_ROWS = 128, S1_COLS = 64;
 #define MVAE_S1_BK 16           // k-tile depth of convT_s1_kernel: 16 = 33 KB of LDS (the col2im tile), FOUR blocks per CU; 32 = 51 KB, three (round 3).  More co-resident blocks hide the cold prologue + col2im epilogue of each: CelebA-19 6.67 -> 6.55 ms, CelebA 2.453 -> 2.425 (profiles/r04_s1bk_wgt_ab.txt)
 #endif
 constexpr int S1_BK = MVAE_S1_BK;
-#ifndef MVAE_S1_HALF
-#define MVAE_S1_HALF 0          // 1: col2im in two 32-column passes (17 KB instead of 33 KB of staging; A/B builds)
+#ifndef MVAE_S1_TAPS
+#define MVAE_S1_TAPS 1          // 8x8 outputs: the col2im tap table is computed once per thread, not once per image (0: A/B builds)
 #endif
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
                                                           const float *dpre, ConvGeom g, int NI) {
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
     constexpr int P_FL = S1_BK * PP, Q_FL = S1_BK * QP;
-    // col2im staging: the whole 128 x 64 tile (33 KB), or -- MVAE_S1_HALF -- two passes of 128 x 32 (17 KB: the block
-    // then needs only its 26 KB of k-loop buffers, SIX blocks per CU instead of four)
-    constexpr int TPH = S1_COLS / 2 + 1;
-    constexpr int EPI_FL = MVAE_S1_HALF ? S1_ROWS * TPH : S1_ROWS * TP;
-    __shared__ __attribute__((aligned(16))) float s1_lds[2 * P_FL + 2 * Q_FL > EPI_FL ? 2 * P_FL + 2 * Q_FL : EPI_FL];
+    // (col2im in two 32-column passes -- 17 KB of staging, six blocks per CU -- measured neutral against four: not kept)
+    __shared__ __attribute__((aligned(16))) float s1_lds[2 * P_FL + 2 * Q_FL > S1_ROWS * TP ? 2 * P_FL + 2 * Q_FL : S1_ROWS * TP];
     auto Ps = [&](int b2) { return reinterpret_cast<float (*)[PP]>(s1_lds + b2 * P_FL); };
     auto Qs = [&](int b2) { return reinterpret_cast<float (*)[QP]>(s1_lds + 2 * P_FL + b2 * Q_FL); };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1118,57 +1115,81 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     // <= 16 taps of its output pixels (image, channel, pixel).  The reads are unconditional from clamped positions with
     // a 0/1 factor (16 LDS reads in flight; a branch per tap made every read wait for the one before it).
     float *sc = s1_lds;
-    const int HW = g.H * g.W;
-    const bool pow2 = (g.H == 8 && g.W == 8);
-    constexpr int NH = MVAE_S1_HALF ? 2 : 1;            // passes; channels per pass: 4 / NH
-    constexpr int CPP = 4 / NH, PITCH = MVAE_S1_HALF ? TPH : TP;
-    const int per_img = CPP * HW;
 #pragma unroll
-    for (int half = 0; half < NH; ++half) {
-        if (half) __syncthreads();                      // the first pass's readers are done with the tile
-        if (!MVAE_S1_HALF || wj == half) {
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                    sc[row * PITCH + (MVAE_S1_HALF ? 0 : wj * 32) + lcol] = acc[x][r];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+            sc[row * TP + wj * 32 + lcol] = acc[x][r];
         }
-        __syncthreads();
-        for (int idx = t; idx < NI * per_img; idx += 256) {
-            int img, cl, ih, iw;
-            if (pow2) {
-                img = idx >> (MVAE_S1_HALF ? 7 : 8); cl = (idx >> 6) & (CPP - 1); ih = (idx >> 3) & 7; iw = idx & 7;
-            } else {
-                img = idx / per_img;
-                const int rem = idx - img * per_img;
-                cl = rem / HW;
-                const int px = rem - cl * HW;
-                ih = px / g.W; iw = px - ih * g.W;
+    __syncthreads();
+    const int HW = g.H * g.W;
+    const int per_img = 4 * HW;
+    if (MVAE_S1_TAPS && g.H == 8 && g.W == 8) {
+        // 8 x 8 outputs (both layers that use this kernel): 4 channels x 64 pixels = the 256 threads, so a thread's
+        // (channel, pixel) -- and with it the 16 tap positions and their validity -- is the same for every image of the
+        // block: computed ONCE; per image a tap is one address add, one LDS read, one FMA.  On fp32 MFMA the vector
+        // instructions of this epilogue are matrix time taken from the co-resident blocks (profiles/r04_celeba_sq_counters.txt:
+        // 5.4 VALU per MFMA instruction over the whole kernel, about half of them here, re-derived per image).
+        const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
+        int toff[16];
+        float tmask[16];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int oh = ih - kh;
+            const bool okh = oh >= 0 && oh < g.OH;
+            const int ohc = min(max(oh, 0), g.OH - 1);
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ow = iw - kw;
+                const bool ok = okh && ow >= 0 && ow < g.OW;
+                const int owc = min(max(ow, 0), g.OW - 1);
+                toff[kh * 4 + kw] = (ohc * g.OW + owc) * TP + cl * 16 + kh * 4 + kw;
+                tmask[kh * 4 + kw] = ok ? 1.f : 0.f;
             }
-            const int n = n0 + img, ci = ci0 + half * CPP + cl;
-            if (n >= g.B || ci >= g.Cin) continue;
-            const float *base = sc + (img * P) * PITCH + cl * 16;
+        }
+        const int ci = ci0 + cl, img_fl = P * TP;
+        for (int img = 0; img < NI; ++img) {
+            const int n = n0 + img;
+            if (n >= g.B) break;                        // block-uniform
+            const float *base = sc + img * img_fl;
             float v = 0.f;
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh) {
-                const int oh = ih - kh;
-                const bool okh = oh >= 0 && oh < g.OH;
-                const int ohc = min(max(oh, 0), g.OH - 1);
-#pragma unroll
-                for (int kw = 0; kw < 4; ++kw) {
-                    const int ow = iw - kw;
-                    const bool ok = okh && ow >= 0 && ow < g.OW;
-                    const int owc = min(max(ow, 0), g.OW - 1);
-                    v += (ok ? 1.f : 0.f) * base[(ohc * g.OW + owc) * PITCH + kh * 4 + kw];
-                }
-            }
-            const size_t o = ((size_t)n * g.Cin + ci) * HW + ih * g.W + iw;
+            for (int k = 0; k < 16; ++k) v += tmask[k] * base[toff[k]];
+            const size_t o = ((size_t)n * g.Cin + ci) * HW + (t & 63);
             if (dpre) v *= swish_grad_(dpre[o]);
             if (out) out[o] = v;
             if (act) act[o] = swishf_(v);
         }
+        return;
+    }
+    for (int idx = t; idx < NI * per_img; idx += 256) {
+        const int img = idx / per_img;
+        const int rem = idx - img * per_img;
+        const int cl = rem / HW;
+        const int px = rem - cl * HW;
+        const int ih = px / g.W, iw = px - ih * g.W;
+        const int n = n0 + img, ci = ci0 + cl;
+        if (n >= g.B || ci >= g.Cin) continue;
+        const float *base = sc + (img * P) * TP + cl * 16;
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int oh = ih - kh;
+            const bool okh = oh >= 0 && oh < g.OH;
+            const int ohc = min(max(oh, 0), g.OH - 1);
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ow = iw - kw;
+                const bool ok = okh && ow >= 0 && ow < g.OW;
+                const int owc = min(max(ow, 0), g.OW - 1);
+                v += (ok ? 1.f : 0.f) * base[(ohc * g.OW + owc) * TP + kh * 4 + kw];
+            }
+        }
+        const size_t o = ((size_t)n * g.Cin + ci) * HW + ih * g.W + iw;
+        if (dpre) v *= swish_grad_(dpre[o]);
+        if (out) out[o] = v;
+        if (act) act[o] = swishf_(v);
     }
 }
 

@@ -207,8 +207,14 @@ __global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float *mu, const
 #ifndef MVAE_POE_CHUNK
 #define MVAE_POE_CHUNK 3        // terms (forward) / experts (backward) per block of a many-term launch; 0: one block walks all
 #endif
-// up to 4 terms / experts (the bimodal steps: 3 and 2-3) stay one block per two rows
-inline int poe_chunk(int n) { return (n <= 4 || MVAE_POE_CHUNK <= 0) ? (n > 0 ? n : 1) : MVAE_POE_CHUNK; }
+#ifndef MVAE_POE_CHUNK_SMALL
+#define MVAE_POE_CHUNK_SMALL 0  // terms / experts per block when there are at most 4 of them (the bimodal steps); 0: all in one block
+#endif
+inline int poe_chunk(int n) {
+    if (n <= 0) return 1;
+    if (n <= 4) return MVAE_POE_CHUNK_SMALL > 0 ? MVAE_POE_CHUNK_SMALL : n;
+    return MVAE_POE_CHUNK <= 0 ? n : MVAE_POE_CHUNK;
+}
 
 inline bool poe_args_ok(const mvae_experts_t *ex, int ld, int E, int T, int B, int D, int variant) {
     if (!ex || E < 0 || E > MVAE_MAX_EXPERTS || T <= 0 || T > POE_MAX_TERMS || B <= 0 || D <= 0 || ld < D)
