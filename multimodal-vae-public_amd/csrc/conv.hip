@@ -25,6 +25,9 @@
 #ifndef MVAE_CONV_BK
 #define MVAE_CONV_BK 32
 #endif
+#ifndef MVAE_FAST_DIV
+#define MVAE_FAST_DIV 1         // shifts instead of run-time divisions in the tile set-up / epilogue of power-of-two layers (0: A/B)
+#endif
 // XCD-aware launch-order re-mapping (round 4; each 0 = plain launch order, for A/B builds)
 #ifndef MVAE_CONV_XCD
 #define MVAE_CONV_XCD 1         // forward / dgrad forms: the channel bands of one column tile on one XCD (igemm_kernel, mode 3)
@@ -44,7 +47,24 @@ namespace {
 // Geometry of a 4x4 convolution y[B,Cout,OH,OW] = conv(x[B,Cin,H,W], w[Cout,Cin,4,4]).
 struct ConvGeom {
     int B, Cin, H, W, Cout, OH, OW, stride, pad;
+    // log2 of the sizes the loaders divide a tile's column index by, or -1 if not a power of two (make_geom): the output
+    // map OH*OW / OW (im2col forms) and the class lattice (H/stride)*(W/stride) / (W/stride) (dgrad forms).  A 32-bit
+    // division by a run-time value is ~30 vector instructions, and on fp32 MFMA the vector instructions of a tile's
+    // set-up and epilogue are matrix time (profiles/r04_celeba_sq_counters.txt: 2-4 VALU per MFMA over whole conv
+    // kernels whose main loops issue 0.2-0.8); every CelebA layer is a power of two (8x8 .. 32x32), the 5x5 / 7x7 ones not.
+    int lg_ohw, lg_ow, lg_hw2, lg_w2;
 };
+__host__ __device__ inline int log2_or_neg(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+// q = m / d, r = m % d for m >= 0: the shift form when lg >= 0 (block-uniform choice)
+__device__ __forceinline__ void divmod_fast(int m, int d, int lg, int &q, int &r) {
+    if (lg >= 0) { q = m >> lg; r = m & (d - 1); }
+    else { q = m / d; r = m - q * d; }
+}
 
 // ---- gather loaders ----------------------------------------------------------------------
 // The k index of an element a thread fetches is  k0 + kq + STEP*v  with k0 a multiple of BK = 32,
@@ -73,12 +93,13 @@ struct LdIm2colT {
         unsigned vw = 0;
         vh = 0; base = 0;
         const int ohw = g.OH * g.OW, hw = g.H * g.W;
-        const int n0 = tile0 / ohw;                   // block-uniform
+        const int n0 = g.lg_ohw >= 0 ? tile0 >> g.lg_ohw : tile0 / ohw;      // block-uniform
         blk = buf_base(x + (size_t)n0 * g.Cin * hw);
         int rel = 0;
         if (m < Mtot) {
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            int b, rem, oh, ow;
+            divmod_fast(m, ohw, g.lg_ohw, b, rem);
+            divmod_fast(rem, g.OW, g.lg_ow, oh, ow);
             const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
             base = (b * g.Cin * g.H + ih0) * g.W + iw0 + kq;      // kw = kq + (KSTEP*v & 3)
             rel = ((b - n0) * g.Cin * g.H + ih0) * g.W + iw0 + kq;
@@ -294,11 +315,11 @@ struct LdDgradDyT {
         const int hw2 = H2 * W2, ohw = g.OH * g.OW;
         if (!KEEP || tile0 != c_tile0) {              // block-uniform
             c_tile0 = tile0;
-            c_n0 = tile0 / hw2;
+            c_n0 = g.lg_hw2 >= 0 ? tile0 >> g.lg_hw2 : tile0 / hw2;
             const int mm = m < Mtot ? m : 0;
-            c_n = mm / hw2;
-            const int rem = mm - c_n * hw2;
-            c_ih2 = rem / W2; c_iw2 = rem - c_ih2 * W2;
+            int rem;
+            divmod_fast(mm, hw2, g.lg_hw2, c_n, rem);
+            divmod_fast(rem, W2, g.lg_w2, c_ih2, c_iw2);
         }
         const int n0 = c_n0;
         blk = buf_base(dy + (size_t)n0 * g.Cout * ohw);
@@ -694,6 +715,12 @@ inline ConvGeom make_geom(int B, int Cin, int H, int W, int Cout, int stride, in
     g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.stride = stride; g.pad = pad;
     g.OH = (H + 2 * pad - 4) / stride + 1;
     g.OW = (W + 2 * pad - 4) / stride + 1;
+    g.lg_ohw = (log2_or_neg(g.OH) >= 0 && log2_or_neg(g.OW) >= 0) ? log2_or_neg(g.OH * g.OW) : -1;
+    g.lg_ow = g.lg_ohw >= 0 ? log2_or_neg(g.OW) : -1;
+    const int H2 = H / stride, W2 = W / stride;
+    g.lg_hw2 = (log2_or_neg(H2) >= 0 && log2_or_neg(W2) >= 0) ? log2_or_neg(H2 * W2) : -1;
+    g.lg_w2 = g.lg_hw2 >= 0 ? log2_or_neg(W2) : -1;
+    if (!MVAE_FAST_DIV) g.lg_ohw = g.lg_ow = g.lg_hw2 = g.lg_w2 = -1;
     return g;
 }
 
@@ -817,6 +844,7 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     e.out = pre; e.act = act; e.dpre = dpre;
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
     e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+    e.lg_hw2 = g.lg_ohw; e.lg_w2 = g.lg_ow;
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
     if (aligned16(w))
@@ -1236,6 +1264,7 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     e.out = dx; e.act = act; e.dpre = dpre;
     e.C = g.Cin; e.HW = g.H * g.W; e.Wfull = g.W; e.H2 = H2; e.W2 = W2;
     e.sy = s; e.py = 0; e.px = 0; e.J = J; e.off = 0;
+    e.lg_hw2 = g.lg_hw2; e.lg_w2 = g.lg_w2;
 #ifndef MVAE_PAIR_STORE
 #define MVAE_PAIR_STORE 1
 #endif

@@ -457,12 +457,19 @@ struct EpNCHW {
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
     int off;   // per-lane column offset, set by col()
+    int lg_hw2 = -1, lg_w2 = -1;   // log2(H2 * W2), log2(W2) when both are powers of two (host), else -1: col() shifts instead of dividing
     __device__ void set_class(int cls) { if (sy > 1) { py = cls / sy; px = cls % sy; } }
     __device__ bool col(int j) {
         if (j >= J) return false;
-        const int hw2 = H2 * W2;
-        const int n = j / hw2, rem = j - n * hw2;
-        const int r = rem / W2, c = rem - r * W2;
+        int n, rem, r, c;
+        if (lg_w2 >= 0) {           // block-uniform
+            n = j >> lg_hw2; rem = j & ((1 << lg_hw2) - 1);
+            r = rem >> lg_w2; c = rem & ((1 << lg_w2) - 1);
+        } else {
+            const int hw2 = H2 * W2;
+            n = j / hw2; rem = j - n * hw2;
+            r = rem / W2; c = rem - r * W2;
+        }
         off = n * C * HW + (r * sy + py) * Wfull + c * sy + px;
         return true;
     }
