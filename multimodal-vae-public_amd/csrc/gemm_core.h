@@ -44,6 +44,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_INTERLEAVE
 #define MVAE_INTERLEAVE 1       // 1: next-tile loads / stores sliced into the MFMA groups' shadows (see igemm_kernel)
 #endif
+#ifndef MVAE_ASM_STORE
+#define MVAE_ASM_STORE 1        // NCHW epilogue stores issued through inline asm (see store_f32_untracked); 0: plain stores (A/B builds)
+#endif
+#ifndef MVAE_KO_EPI
+#define MVAE_KO_EPI 0           // knock-out experiment (results are wrong): 1 = the conv / Linear epilogues store nothing
+#endif
 #ifndef MVAE_KO
 #define MVAE_KO 0               // knock-out experiments on the interleaved loop (results are wrong): 1 no global loads,
 #endif                          // 2 + no LDS stores, 3 + no barrier, 4 + no fragment reads (MFMAs only)
@@ -345,6 +351,7 @@ struct EpRowMajor {
     }
     __device__ bool col(int j) const { return j < J; }
     __device__ void put(int i, int j, float v) const {
+        if (MVAE_KO_EPI) return;
         if (i >= I) return;
         if (bias) v += bias[j];
         float m = 1.f;
@@ -431,6 +438,33 @@ struct EpRowCe {
     }
 };
 
+// ---- stores the compiler's wait-count bookkeeping does not see ----
+// gfx950 is a gfx9 core: vector loads AND stores share ONE counter (vmcnt), and LLVM, seeing both kinds pending, can no
+// longer wait for "the oldest n loads" -- every wait behind a store becomes s_waitcnt vmcnt(0).  In a multi-item block
+// the epilogue stores of item w are followed by the k-steps of item w + 1, whose tile loads were issued two tiles ahead:
+// the first wait behind the stores then drains EVERYTHING (the prefetched tiles and the stores' L2 acknowledgements).
+// Knock-out build (profiles/r04_conv_knockout.txt): the 32-row transposed conv runs 50.7 us without its stores -- the
+// MFMA floor -- and 90.3 us with them, for 67 MB.  Issued through inline asm the stores stay out of that bookkeeping;
+// the hardware counter still includes them, so a compiler-computed vmcnt(n) can only wait longer than needed, never
+// shorter (loads retire in order among themselves), nothing in the kernel reads what they write, and a wave's stores
+// complete before its termination is signalled.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_f32_untracked(float *p, float v) {
+#if MVAE_ASM_STORE
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void store_f32x2_untracked(float *p, float a, float b) {
+#if MVAE_ASM_STORE
+    f32x2 v; v.x = a; v.y = b;
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v));
+#else
+    *reinterpret_cast<float2 *>(p) = make_float2(a, b);
+#endif
+}
+
 // NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
@@ -445,14 +479,14 @@ struct EpNCHW {
     int pair = 0;                             // host-side choice between the two types
     __device__ bool pair_ok() const { return pair != 0; }
     __device__ void put2(int i, float v0, float v1) const {      // off was computed for px = 0
-        if (i >= C) return;
+        if (MVAE_KO_EPI || i >= C) return;
         const int idx = off + i * HW;
         if (dpre) {
             const float2 d = *reinterpret_cast<const float2 *>(dpre + idx);
             v0 *= swish_grad_(d.x); v1 *= swish_grad_(d.y);
         }
-        if (out) *reinterpret_cast<float2 *>(out + idx) = make_float2(v0, v1);
-        if (act) *reinterpret_cast<float2 *>(act + idx) = make_float2(swishf_(v0), swishf_(v1));
+        if (out) store_f32x2_untracked(out + idx, v0, v1);
+        if (act) store_f32x2_untracked(act + idx, swishf_(v0), swishf_(v1));
     }
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
@@ -474,11 +508,11 @@ struct EpNCHW {
         return true;
     }
     __device__ void put(int i, int, float v) const {
-        if (i >= C) return;
+        if (MVAE_KO_EPI || i >= C) return;
         const int idx = off + i * HW;
         if (dpre) v *= swish_grad_(dpre[idx]);
-        if (out) out[idx] = v;
-        if (act) act[idx] = swishf_(v);
+        if (out) store_f32_untracked(out + idx, v);
+        if (act) store_f32_untracked(act + idx, swishf_(v));
     }
 };
 
