@@ -44,9 +44,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_INTERLEAVE
 #define MVAE_INTERLEAVE 1       // 1: next-tile loads / stores sliced into the MFMA groups' shadows (see igemm_kernel)
 #endif
-#ifndef MVAE_ASM_STORE
-#define MVAE_ASM_STORE 1        // NCHW epilogue stores issued through inline asm (see store_f32_untracked); 0: plain stores (A/B builds)
-#endif
 #ifndef MVAE_KO_EPI
 #define MVAE_KO_EPI 0           // knock-out experiment (results are wrong): 1 = the conv / Linear epilogues store nothing
 #endif
@@ -438,33 +435,6 @@ struct EpRowCe {
     }
 };
 
-// ---- stores the compiler's wait-count bookkeeping does not see ----
-// gfx950 is a gfx9 core: vector loads AND stores share ONE counter (vmcnt), and LLVM, seeing both kinds pending, can no
-// longer wait for "the oldest n loads" -- every wait behind a store becomes s_waitcnt vmcnt(0).  In a multi-item block
-// the epilogue stores of item w are followed by the k-steps of item w + 1, whose tile loads were issued two tiles ahead:
-// the first wait behind the stores then drains EVERYTHING (the prefetched tiles and the stores' L2 acknowledgements).
-// Knock-out build (profiles/r04_conv_knockout.txt): the 32-row transposed conv runs 50.7 us without its stores -- the
-// MFMA floor -- and 90.3 us with them, for 67 MB.  Issued through inline asm the stores stay out of that bookkeeping;
-// the hardware counter still includes them, so a compiler-computed vmcnt(n) can only wait longer than needed, never
-// shorter (loads retire in order among themselves), nothing in the kernel reads what they write, and a wave's stores
-// complete before its termination is signalled.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_f32_untracked(float *p, float v) {
-#if MVAE_ASM_STORE
-    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v));
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ void store_f32x2_untracked(float *p, float a, float b) {
-#if MVAE_ASM_STORE
-    f32x2 v; v.x = a; v.y = b;
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v));
-#else
-    *reinterpret_cast<float2 *>(p) = make_float2(a, b);
-#endif
-}
-
 // NCHW destination: i = channel, j = (n, row', col') of a (possibly strided) sub-lattice:
 // address = (n * C + i) * HW + (row' * s + py) * Wfull + col' * s + px.
 struct EpNCHW {
@@ -485,8 +455,8 @@ struct EpNCHW {
             const float2 d = *reinterpret_cast<const float2 *>(dpre + idx);
             v0 *= swish_grad_(d.x); v1 *= swish_grad_(d.y);
         }
-        if (out) store_f32x2_untracked(out + idx, v0, v1);
-        if (act) store_f32x2_untracked(act + idx, swishf_(v0), swishf_(v1));
+        if (out) *reinterpret_cast<float2 *>(out + idx) = make_float2(v0, v1);
+        if (act) *reinterpret_cast<float2 *>(act + idx) = make_float2(swishf_(v0), swishf_(v1));
     }
     float *out; float *act; const float *dpre;
     int C, HW, Wfull, H2, W2, sy, py, px, J;
@@ -511,8 +481,8 @@ struct EpNCHW {
         if (MVAE_KO_EPI || i >= C) return;
         const int idx = off + i * HW;
         if (dpre) v *= swish_grad_(dpre[idx]);
-        if (out) store_f32_untracked(out + idx, v);
-        if (act) store_f32_untracked(act + idx, swishf_(v));
+        if (out) out[idx] = v;
+        if (act) act[idx] = swishf_(v);
     }
 };
 
@@ -835,6 +805,11 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             // ... the 32-row (1 x 4 waves) and 64-row (2 x 2 waves) layouts: 146 and 127 VGPRs, same occupancy as without
             constexpr bool PAIRK = E::PAIR && WM * WN == 1 && loader_pairable<Q>::value;
             std::conditional_t<PAIRK, f32x16, char> hold;
+            // (Round 4, measured and not kept -- profiles/r04_conv_knockout.txt: without its stores the 32-row kernel runs AT the
+            //  matrix floor, 50.7 us, with them 90.3 us for 67 MB.  Neither issuing the stores outside the compiler's shared
+            //  load / store wait counter (inline asm: 90.9 vs 90.7 us) nor parking a finished pair and issuing its sixteen
+            //  stores one per MFMA group during the next item's first k-step (16 more registers, an occupancy step: 94.9 vs
+            //  92.0 us) recovers any of it.)
             // statistics-only destination (EpStats; one-tile waves): per-lane sums of v and v^2 over the block's items
             constexpr bool STATK = ep_stats<E>::value && WM * WN == 1;
             std::conditional_t<STATK, f32x16, char> st1, st2;
