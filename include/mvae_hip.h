@@ -101,6 +101,29 @@ typedef struct {
 } mvae_wgrad_item;
 int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_items, mvae_stream_t stream);
 
+/* The same launch, which also runs optimizer.step() (torch.optim.Adam defaults, mnist/train.py:168,219) on the
+ * parameters whose gradients it has just produced: the weight gradients are the last thing loss.backward() computes
+ * for a layer and nothing but the optimizer reads them, so the update rides the gradient's epilogue instead of
+ * waiting for one arena-wide launch behind the whole backward pass (15 us + a join at the very end of a 296-us
+ * MNIST step).  The gradient is still written.  The four arenas are laid out alike: the parameter / moment element
+ * of gradient address g is at the same offset from its base as g is from grad_base.  coef2: the step's two
+ * bias-correction factors, left there by mvae_adam_prepare earlier on a stream this one is ordered behind.
+ * MVAE_ACCUMULATE is refused (the update needs the step's whole gradient; the CALLER guarantees that no other
+ * launch of the step adds to these gradients or reads these parameters afterwards).  An item with dy == x == NULL
+ * is a finished gradient of K elements at dw (written earlier on this stream, e.g. an Embedding's): it only takes
+ * the update.  Same arithmetic, bit for bit, as mvae_linear_wgrad_batched followed by mvae_adam_apply_at. */
+typedef struct {
+    const float *grad_base;         /* gradient arena */
+    float *param_base;              /* parameter arena */
+    float *exp_avg_base;            /* first / second moment arenas */
+    float *exp_avg_sq_base;
+    const float *coef2;             /* device: { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) } (mvae_adam_prepare) */
+    double beta1, beta2, eps;
+    float grad_scale;               /* gradients are multiplied by this first (1 / world size; 1 here) */
+} mvae_adam_fuse;
+int mvae_linear_wgrad_batched_adam(const mvae_wgrad_item *items, int n_items, const mvae_adam_fuse *adam,
+                                   mvae_stream_t stream);
+
 /* Grouped forms: G independent Linear problems of ONE shape in one launch.  celeba19 builds 18
  * identical attribute encoders / decoders (celeba19/model.py:29-30, 173-196) and the reference runs
  * them one after another (celeba19/model.py:78-81, 53-54); here operand g of every array is at
@@ -413,6 +436,12 @@ int mvae_adam_apply(float *param, const float *grad, float *exp_avg, float *exp_
 int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                        size_t n, double lr, double beta1, double beta2, double eps, float grad_scale,
                        const int64_t *step_dev, int64_t step_add, mvae_stream_t stream);
+/* *step_dev += delta, then coef2[0..1] = { lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) } at t = the new counter value:
+ * the counter launch of a step whose weight-gradient launches apply Adam themselves
+ * (mvae_linear_wgrad_batched_adam); a later mvae_adam_apply_at(..., step_add = 0) on the rest of the arena computes
+ * the same two factors from the counter. */
+int mvae_adam_prepare(int64_t *step_dev, int64_t delta, double lr, double beta1, double beta2, float *coef2,
+                      mvae_stream_t stream);
 int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
 
 /* Measurement aid (no reference counterpart): an EMPTY kernel on `stream`.  A profiling host launches one in front of

@@ -47,6 +47,12 @@ class WgradItem(ctypes.Structure):          # mvae_wgrad_item
 WGRAD_BATCH_MAX = 16
 
 
+class AdamFuse(ctypes.Structure):           # mvae_adam_fuse
+    _fields_ = [('grad_base', c_void_p), ('param_base', c_void_p), ('exp_avg_base', c_void_p),
+                ('exp_avg_sq_base', c_void_p), ('coef2', c_void_p), ('beta1', ctypes.c_double),
+                ('beta2', ctypes.c_double), ('eps', ctypes.c_double), ('grad_scale', ctypes.c_float)]
+
+
 class RepackItem(ctypes.Structure):         # mvae_repack_item
     _fields_ = [('w', c_void_p), ('wr', c_void_p), ('transposed', c_int), ('Cin', c_int), ('Cout', c_int),
                 ('stride', c_int), ('pad', c_int)]
@@ -120,6 +126,8 @@ _SIGNATURES = {
     'mvae_convT2d_k4_fwd_stats': (c_int, [P, P, P, c_size_t] + [c_int] * 7 + [P, c_size_t, P]),
     'mvae_bn_stats_merge': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, c_float, c_float, c_int, P, P]),
     'mvae_linear_wgrad_batched': (c_int, [ctypes.POINTER(WgradItem), c_int, P]),
+    'mvae_linear_wgrad_batched_adam': (c_int, [ctypes.POINTER(WgradItem), c_int, ctypes.POINTER(AdamFuse), P]),
+    'mvae_adam_prepare': (c_int, [P, ctypes.c_int64, c_double, c_double, c_double, P, P]),
     'mvae_elbo_reduce': (c_int, [ctypes.POINTER(ElboPart), c_int, P, c_int, P, c_size_t, P, c_uint64, P]),
     'mvae_philox_fill': (c_int, [P, c_size_t, c_int, c_float, c_uint64, P, c_uint64, P]),
     'mvae_randn': (c_int, [P, c_size_t, c_uint64, P, P]),
@@ -199,7 +207,7 @@ def lib():
             if fn is not None:
                 fn.restype = res
                 fn.argtypes = args
-        if handle.mvae_abi_version() != 3:
+        if handle.mvae_abi_version() != 4:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle
     return _lib

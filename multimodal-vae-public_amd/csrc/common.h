@@ -61,6 +61,33 @@ __device__ __forceinline__ float bce_grad(float x, float t) {
     return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e / (1.0f + e));
 }
 
+// One element of torch.optim.Adam (defaults: no weight decay, no amsgrad; mnist/train.py:168,219), shared by the
+// arena-wide launch (misc.hip) and by the weight-gradient kernels that update their own outputs (linear_direct.h),
+// so that both round identically:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+// p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps),  step_size = lr / (1 - b1^t),  inv_sqrt_bc2 = 1 / sqrt(1 - b2^t)
+struct AdamCoef { float b1, b2, omb1, omb2, eps, gscale, step_size, inv_sqrt_bc2; };
+__device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, const AdamCoef &c) {
+#pragma clang fp contract(off)      // only the fused multiply-adds written here, wherever this is inlined
+    const float gg = g * c.gscale;
+    m = __builtin_fmaf(c.b1, m, c.omb1 * gg);
+    v = __builtin_fmaf(c.b2, v, c.omb2 * gg * gg);
+    p -= c.step_size * (m / __builtin_fmaf(sqrtf(v), c.inv_sqrt_bc2, c.eps));
+}
+// hyper-parameters arrive as doubles and are rounded the way torch rounds python floats into fp32 tensor ops:
+// beta and (1 - beta) separately (1 - 0.999 != 1 - float(0.999))
+__device__ __forceinline__ AdamCoef adam_coef(double b1d, double b2d, double epsd, float gscale) {
+    AdamCoef c;
+    c.b1 = (float)b1d; c.b2 = (float)b2d; c.eps = (float)epsd; c.gscale = gscale;
+    c.omb1 = (float)(1.0 - b1d); c.omb2 = (float)(1.0 - b2d);
+    c.step_size = 0.f; c.inv_sqrt_bc2 = 0.f;
+    return c;
+}
+__device__ __forceinline__ void adam_bias_corrections(double lr, double b1d, double b2d, double t, float *step_size,
+                                                      float *inv_sqrt_bc2) {
+    *step_size = (float)(lr / (1.0 - pow(b1d, t)));
+    *inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(b2d, t)));
+}
+
 // Block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS.
 // Every thread receives the total.
 __device__ __forceinline__ float block_sum(float v, float *red) {

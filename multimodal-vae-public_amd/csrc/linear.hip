@@ -11,7 +11,7 @@
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-MVAE_EXPORT int mvae_abi_version(void) { return 3; }
+MVAE_EXPORT int mvae_abi_version(void) { return 4; }
 
 #ifdef MVAE_TUNING
 // tuning build only (libmvae_hip_tuning.so): force tile shapes / split counts for tools/gemm_bench.py
@@ -142,18 +142,28 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
                : launch_igemm<LdRowsMNS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, N, K, M, sink, st);
 }
 
-MVAE_EXPORT int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_items, mvae_stream_t stream) {
+// items -> the kernel's table; with `adam`: no accumulation, and items without dy / x are finished gradients of J = K
+// elements that only take the update
+static int wgrad_batch_table(const mvae_wgrad_item *items, int n_items, bool adam, WgradBatchArgs &a) {
     if (n_items < 1 || n_items > WGRAD_BATCH_MAX || !items) return MVAE_ERR_ARG;
-    WgradBatchArgs a;
     a.n = n_items;
     int tiles = 0;
     for (int q = 0; q < n_items; ++q) {
         const mvae_wgrad_item &s = items[q];
-        if (!s.dy || !s.x || !s.dw || s.M < 1 || s.N < 1 || s.K < 1 || s.lddy < s.N || s.ldx < s.K) return MVAE_ERR_ARG;
-        if (!wgrad_batch_item_ok(s.N, s.K, s.M, s.lddy, s.ldx)) return MVAE_ERR_ARG;
+        WgradBatchItem &w = a.it[q];
         for (int r = 0; r < q; ++r)
             if (items[r].dw == s.dw || (s.db && items[r].db == s.db)) return MVAE_ERR_ARG;   // one writer per gradient
-        WgradBatchItem &w = a.it[q];
+        if (adam && !s.dy && !s.x) {
+            if (!s.dw || s.db || s.K < 1 || s.flags) return MVAE_ERR_ARG;
+            w.dy = w.x = nullptr; w.dw = s.dw; w.db = nullptr;
+            w.lddy = w.ldx = w.M = w.I = 0; w.J = s.K; w.accumulate = 0; w.tiles_j = 1;
+            tiles += cdiv(s.K, ADAM_ONLY_TILE);
+            w.tile_end = tiles;
+            continue;
+        }
+        if (!s.dy || !s.x || !s.dw || s.M < 1 || s.N < 1 || s.K < 1 || s.lddy < s.N || s.ldx < s.K) return MVAE_ERR_ARG;
+        if (!wgrad_batch_item_ok(s.N, s.K, s.M, s.lddy, s.ldx)) return MVAE_ERR_ARG;
+        if (adam && (s.flags & MVAE_ACCUMULATE)) return MVAE_ERR_ARG;      // the update needs the step's WHOLE gradient
         w.dy = s.dy; w.x = s.x; w.dw = s.dw; w.db = s.db;
         w.lddy = s.lddy; w.ldx = s.ldx; w.M = s.M; w.I = s.N; w.J = s.K;
         w.accumulate = (s.flags & MVAE_ACCUMULATE) ? 1 : 0;
@@ -161,7 +171,35 @@ MVAE_EXPORT int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_it
         tiles += cdiv(s.N, 32) * w.tiles_j;
         w.tile_end = tiles;
     }
-    return wgrad_batched_launch(a, (hipStream_t)stream);
+    return MVAE_OK;
+}
+
+MVAE_EXPORT int mvae_linear_wgrad_batched(const mvae_wgrad_item *items, int n_items, mvae_stream_t stream) {
+    WgradBatchArgs a;
+    const int rc = wgrad_batch_table(items, n_items, false, a);
+    return rc != MVAE_OK ? rc : wgrad_batched_launch(a, (hipStream_t)stream);
+}
+
+MVAE_EXPORT int mvae_linear_wgrad_batched_adam(const mvae_wgrad_item *items, int n_items, const mvae_adam_fuse *adam,
+                                               mvae_stream_t stream) {
+    if (!adam || !adam->grad_base || !adam->param_base || !adam->exp_avg_base || !adam->exp_avg_sq_base || !adam->coef2)
+        return MVAE_ERR_ARG;
+    WgradBatchArgs a;
+    const int rc = wgrad_batch_table(items, n_items, true, a);
+    if (rc != MVAE_OK) return rc;
+    for (int q = 0; q < n_items; ++q) {      // 32-bit element offsets from the arena bases inside the kernel
+        const size_t n = items[q].dy ? (size_t)items[q].N * items[q].K : (size_t)items[q].K;
+        if (items[q].dw < adam->grad_base || (size_t)(items[q].dw - adam->grad_base) + n >= ((size_t)1 << 32)) return MVAE_ERR_ARG;
+        if (items[q].db && (items[q].db < adam->grad_base || (size_t)(items[q].db - adam->grad_base) + items[q].N >= ((size_t)1 << 32)))
+            return MVAE_ERR_ARG;
+    }
+    AdamFuse f;
+    f.grad_base = adam->grad_base; f.param = adam->param_base; f.m = adam->exp_avg_base; f.v = adam->exp_avg_sq_base;
+    f.coef = adam->coef2;
+    // rounded as mvae_adam_apply rounds them (beta and 1 - beta separately)
+    f.b1 = (float)adam->beta1; f.b2 = (float)adam->beta2; f.eps = (float)adam->eps; f.gscale = adam->grad_scale;
+    f.omb1 = (float)(1.0 - adam->beta1); f.omb2 = (float)(1.0 - adam->beta2);
+    return wgrad_batched_launch(a, (hipStream_t)stream, &f);
 }
 
 static const LinGroups kOneGroup = {1, 0, 0, 0, 0};

@@ -24,12 +24,32 @@ namespace {
 #endif
 constexpr int WD_PD = 4;      // chunks (of 8 reduction rows) in flight per wave: 2 x 16 VGPRs
 
+// A weight-gradient launch that ALSO applies Adam to the parameters whose gradients it just produced
+// (mvae_linear_wgrad_batched_adam): the gradient arena, the parameter arena and the two moment arenas are laid out
+// alike, so the element behind gradient address g is at the same offset from each base.  `coef` = the two
+// bias-correction factors of this step (mvae_adam_prepare).
+struct AdamFuse {
+    const float *grad_base; float *param, *m, *v; const float *coef;
+    float b1, b2, omb1, omb2, eps, gscale;
+    __device__ AdamCoef load() const {
+        AdamCoef c;
+        c.b1 = b1; c.b2 = b2; c.omb1 = omb1; c.omb2 = omb2; c.eps = eps; c.gscale = gscale;
+        c.step_size = coef[0]; c.inv_sqrt_bc2 = coef[1];
+        return c;
+    }
+    __device__ void update(const float *gptr, float g, const AdamCoef &c) const {
+        const size_t off = (size_t)(gptr - grad_base);
+        adam_one(param[off], m[off], v[off], g, c);
+    }
+};
+
 // MODE (tuning build only: mvae_debug_set_knockout): 0 = the kernel; 1 = loads without the MFMAs; 2 = MFMAs
 // without the loads -- where the time of a launch goes.
-template <bool ROWSUM, int KW, int MODE = 0>
+template <bool ROWSUM, int KW, int MODE = 0, bool ADAM = false>
 __device__ __forceinline__ void wgrad_direct_tile(const float *dy, int lddy, const float *x, int ldx,
                                                   const EpRowMajor &e, int I, int J, int M, float *db,
-                                                  int db_accumulate, int tile_i, int tile_j) {
+                                                  int db_accumulate, int tile_i, int tile_j,
+                                                  const AdamFuse *af = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float wd_lds[];
     const int t = threadIdx.x, lane = t & 63, kg = t >> 6;
     const int lcol = lane & 31, lrow = lane >> 5;
@@ -41,6 +61,24 @@ __device__ __forceinline__ void wgrad_direct_tile(const float *dy, int lddy, con
     const char *dyb = reinterpret_cast<const char *>(dy), *xb = reinterpret_cast<const char *>(x);
     const int full = M >> 3;                        // chunks of 8 reduction rows entirely inside the batch
 
+    // ADAM: the parameter and the two moments of the outputs this thread will finish in the epilogue are fetched NOW
+    // and arrive behind the whole reduction -- fetched in the epilogue, every block ended with a dependent
+    // load -> compute -> store round trip to HBM (MNIST step +3 % against the arena-wide launch; +1.9 % this way:
+    // profiles/r04_fuse_adam_ab.txt -- the form stays an option, the engines do not use it by default).
+    constexpr int NE = 1024 / (64 * KW);            // epilogue elements per thread
+    float ap[NE], am[NE], av2[NE];
+    unsigned aoff[NE];                              // arena element index (the arenas are far below 2^32 elements: host)
+    if (ADAM) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int el = t + k * 64 * KW, i = i0 + (el >> 5), j = j0 + (el & 31);
+            const bool ok = i < I && j < J;
+            aoff[k] = ok ? (unsigned)(e.out - af->grad_base) + (unsigned)i * (unsigned)e.ld + (unsigned)j : ~0u;
+            ap[k] = ok ? af->param[aoff[k]] : 0.f;
+            am[k] = ok ? af->m[aoff[k]] : 0.f;
+            av2[k] = ok ? af->v[aoff[k]] : 0.f;
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -115,12 +153,23 @@ __device__ __forceinline__ void wgrad_direct_tile(const float *dy, int lddy, con
     float *rsl = wd_lds + KW * (32 * TP);           // [KW][2][32] partial row sums
     if (ROWSUM) rsl[(kg * 2 + lrow) * 32 + lcol] = rs;
     __syncthreads();
-    for (int el = t; el < 32 * 32; el += 64 * KW) {
+    AdamCoef ac;
+    if (ADAM) ac = af->load();
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int el = t + k * 64 * KW;
         const int il = el >> 5, jl = el & 31;
         float v = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < KW; ++g2) v += wd_lds[g2 * (32 * TP) + il * TP + jl];
-        if (e.col(j0 + jl)) e.put(i0 + il, j0 + jl, v);
+        if (e.col(j0 + jl)) {
+            e.put(i0 + il, j0 + jl, v);
+            // ADAM launches never accumulate (host): v IS the gradient the put just stored
+            if (ADAM && aoff[k] != ~0u) {
+                adam_one(ap[k], am[k], av2[k], v, ac);
+                af->param[aoff[k]] = ap[k]; af->m[aoff[k]] = am[k]; af->v[aoff[k]] = av2[k];
+            }
+        }
     }
     if (ROWSUM) {
         if (tile_j == 0 && t < 32 && i0 + t < I) {
@@ -129,6 +178,7 @@ __device__ __forceinline__ void wgrad_direct_tile(const float *dy, int lddy, con
             for (int g2 = 0; g2 < 2 * KW; ++g2) s += rsl[g2 * 32 + t];
             if (db_accumulate) s += db[i0 + t];
             db[i0 + t] = s;
+            if (ADAM) af->update(db + i0 + t, s, ac);
         }
     }
 }
@@ -153,9 +203,25 @@ struct WgradBatchItem {
     int tiles_j, tile_end;          // tiles along J; first tile index AFTER this problem in the launch
 };
 struct WgradBatchArgs { WgradBatchItem it[WGRAD_BATCH_MAX]; int n; };
+// ... with Adam on the outputs (mvae_linear_wgrad_batched_adam).  An item with dy == nullptr is a gradient that is
+// already final -- J elements at dw, written by an earlier launch of the stream (an Embedding's weight gradient):
+// its tiles of 1024 elements only run the update, so that no parameter of the chain is left for a launch behind it.
+struct WgradBatchAdamArgs { WgradBatchArgs w; AdamFuse adam; };
+constexpr int ADAM_ONLY_TILE = 1024;
+
+template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(const WgradBatchArgs &a, const AdamFuse *af);
 
 template <int KW>
 __global__ __launch_bounds__(64 * KW) void wgrad_batched_kernel(WgradBatchArgs a) {
+    wgrad_batched_body<KW, false>(a, nullptr);
+}
+template <int KW>
+__global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(4, 4)))      // as resident as the plain batch
+void wgrad_batched_adam_kernel(WgradBatchAdamArgs a) {
+    wgrad_batched_body<KW, true>(a.w, &a.adam);
+}
+
+template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(const WgradBatchArgs &a, const AdamFuse *af) {
     int p = 0, first = 0;
     const int tile = blockIdx.x;
 #pragma unroll 1
@@ -164,12 +230,20 @@ __global__ __launch_bounds__(64 * KW) void wgrad_batched_kernel(WgradBatchArgs a
     }
     const WgradBatchItem &w = a.it[p];
     const int local = tile - first;
+    if (ADAM && w.dy == nullptr) {
+        const AdamCoef ac = af->load();
+        for (int el = threadIdx.x; el < ADAM_ONLY_TILE; el += 64 * KW) {
+            const int idx = local * ADAM_ONLY_TILE + el;
+            if (idx < w.J) af->update(w.dw + idx, w.dw[idx], ac);
+        }
+        return;
+    }
     const int tile_i = local / w.tiles_j, tile_j = local - tile_i * w.tiles_j;
     EpRowMajor e;
     e.out = w.dw; e.act = nullptr; e.ld = w.J; e.bias = nullptr; e.dpre = nullptr; e.ldp = 0;
     e.mask = nullptr; e.ldm = 0; e.mask_scale = 1.f; e.I = w.I; e.J = w.J; e.accumulate = w.accumulate;
-    if (w.db) wgrad_direct_tile<true, KW>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, w.db, w.accumulate, tile_i, tile_j);
-    else wgrad_direct_tile<false, KW>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, nullptr, 0, tile_i, tile_j);
+    if (w.db) wgrad_direct_tile<true, KW, 0, ADAM>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, w.db, w.accumulate, tile_i, tile_j, af);
+    else wgrad_direct_tile<false, KW, 0, ADAM>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, nullptr, 0, tile_i, tile_j, af);
 }
 
 // shapes the direct tile code serves well on its own merits (32-bit byte offsets inside the operands included)
@@ -178,7 +252,7 @@ inline bool wgrad_batch_item_ok(int I, int J, int M, int lddy, int ldx) {
     return tiles <= 2048 && M <= 4096 && (long)M * lddy * 4 < (1L << 32) && (long)M * ldx * 4 < (1L << 32);
 }
 
-inline int wgrad_batched_launch(WgradBatchArgs &a, hipStream_t st) {
+inline int wgrad_batched_launch(WgradBatchArgs &a, hipStream_t st, const AdamFuse *adam = nullptr) {
     const int total = a.it[a.n - 1].tile_end;
     // waves per tile: enough blocks x waves to put ~4 waves on every SIMD, a reduction slice of >= 4 chunks each
     const int kw = total >= 768 ? 4 : (total >= 256 ? 8 : 16);
@@ -191,7 +265,18 @@ inline int wgrad_batched_launch(WgradBatchArgs &a, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
             attr_done = true;                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL(wgrad_batched_kernel<KWV>, dim3(total), dim3(64 * KWV), lds, st, a);               \
+        static bool attr_done_adam = false;                                                                   \
+        if (adam && !attr_done_adam) {                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_batched_adam_kernel<KWV>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+            attr_done_adam = true;                                                                            \
+        }                                                                                                     \
+        if (adam) {                                                                                           \
+            WgradBatchAdamArgs aa;                                                                            \
+            aa.w = a; aa.adam = *adam;                                                                        \
+            hipLaunchKernelGGL(wgrad_batched_adam_kernel<KWV>, dim3(total), dim3(64 * KWV), lds, st, aa);     \
+        } else                                                                                                \
+            hipLaunchKernelGGL(wgrad_batched_kernel<KWV>, dim3(total), dim3(64 * KWV), lds, st, a);           \
     }
     if (kw == 4) MVAE_WB(4) else if (kw == 8) MVAE_WB(8) else MVAE_WB(16)
 #undef MVAE_WB

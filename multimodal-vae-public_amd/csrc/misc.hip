@@ -131,13 +131,8 @@ __global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
                                                    double lr, double b1d, double b2d, double epsd, float gscale,
                                                    const int64_t *step_dev, int64_t step_add) {
-    // hyper-parameters arrive as doubles and are rounded the way torch rounds python floats into
-    // fp32 tensor ops: beta and (1 - beta) separately (1 - 0.999 != 1 - float(0.999))
-    const float b1 = (float)b1d, b2 = (float)b2d, eps = (float)epsd;
-    const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    const double t = (double)(*step_dev + step_add);
-    const float step_size = (float)(lr / (1.0 - pow(b1d, t)));
-    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(b2d, t)));
+    AdamCoef c = adam_coef(b1d, b2d, epsd, gscale);
+    adam_bias_corrections(lr, b1d, b2d, (double)(*step_dev + step_add), &c.step_size, &c.inv_sqrt_bc2);
     const size_t n4 = n / 4;
     const bool vec = aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v);
     if (vec) {
@@ -146,28 +141,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
             const float4 gv = reinterpret_cast<const float4 *>(g)[i];
             float4 mv = reinterpret_cast<float4 *>(m)[i];
             float4 vv = reinterpret_cast<float4 *>(v)[i];
-#define MVAE_ADAM1(c)                                                       \
-    {                                                                       \
-        const float gg = gv.c * gscale;                                     \
-        mv.c = b1 * mv.c + omb1 * gg;                                 \
-        vv.c = b2 * vv.c + omb2 * gg * gg;                            \
-        pv.c -= step_size * (mv.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));    \
-    }
-            MVAE_ADAM1(x) MVAE_ADAM1(y) MVAE_ADAM1(z) MVAE_ADAM1(w)
-#undef MVAE_ADAM1
+            adam_one(pv.x, mv.x, vv.x, gv.x, c); adam_one(pv.y, mv.y, vv.y, gv.y, c);
+            adam_one(pv.z, mv.z, vv.z, gv.z, c); adam_one(pv.w, mv.w, vv.w, gv.w, c);
             reinterpret_cast<float4 *>(p)[i] = pv;
             reinterpret_cast<float4 *>(m)[i] = mv;
             reinterpret_cast<float4 *>(v)[i] = vv;
         }
     }
     const size_t tail0 = vec ? n4 * 4 : 0;
-    for (size_t i = tail0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gg = g[i] * gscale;
-        const float mi = b1 * m[i] + omb1 * gg;
-        const float vi = b2 * v[i] + omb2 * gg * gg;
-        m[i] = mi; v[i] = vi;
-        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-    }
+    for (size_t i = tail0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        adam_one(p[i], m[i], v[i], g[i], c);
+}
+
+// The step counter advanced by `delta` and the two bias-correction factors of step t = the NEW counter value left in
+// coef[0..1] (step_size, inv_sqrt_bc2): what a weight-gradient launch that applies Adam to its own outputs reads
+// (mvae_linear_wgrad_batched_adam).  One thread, early in the step, off the critical chain.
+__global__ void adam_prepare_kernel(int64_t *step, int64_t delta, double lr, double b1d, double b2d, float *coef) {
+    *step += delta;
+    adam_bias_corrections(lr, b1d, b2d, (double)*step, coef, coef + 1);
 }
 
 __global__ void bump_i64_kernel(int64_t *step) { *step += 1; }
@@ -329,6 +320,14 @@ __global__ void trace_marker_kernel(int tag) { (void)tag; }
 
 MVAE_EXPORT int mvae_trace_marker(int tag, mvae_stream_t stream) {
     hipLaunchKernelGGL(trace_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, tag);
+    return mvae_launch_status();
+}
+
+MVAE_EXPORT int mvae_adam_prepare(int64_t *step_dev, int64_t delta, double lr, double beta1, double beta2,
+                                  float *coef2, mvae_stream_t stream) {
+    if (!step_dev || !coef2) return MVAE_ERR_ARG;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, delta, lr, beta1, beta2,
+                       coef2);
     return mvae_launch_status();
 }
 

@@ -187,6 +187,10 @@ class _StepBase(object):
         self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else self.wg_main
         self._wg_pending = []
         self._forked = False
+        # single-GPU captured step: the Linear weight-gradient batches apply Adam to their own outputs (see
+        # _single_gpu_step); set per model family by the subclass, None while no such step is being issued
+        self.fuse_adam = False
+        self._fusion = None
 
     @contextlib.contextmanager
     def _branch(self, after=None):
@@ -219,7 +223,7 @@ class _StepBase(object):
         done (MVAE_BATCH_WGRAD=0: inline, one launch per layer)."""
         if self.wg_main is not None:
             return []
-        return L.WgradBatch() if self.batch_wgrad else None
+        return L.WgradBatch(adam=self._fusion) if self.batch_wgrad else None
 
     def _launch_deferred(self, fns, stream):
         """Run the queued weight-gradient launches on ``stream``, ordered after everything the
@@ -374,20 +378,30 @@ class _StepBase(object):
     def _single_gpu_step(self, optimizer):
         """The captured single-GPU step.  With the fused optimizer the step counter is advanced on the side stream behind
         the label / attribute encoders' forward -- the shorter encoder branch; a one-thread launch, nothing waits for it -- and the update at the end of the chain
-        is ONE launch at t = counter (MVAE_EARLY_COUNTER=0: update + counter launch at the end)."""
+        is ONE launch at t = counter (MVAE_EARLY_COUNTER=0: update + counter launch at the end).
+        ``fuse_adam`` (MVAE_FUSE_ADAM=1, off -- measured slower, see BimodalStep): the weight-gradient batches update their
+        own parameters (layers.WgradBatch(adam=...)), the counter launch also leaves the step's bias corrections for them,
+        and what remains for the end of the chain is Adam over the ranges no batch covered -- on MNIST none."""
         early = (os.environ.get('MVAE_EARLY_COUNTER', '1') != '0' and self.side is not None
                  and hasattr(optimizer, 'step_counted'))
         self._adam_counter = optimizer.step_counter() if early else None
+        fuse = (early and self.fuse_adam and self.batch_wgrad and self.wg_main is None
+                and hasattr(optimizer, 'fusion') and optimizer.grad_scale == 1.0)
+        self._fusion = optimizer.fusion() if fuse else None
+        if self._fusion is not None:
+            self._fusion.begin()
+            self._adam_prepare = lambda: optimizer.prepare_counted(self._fusion)
         try:
             self._body_a()
             self._phase_b('all')
+            if early:
+                optimizer.step_counted(self._fusion) if self._fusion is not None else optimizer.step_counted()
+            else:
+                optimizer.step()
         finally:
             self._step_end()
-        if early:
-            optimizer.step_counted()
-        else:
-            optimizer.step()
-        self._adam_counter = None
+            self._adam_counter = None
+            self._fusion = None
 
     def _dp_step(self, optimizer):
         """One data-parallel step as a plain launch sequence (capturable when the communicator is): bucket k's
@@ -449,7 +463,10 @@ class _StepBase(object):
     def _early_counter(self):
         """Called at the end of the side stream's encoder forward (the shorter of the two encoder branches)."""
         if getattr(self, '_adam_counter', None) is not None:
-            K.counter_add(self._adam_counter, 1)
+            if self._fusion is not None:
+                self._adam_prepare()        # counter + the bias corrections the fused weight-gradient launches read
+            else:
+                K.counter_add(self._adam_counter, 1)
 
     def _body_a(self):
         self.model.zero_grad(set_to_none=True)
@@ -538,7 +555,21 @@ class BimodalStep(_StepBase):
         self.pair_enc = self._pairable_encoder_layers() if os.environ.get('MVAE_PAIR_ENC', '0') == '1' else 0
         # each decoder's backward runs to the latent on its own stream into its own buffer (poe_bwd_split adds
         # them); MVAE_SPLIT_DZ=0: one cleared dz both first layers accumulate into after the join
-        self.split_dz = os.environ.get('MVAE_SPLIT_DZ', '1') != '0' 
+        self.split_dz = os.environ.get('MVAE_SPLIT_DZ', '1') != '0'
+        # MVAE_FUSE_ADAM=1 (tuning aid, off): the Linear weight-gradient batches run optimizer.step() on their own
+        # outputs (_single_gpu_step, mvae_linear_wgrad_batched_adam) and -- on the all-Linear MNIST model -- nothing is
+        # left for a launch at the end of the chain.  Bit-identical parameters (tests), but measured on MI355X
+        # (profiles/r04_fuse_adam_ab.txt, three interleaved rounds): MNIST B=512 0.3042 / 0.3055 / 0.3038 ms fused
+        # against 0.2988 / 0.2990 / 0.2988 with the arena-wide launch -- 1.9 % SLOWER (3 % before the parameter and
+        # moments were prefetched ahead of the reduction); forced on the conv models +0.9 % / +1.3 %.  The arena-wide
+        # launch streams its 28 B / parameter at 5 TB/s in 15 us; the same traffic inside the batches -- which sit in
+        # FRONT of the label encoder's backward on the side stream -- lengthens them by more than the launch it removes.
+        # Sound only where nothing reads a layer's weights after its weight-gradient batch went out: each decoder's
+        # backward must run to the latent inside its own chain (split_dz) and the decoders may not be paired.
+        # MVAE_COUNTER_RIDES=decoder: the step-counter launch on the label DECODER's branch instead of behind the label
+        # encoder's forward -- same A/B: 0.2988 vs 0.2980 ms, nothing.
+        self.counter_rides = os.environ.get('MVAE_COUNTER_RIDES', 'encoder')
+        self.fuse_adam = (os.environ.get('MVAE_FUSE_ADAM', '0') == '1' and self.split_dz and not self.pair_dec)
         # per-term loss coefficients lambda/B, beta/B: pinned host mirror -> device, so a captured
         # graph sees new annealing factors without re-capture
         self.tables = StepTables(3 * self.T, dev)
@@ -622,7 +653,7 @@ class BimodalStep(_StepBase):
         m, B, P, dev, c = self.model, self.B, self.pair_enc, self.dev, self._carry
         pi, pl = m.image_encoder.plan(), m.label_encoder.plan()
         layers, tape_i, tape_l, ni, nl = c['enc_pair']
-        wb = L.WgradBatch()
+        wb = L.WgradBatch(adam=self._fusion)
         g = (g_img, g_lbl)
         keep = [g]
         first_i = [k for k, op in enumerate(pi[:ni]) if op.kind == 'lin'][0]
@@ -820,7 +851,8 @@ class BimodalStep(_StepBase):
         def encode_label(after=None):
             with self._branch(after):
                 heads, c['tape_lbl'] = L.forward_tape(m.label_encoder.plan(), lbl_in, bn_updates=n_up)
-                self._early_counter()
+                if self.counter_rides == 'encoder' or self.pair_dec:
+                    self._early_counter()
             return heads
         paired = self._pair_enc_now()
         fork = None if paired else self._fork_point()
@@ -862,8 +894,8 @@ class BimodalStep(_StepBase):
             def label_branch(after=None):
                 # ---- label branch: decoder forward, reconstruction term + gradient, decoder backward
                 with self._branch(after):
-                    if paired:
-                        self._early_counter()       # no encoder side branch in this mode: the step counter rides this one
+                    if paired or self.counter_rides == 'decoder':
+                        self._early_counter()       # 'paired': no encoder side branch, the step counter rides this one
                     zl = z[l0:l0 + nl].reshape(nl * B, D)
                     lbl_kind = 'class' if m.LABEL_KIND == 'class' else 'bce'
                     rpg_lbl = B

@@ -137,21 +137,34 @@ def wgrad_batchable(dy, x):
             and dy.stride(1) == 1 and x.stride(1) == 1)
 
 
-def linear_wgrad_batched(items):
+def linear_wgrad_batched(items, adam=None):
     """items: [(dy[M,N], x[M,K], dw[N,K], db[N] or None, accumulate)] -- the weight gradients of several Linear
-    layers in ONE launch (mvae_linear_wgrad_batched); more than WGRAD_BATCH_MAX items go out in several."""
+    layers in ONE launch (mvae_linear_wgrad_batched); more than WGRAD_BATCH_MAX items go out in several.
+    ``adam`` (an ``_lib.AdamFuse``, see ``optim.FusedAdam.fuse_record``): the launch also applies Adam to the
+    parameters behind these gradients (mvae_linear_wgrad_batched_adam); an item (None, None, g, None, False) is a
+    finished flat gradient that only takes the update."""
     items = list(items)
     for lo in range(0, len(items), _lib.WGRAD_BATCH_MAX):
         chunk = items[lo:lo + _lib.WGRAD_BATCH_MAX]
         arr = (_lib.WgradItem * len(chunk))()
         for q, (dy, x, dw, db, acc) in enumerate(chunk):
+            if dy is None:
+                if adam is None:
+                    raise RuntimeError('update-only items need adam=')
+                _need_gpu(dw); _f32c(dw)
+                arr[q] = _lib.WgradItem(None, 0, None, 0, _ptr(dw), None, 0, 0, dw.numel(), 0)
+                continue
             _need_gpu(dy, x, dw, db); _f32c(dw, db)
             M, N = dy.shape
             if x.shape[0] != M or tuple(dw.shape) != (N, x.shape[1]):
                 raise RuntimeError('wgrad item %d: shapes %s %s %s' % (q, tuple(dy.shape), tuple(x.shape), tuple(dw.shape)))
             arr[q] = _lib.WgradItem(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), _ptr(db), M, N,
                                     x.shape[1], ACCUMULATE if acc else 0)
-        check(_lib.lib().mvae_linear_wgrad_batched(arr, len(chunk), _stream()), 'mvae_linear_wgrad_batched')
+        if adam is not None:
+            check(_lib.lib().mvae_linear_wgrad_batched_adam(arr, len(chunk), ctypes.byref(adam), _stream()),
+                  'mvae_linear_wgrad_batched_adam')
+        else:
+            check(_lib.lib().mvae_linear_wgrad_batched(arr, len(chunk), _stream()), 'mvae_linear_wgrad_batched')
 
 
 # ---------------------------------------------------------------------------- grouped Linear
@@ -772,6 +785,13 @@ def adam_apply_at(param, grad, exp_avg, exp_avg_sq, step_dev, step_add, lr, beta
     check(_lib.lib().mvae_adam_apply_at(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
                                         lr, beta1, beta2, eps, grad_scale, _ptr(step_dev), int(step_add), _stream()),
           'mvae_adam_apply_at')
+
+
+def adam_prepare(step_dev, delta, lr, beta1, beta2, coef2):
+    """*step_dev += delta; coef2[0:2] = Adam's two bias-correction factors at the new step (mvae_adam_prepare)."""
+    _need_gpu(step_dev, coef2); _f32c(coef2)
+    check(_lib.lib().mvae_adam_prepare(_ptr(step_dev), int(delta), lr, beta1, beta2, _ptr(coef2), _stream()),
+          'mvae_adam_prepare')
 
 
 def trace_marker(tag=0):

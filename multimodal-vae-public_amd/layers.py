@@ -486,6 +486,8 @@ def backward_tape(plan, tape, g, need_input_grad=False, groups=1, input_grad_out
             def emb_wgrad(m=op.mod, idx=saved[0], g=g.contiguous()):
                 dw, acc = grad_target(m.weight)
                 K.embedding_swish_bwd(idx, m.weight.detach(), g, dw, accumulate=acc)
+                if not acc and isinstance(deferred, WgradBatch):
+                    deferred.final_gradient(dw)
             side(emb_wgrad)
             g = None
     return g if need_input_grad else None
@@ -592,14 +594,35 @@ class WgradBatch(list):
     between its launches.  ``flush()`` issues the batch (and any other queued closure) on the current stream;
     the entries keep dy / x alive until then."""
 
+    adam = None      # an ``optim.AdamFusion``: the batch launch also applies Adam to what it computed
+
+    def __init__(self, adam=None):
+        list.__init__(self)
+        self.adam = adam
+        self._final = []
+
     def add_linear(self, op, g, x):
         self.append(('lin', op, g, x))
 
+    def final_gradient(self, grad):
+        """A queued closure reports a gradient it has just written in full (first and only contribution of the
+        step): with ``adam`` its update rides the batch launch too."""
+        if self.adam is not None:
+            self._final.append(grad)
+
     def flush(self):
         items, seen = [], set()
+        adam = self.adam
 
         def issue():
-            if len(items) == 1:
+            fused = adam is not None and items and not any(it[4] for it in items)
+            if fused:
+                for it in items:
+                    adam.cover(it[2])
+                    if it[3] is not None:
+                        adam.cover(it[3])
+                K.linear_wgrad_batched(items, adam=adam.struct)
+            elif len(items) == 1:
                 K.linear_wgrad(*items[0][:4], accumulate=items[0][4])
             elif items:
                 K.linear_wgrad_batched(items)
@@ -619,8 +642,17 @@ class WgradBatch(list):
                 items.append((g, x, dw, db, acc))
             else:
                 K.linear_wgrad(g, x, dw, db, accumulate=acc)
+        if adam is not None and self._final:
+            if any(it[4] for it in items):
+                issue()
+            for grad in self._final:
+                items.append((None, None, grad.reshape(-1), None, False))
+            if not any(it[0] is not None for it in items):
+                # nothing but finished gradients: they are the arena-wide launch's business (rest())
+                del items[:]
         issue()
         del self[:]
+        self._final = []
 
 
 # ----------------------------------------------------------------------------- grouped executor

@@ -13,7 +13,60 @@ Drop-in surface: ``FusedAdam(model.parameters(), lr=...)``, ``zero_grad()``, ``s
 """
 import torch
 
+from . import _lib
 from . import kernels as K
+
+
+class AdamFusion(object):
+    """One step's record of the parameters that weight-gradient launches have already updated themselves
+    (``K.linear_wgrad_batched(items, adam=fusion.struct)``; include/mvae_hip.h: mvae_linear_wgrad_batched_adam).
+    ``cover(grad)`` is called for every gradient tensor handed to such a launch; ``rest()`` is what
+    ``FusedAdam.step_counted(fusion)`` still has to update -- for an all-Linear model (mnist/model.py) nothing:
+    optimizer.step() has then no launch of its own at the end of the backward chain."""
+
+    def __init__(self, opt):
+        arena, g = opt._arena, opt.param_groups[0]
+        self.arena = arena
+        self.coef = torch.zeros(2, dtype=torch.float32, device=arena.flat.device)
+        self.struct = _lib.AdamFuse(arena.grad.data_ptr(), arena.flat.data_ptr(), opt._m.data_ptr(), opt._v.data_ptr(),
+                                    self.coef.data_ptr(), g['betas'][0], g['betas'][1], g['eps'], opt.grad_scale)
+        self._keep = (opt._m, opt._v)        # the struct holds raw addresses
+        self.covered = []
+
+    def begin(self):
+        self.covered = []
+
+    def cover(self, grad):
+        base = self.arena.grad.data_ptr()
+        lo = (grad.data_ptr() - base) // 4
+        hi = lo + grad.numel()
+        if (grad.data_ptr() - base) % 4 or lo < 0 or hi > self.arena.numel or not grad.is_contiguous():
+            raise RuntimeError('a fused update needs a contiguous slice of the gradient arena')
+        for a, b in self.covered:
+            if lo < b and a < hi:
+                raise RuntimeError('arena elements [%d, %d) would be updated twice in one step' % (max(lo, a), min(hi, b)))
+        self.covered.append((lo, hi))
+
+    def rest(self):
+        """Arena ranges (whole parameters, merged) no fused launch has updated this step."""
+        out, cur = [], None
+        for p, o in zip(self.arena.params, self.arena.offsets):
+            n = p.numel()
+            inside = [(a, b) for a, b in self.covered if a < o + n and o < b]
+            if inside:
+                # a parameter is covered by one launch item, or by the two halves of nothing: never partially
+                if not any(a <= o and o + n <= b for a, b in inside):
+                    raise RuntimeError('a parameter was only partially updated by a fused launch')
+                if cur is not None:
+                    out.append(tuple(cur))
+                    cur = None
+            elif cur is None:
+                cur = [o, o + n]
+            else:
+                cur[1] = o + n
+        if cur is not None:
+            out.append(tuple(cur))
+        return out
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -40,6 +93,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._v = torch.zeros_like(arena.flat)
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=arena.flat.device)
         self._host_step = 0
+        self._fusion = None
 
     def zero_grad(self, set_to_none=True):
         # None marks "first write of the step overwrites": no memset over the gradient arena
@@ -71,16 +125,35 @@ class FusedAdam(torch.optim.Optimizer):
             self._bind()
         return self._step_dev
 
+    def fusion(self):
+        """The ``AdamFusion`` of this optimizer (one per arena binding): a fused step engine hands it to its
+        weight-gradient launches, advances the counter with ``prepare_counted`` and ends the step with
+        ``step_counted(fusion)``."""
+        arena = self._arena
+        if arena is None or arena is not getattr(self.param_groups[0]['params'][0], '_arena', None):
+            self._bind()
+        if self._fusion is None:
+            self._fusion = AdamFusion(self)
+        return self._fusion
+
+    def prepare_counted(self, fusion):
+        """Advance the step counter by one AND leave the step's two bias-correction factors where the fused
+        weight-gradient launches read them (instead of ``K.counter_add(step_counter(), 1)``)."""
+        g = self.param_groups[0]
+        K.adam_prepare(self._step_dev, 1, g['lr'], g['betas'][0], g['betas'][1], fusion.coef)
+
     @torch.no_grad()
-    def step_counted(self):
-        """``step()`` for a caller that already advanced ``step_counter()`` by one this step: one launch."""
+    def step_counted(self, fusion=None):
+        """``step()`` for a caller that already advanced ``step_counter()`` by one this step: one launch -- or, with
+        the step's ``AdamFusion``, one launch per arena range its weight-gradient launches have not updated."""
         arena = self._arena
         for p in arena.params:
             if p.grad is None:
                 raise RuntimeError('a parameter received no gradient this step')
         g = self.param_groups[0]
-        K.adam_apply_at(arena.flat, arena.grad, self._m, self._v, self._step_dev, 0, g['lr'], g['betas'][0],
-                        g['betas'][1], g['eps'], self.grad_scale)
+        for lo, hi in ([(0, arena.numel)] if fusion is None else fusion.rest()):
+            K.adam_apply_at(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, 0,
+                            g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
         self._host_step += 1
 
     @torch.no_grad()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
-    assert handle.mvae_abi_version() == 3
+    assert handle.mvae_abi_version() == 4
 
 
 def test_product_library_has_no_tuning_state():

@@ -326,3 +326,36 @@ def test_captured_step_with_early_counter_equals_update_plus_counter_launch(monk
         assert opt._step_dev.item() == 3
         finals.append(model.arena.flat.clone())
     assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 24), ('mnist', 512), ('fashionmnist', 8)])
+def test_weight_gradient_launches_that_update_their_parameters(kind, batch, monkeypatch):
+    """MVAE_FUSE_ADAM=1: the Linear weight-gradient batches of the captured single-GPU step run optimizer.step() on
+    their own outputs (FashionMNIST's conv / BatchNorm parameters stay with the launch at the end of the chain).  Same
+    parameters, moments and counter, bit for bit, as the arena-wide update -- and on MNIST nothing is left for a launch
+    at the end.  (Off by default: measured slower, profiles/r04_fuse_adam_ab.txt.)"""
+    finals = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('MVAE_FUSE_ADAM', fuse)
+        _, model, _ = build_pair(kind, weight_seed=29)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        eng = BimodalStep(model, batch, 1.0, 50.0)
+        assert eng.fuse_adam == (fuse == '1')
+        image, label = OS.synthetic_batch(kind, batch, seed=700)
+        eng.capture(opt, image.shape[1:], label)
+        if fuse == '1':
+            rest = opt.fusion().rest()
+            covered = sum(b - a for a, b in opt.fusion().covered)
+            assert covered > 0
+            if kind == 'mnist':
+                assert rest == [], rest
+            else:
+                assert rest and sum(b - a for a, b in rest) + covered <= model.arena.numel
+        for step in range(3):
+            image, label = OS.synthetic_batch(kind, batch, seed=710 + step)
+            eng.replay(image.to(DEV), label.to(DEV), 0.5)
+        torch.cuda.synchronize()
+        assert opt._step_dev.item() == 3
+        finals.append((model.arena.flat.clone(), opt._m.clone(), opt._v.clone(), model.arena.grad.clone()))
+    for a, b, what in zip(finals[0], finals[1], ('parameters', 'exp_avg', 'exp_avg_sq', 'gradients')):
+        assert torch.equal(a, b), what

@@ -213,3 +213,55 @@ def test_celeba19_bn_stats_flag_defaults_to_the_reference_behaviour():
         p.parse_args(['--bn-stats', 'fast'])
     with pytest.raises(SystemExit):
         reference_parser('celeba').parse_args(['--bn-stats', 'loss-bearing'])
+
+
+def test_adam_fusion_rest_ranges():
+    """optim.AdamFusion: what is left for the arena-wide launch after the fused weight-gradient launches of a step
+    (whole parameters, merged across alignment padding); double updates and partial covers are refused."""
+    import types
+    from mvae_amd import optim
+
+    class P(object):
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+    sizes = [10, 6, 33, 4, 7]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off); off += (n + 3) // 4 * 4
+    arena = types.SimpleNamespace(params=[P(n) for n in sizes], offsets=offs, numel=off)
+    f = optim.AdamFusion.__new__(optim.AdamFusion)
+    f.arena, f.covered = arena, []
+    assert f.rest() == [(0, offs[4] + 7)]
+    f.covered = [(offs[1], offs[1] + 6)]
+    assert f.rest() == [(0, 10), (offs[2], offs[4] + 7)]
+    f.covered = [(offs[0], offs[1] + 6), (offs[3], offs[3] + 4)]       # a joined pair of parameters, one item
+    assert f.rest() == [(offs[2], offs[2] + 33), (offs[4], offs[4] + 7)]
+    f.covered = [(0, off)]
+    assert f.rest() == []
+    f.covered = [(offs[2], offs[2] + 20)]
+    with pytest.raises(RuntimeError):
+        f.rest()
+
+    class G(object):            # a gradient slice: cover() takes data_ptr / numel / is_contiguous
+        def __init__(self, lo, n):
+            self.lo, self.n = lo, n
+
+        def data_ptr(self):
+            return 4096 + 4 * self.lo
+
+        def numel(self):
+            return self.n
+
+        def is_contiguous(self):
+            return True
+    f.arena.grad = G(0, off)
+    f.begin()
+    f.cover(G(offs[1], 6)); f.cover(G(offs[2], 33))
+    assert f.covered == [(offs[1], offs[1] + 6), (offs[2], offs[2] + 33)]
+    with pytest.raises(RuntimeError):
+        f.cover(G(offs[2] + 5, 3))
+    with pytest.raises(RuntimeError):
+        f.cover(G(off - 2, 8))

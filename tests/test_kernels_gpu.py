@@ -151,6 +151,91 @@ def test_conv_repack_batched_equals_in_launch_repack():
                       wr=torch.empty(32 * 3 * 16, device=DEV))
 
 
+@pytest.mark.parametrize('shapes', [
+    [(1024, 512, 64), (1024, 512, 512), (1024, 784, 512)],
+    [(100, 33, 70), (7, 40, 40), (257, 96, 32)],
+    [(64, 32, 32)] * 17,
+])
+def test_linear_wgrad_batched_adam_is_wgrad_then_adam(shapes):
+    """The launch that updates its own outputs == the plain batch followed by Adam over the same arena ranges, bit for
+    bit (gradients, parameters, both moments) -- incl. an update-only item for a gradient written earlier."""
+    from mvae_amd import _lib
+    sizes = []
+    for (M, N, Kd) in shapes:
+        sizes += [N * Kd, N]
+    extra = 5120 + 3                      # the finished gradient (an Embedding's), ragged against the 1024-element tile
+    offs, off = [], 0
+    for n in sizes + [extra]:
+        offs.append(off); off += (n + 3) // 4 * 4
+    total = off
+
+    def arenas(seed):
+        return (dev(g(total, seed=seed, scale=0.1)), torch.zeros(total, device=DEV),
+                dev(g(total, seed=seed + 1, scale=0.01)), dev(g(total, seed=seed + 2, scale=0.01)).abs())
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    results = []
+    for fused in (True, False):
+        param, grad, m, v = arenas(900)
+        step = torch.full((1,), 6, dtype=torch.int64, device=DEV)
+        coef = torch.zeros(2, device=DEV)
+        o_extra = offs[-1]
+        grad[o_extra:o_extra + extra] = dev(g(extra, seed=77))
+        items = []
+        for q, (M, N, Kd) in enumerate(shapes):
+            dy, x = dev(g(M, N, seed=100 + q)), dev(g(M, Kd, seed=200 + q))
+            ow, ob = offs[2 * q], offs[2 * q + 1]
+            dw = grad[ow:ow + N * Kd].view(N, Kd)
+            db = grad[ob:ob + N] if q % 3 != 2 else None
+            items.append((dy, x, dw, db, False))
+        K.adam_prepare(step, 1, lr, b1, b2, coef)
+        assert int(step.item()) == 7
+        if fused:
+            st = _lib.AdamFuse(grad.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(), coef.data_ptr(), b1, b2,
+                               eps, 1.0)
+            K.linear_wgrad_batched(items + [(None, None, grad[o_extra:o_extra + extra], None, False)], adam=st)
+        else:
+            K.linear_wgrad_batched(items)
+            for (dy, x, dw, db, _) in items:
+                for t in (dw, db):
+                    if t is not None:
+                        lo = (t.data_ptr() - grad.data_ptr()) // 4
+                        hi = lo + t.numel()
+                        K.adam_apply_at(param[lo:hi], grad[lo:hi], m[lo:hi], v[lo:hi], step, 0, lr, b1, b2, eps)
+            lo, hi = o_extra, o_extra + extra
+            K.adam_apply_at(param[lo:hi], grad[lo:hi], m[lo:hi], v[lo:hi], step, 0, lr, b1, b2, eps)
+        torch.cuda.synchronize()
+        results.append((param.clone(), grad.clone(), m.clone(), v.clone()))
+    for a, b, what in zip(results[0], results[1], ('param', 'grad', 'exp_avg', 'exp_avg_sq')):
+        assert torch.equal(a, b), what
+    # and the bias gradients nobody asked for (db = None) left their parameters alone
+    p0 = arenas(900)[0]
+    for q in range(len(shapes)):
+        if q % 3 == 2:
+            ob, N = offs[2 * q + 1], shapes[q][1]
+            assert torch.equal(results[0][0][ob:ob + N], p0[ob:ob + N])
+    # Adam against torch's own arithmetic on one weight (tolerance: its lerp / addcdiv round differently)
+    M, N, Kd = shapes[0]
+    w0, m0, v0 = [t[offs[0]:offs[0] + N * Kd].cpu().double() for t in arenas(900)[0:1] + arenas(900)[2:4]]
+    gw = (g(M, N, seed=100).double().t() @ g(M, Kd, seed=200).double()).reshape(-1)
+    m1 = b1 * m0 + (1 - b1) * gw
+    v1 = b2 * v0 + (1 - b2) * gw * gw
+    ref = w0 - (lr / (1 - b1 ** 7)) * m1 / (v1.sqrt() / (1 - b2 ** 7) ** 0.5 + eps)
+    assert_close(results[0][0][offs[0]:offs[0] + N * Kd], ref.float(), 'fused Adam vs fp64')
+
+
+def test_linear_wgrad_batched_adam_refuses_accumulation():
+    from mvae_amd import _lib
+    dy, x = dev(g(64, 32, seed=1)), dev(g(64, 32, seed=2))
+    buf = torch.zeros(4, 32 * 32, device=DEV)
+    coef = torch.zeros(2, device=DEV)
+    st = _lib.AdamFuse(buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr(), coef.data_ptr(),
+                       0.9, 0.999, 1e-8, 1.0)
+    with pytest.raises(RuntimeError):
+        K.linear_wgrad_batched([(dy, x, buf[0].view(32, 32), None, True)], adam=st)
+    with pytest.raises(RuntimeError):
+        K.linear_wgrad_batched([(None, None, buf[0], None, False)])          # update-only items need adam=
+
+
 def test_linear_wgrad_batched_rejects_shared_gradient():
     dy, x = dev(g(64, 32, seed=1)), dev(g(64, 32, seed=2))
     dw = torch.empty(32, 32, device=DEV)
