@@ -38,9 +38,18 @@
 #ifndef MVAE_DY_KEEP
 #define MVAE_DY_KEEP 1          // 32-row transposed-conv form: the column decode of a tile kept across its parity classes (0: A/B)
 #endif
+#ifndef MVAE_CONVT_SMALL3
+#define MVAE_CONVT_SMALL3 1         // <= 4-output-channel transposed conv: input rows staged through LDS (convT_small3_kernel)
+#endif
+#ifndef MVAE_SMALL2_DEPTH
+#define MVAE_SMALL2_DEPTH 8
+#endif
 #ifndef MVAE_S1_XCD
 #define MVAE_S1_XCD 1           // convT_s1_kernel: the channel groups of one image group on one XCD
 #endif
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ f32x2_t llvm_raw_buffer_load_f32x2(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 
 namespace {
 
@@ -913,7 +922,11 @@ __global__ __launch_bounds__(256) void convT_small_kernel(const float *dy, const
 // and the weights are read at block-uniform addresses straight from global memory -- scalar loads into SGPRs that
 // the FMAs take as operands -- instead of twelve LDS broadcasts per input channel (the LDS pipe was as busy as
 // the vector ALU: 28 TFLOP/s on ConvTranspose2d(32, 3), celeba/model.py:126).
-template <int C>
+// U: input channels fetched per trip of the channel loop.  With ONE (rounds 2-3, the next channel in flight behind the
+// current) every trip waited out a full memory latency -- 32 FMAs per output channel do not cover it, and these launches
+// have only 3-5 waves per SIMD to hide it behind (ConvTranspose2d(64, 1) at 2048 rows: 74 us for 103 MB, 1.5 TB/s, with
+// the ALU, the texture path and HBM each good for ~20 us) -- so a trip fetches U channels at once (host: Cout % U == 0).
+template <int C, int U>
 __global__ __launch_bounds__(256) void convT_small2_kernel(const float *__restrict__ dy, const float *__restrict__ w,
                                                            float *__restrict__ out, float *__restrict__ act,
                                                            const float *__restrict__ dpre, ConvGeom g, int total) {
@@ -926,40 +939,56 @@ __global__ __launch_bounds__(256) void convT_small2_kernel(const float *__restri
     for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[c][q >> 2][q & 3] = 0.f;
-    const float rm = a > 0 ? 1.f : 0.f, rp = a + 1 < OH ? 1.f : 0.f, cm = b0 > 0 ? 1.f : 0.f, cp = b0 + 2 < OW ? 1.f : 0.f;
-    // clamped (always legal) addresses, 0/1 factors: no load under a branch
-    const int ra = a > 0 ? -OW : 0, rb = a + 1 < OH ? OW : 0, ca = b0 > 0 ? -1 : 0, cb = b0 + 2 < OW ? 2 : 1;
-    const float *src = dy + ((size_t)n * g.Cout * OH + a) * OW + b0;
     const int plane = OH * OW;
-    // the next channel's neighbourhood is fetched while this one is multiplied (raw values; the 0/1 factors are
-    // applied when the registers are consumed)
-    float nx[3][4];
-    auto fetch = [&](const float *sp) {
+    // Buffer loads: ONE scalar base (the block's first image), nine per-thread byte offsets that stay put for the
+    // whole loop, and the channel rides the scalar offset -- with 64-bit pointers the U-deep ring kept a pointer
+    // pair per load per stage (200 VGPRs, two waves per SIMD).  A neighbour outside the image carries the offset
+    // BUF_OOB and reads as 0: the loaded registers go into the FMAs as they arrived (a 0/1 multiply made copies, and
+    // the compiler parked the copies' waits at the loop's back edge -- behind every load of the trip).
+    const int n_first = (blockIdx.x * 256) / (OW2 * OH);
+    const i32x4_t rs = buf_rsrc(buf_base(dy), (size_t)n_first * g.Cout * plane);
+    int vo[3][3];                                   // [row a-1, a, a+1][column b0-1 | b0, b0+1 | b0+2]
+    {
+        const int at = ((n - n_first) * g.Cout * plane + a * OW + b0) * 4;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int ro = r == 0 ? ra : (r == 2 ? rb : 0);
-            const float2 mid = *reinterpret_cast<const float2 *>(sp + ro);
-            nx[r][0] = sp[ro + ca]; nx[r][1] = mid.x; nx[r][2] = mid.y; nx[r][3] = sp[ro + cb];
+            const bool rok = r == 0 ? a > 0 : (r == 2 ? a + 1 < OH : true);
+            const int ro = (r - 1) * OW;
+            vo[r][0] = rok && b0 > 0 ? at + (ro - 1) * 4 : BUF_OOB;
+            vo[r][1] = rok ? at + ro * 4 : BUF_OOB;
+            vo[r][2] = rok && b0 + 2 < OW ? at + (ro + 2) * 4 : BUF_OOB;
+        }
+    }
+    // U channels' neighbourhoods are fetched together at the top of a trip and multiplied as they land
+    float nx[U][3][4];
+    auto fetch = [&](int u, int ch) {
+        const int so = ch * plane * 4;              // block-uniform
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const f32x2_t mid = llvm_raw_buffer_load_f32x2(rs, vo[r][1], so, 0);
+            nx[u][r][0] = llvm_raw_buffer_load_f32(rs, vo[r][0], so, 0); nx[u][r][1] = mid.x; nx[u][r][2] = mid.y;
+            nx[u][r][3] = llvm_raw_buffer_load_f32(rs, vo[r][2], so, 0);
         }
     };
-    fetch(src);
-    for (int co = 0; co < g.Cout; ++co) {
-        float d[3][4];                              // rows a-1, a, a+1; columns b0-1 .. b0+2
+    // (A ring -- stage u refilled for trip + 1 right after it is consumed -- does not survive hipcc 7.2: the loaded
+    //  values are loop-carried, the compiler copies them into the registers the next trip reads at the BACK EDGE, and
+    //  the copies wait for all but the last two loads of the trip.  Within one trip nothing is carried.)
+#pragma unroll 1
+    for (int co0 = 0; co0 < g.Cout; co0 += U) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float rf = r == 0 ? rm : (r == 2 ? rp : 1.f);
-            d[r][0] = nx[r][0] * (rf * cm); d[r][1] = nx[r][1] * rf; d[r][2] = nx[r][2] * rf; d[r][3] = nx[r][3] * (rf * cp);
-        }
-        src += (co + 1 < g.Cout) ? plane : 0;       // the last trip re-reads its own plane: no load under a branch
-        fetch(src);
+      for (int u = 0; u < U; ++u) fetch(u, co0 + u);
+      __builtin_amdgcn_sched_barrier(0);            // all 9 U loads are issued before the first is waited for
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int co = co0 + u;
         const float *wc = w + (size_t)co * C * 16;  // block-uniform
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float *wp = wc + c * 16;          // [kh][kw]
 #pragma unroll
             for (int pos = 0; pos < 2; ++pos) {     // input column b0 + pos -> output columns 2*(b0+pos), +1
-                const float (*e)[4] = d;
-                const int q = pos;                  // d[.][q] = column b-1, d[.][q+1] = b, d[.][q+2] = b+1
+                const float (*e)[4] = nx[u];        // rows a-1, a, a+1; columns b0-1 .. b0+2
+                const int q = pos;                  // e[.][q] = column b-1, e[.][q+1] = b, e[.][q+2] = b+1
                 // chained FMAs into the accumulator (a sum of four products added afterwards costs a fifth instruction)
                 auto mac4 = [](float acc0, float w0, float x0, float w1, float x1, float w2, float x2, float w3, float x3) {
                     return fmaf(w3, x3, fmaf(w2, x2, fmaf(w1, x1, fmaf(w0, x0, acc0))));
@@ -973,6 +1002,7 @@ __global__ __launch_bounds__(256) void convT_small2_kernel(const float *__restri
                 acc[c][1][2 * pos + 1] = mac4(acc[c][1][2 * pos + 1], wp[0], e[2][q + 2], wp[2], e[2][q + 1], wp[8], e[1][q + 2], wp[10], e[1][q + 1]);
             }
         }
+      }
     }
     const int H = 2 * OH, W = 2 * OW;
 #pragma unroll
@@ -991,6 +1021,167 @@ __global__ __launch_bounds__(256) void convT_small2_kernel(const float *__restri
     }
 }
 
+// ---- the same through LDS (round 4).  SQ / cache counters of convT_small2_kernel (profiles/r04_small_conv_counters.txt):
+//      the texture addresser is the busy unit (57 % of the launch) -- the nine loads of a neighbourhood are 8- and 4-byte
+//      accesses at a lane stride of 8 bytes, which the addresser takes a quad of lanes at a time (24 cache accesses per
+//      load instruction: ~190 addresser cycles per channel per wave, 63 us of a 67-us launch on ConvTranspose2d(64, 1) at
+//      2048 rows), and every input element is fetched six times.  Here a block owns NI whole images (or a band of R rows
+//      of one) and stages each input channel's rows ONCE, with consecutive lanes on consecutive floats (4 addresser cycles
+//      per load), into a zero-bordered LDS image [NI][R + 2][OW + 2]; a thread then reads its 3 x 4 neighbourhood as six
+//      8-byte LDS reads with no bounds logic (the border and the rows outside the image stay zero from the fill at block
+//      start: an element outside carries BUF_OOB, loads as 0 and is stored as 0).  D channels are staged per trip into one
+//      half of a double buffer while the other half is multiplied: the staging registers live inside a trip, nothing
+//      loaded is carried around the loop (see convT_small2_kernel's note on what hipcc does to that).
+struct Small3Geo {
+    int R, NI, bands;             // rows of a block's band, images per block, bands per image
+    int E;                        // staged floats per channel per block: NI * (R + 2) * OW
+    int ch_stride;                // LDS floats per staged channel: NI * (R + 2) * (OW + 2)
+};
+constexpr int S3_NE = 4;          // staged floats per thread per channel, at most
+
+template <int C, int D>
+__global__ __launch_bounds__(256) void convT_small3_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                           float *__restrict__ out, float *__restrict__ act,
+                                                           const float *__restrict__ dpre, ConvGeom g, Small3Geo sg) {
+    extern __shared__ __attribute__((aligned(16))) float s3_lds[];      // [2][D][ch_stride] + a dummy float per thread
+    const int t = threadIdx.x;
+    const int OH = g.OH, OW = g.OW, OW2 = OW >> 1, PITCH = OW + 2, plane = OH * OW;
+    const int n0 = blockIdx.x * sg.NI, a0 = blockIdx.y * sg.R;
+    const int half = D * sg.ch_stride, dummy = 2 * half + t;
+    for (int j = t; j < 2 * half; j += 256) s3_lds[j] = 0.f;
+    // this thread's staged elements: (image, band row -1 .. R, column) -> global byte offset from the block's first image
+    // (channel 0) and LDS offset inside a channel image; both fixed for the whole launch
+    const i32x4_t rs = buf_rsrc(buf_base(dy), (size_t)n0 * g.Cout * plane);
+    int gofs[S3_NE], lofs[S3_NE];
+    const int per_img = (sg.R + 2) * OW;
+#pragma unroll
+    for (int k = 0; k < S3_NE; ++k) {
+        const int e = t + k * 256;
+        const int i = e / per_img, rem = e - i * per_img, rr = rem / OW, cc = rem - rr * OW;
+        const int row = a0 - 1 + rr;
+        const bool ok = e < sg.E && n0 + i < g.B && row >= 0 && row < OH;
+        gofs[k] = ok ? ((i * g.Cout * OH + row) * OW + cc) * 4 : BUF_OOB;
+        lofs[k] = e < sg.E ? (i * (sg.R + 2) + rr) * PITCH + cc + 1 : -1;
+    }
+    // (all S3_NE slots are always loaded and stored -- an unused one carries BUF_OOB and lands in the thread's dummy
+    //  float: a block-uniform `if (k < ne)` around a load made hipcc drain the memory queue after every one of them)
+    // this thread's outputs: image i, band row al, input columns b0, b0 + 1
+    const int per_band = sg.R * OW2;
+    const int ti = t / per_band, trem = t - ti * per_band, al = trem / OW2, b0 = (trem - al * OW2) * 2;
+    const int n = n0 + ti, a = a0 + al;
+    const bool live = ti < sg.NI && n < g.B && a < OH;
+    const int rd = live ? (ti * (sg.R + 2) + al) * PITCH + b0 : 0;      // neighbourhood corner (row a - 1, column b0 - 1)
+    float acc[C][2][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q >> 2][q & 3] = 0.f;
+    float st[D][S3_NE];
+    auto load_batch = [&](int co0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int so = (co0 + d) * plane * 4;   // block-uniform
+#pragma unroll
+            for (int k = 0; k < S3_NE; ++k) st[d][k] = llvm_raw_buffer_load_f32(rs, gofs[k], so, 0);
+        }
+    };
+    auto store_batch = [&](float *buf) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int k = 0; k < S3_NE; ++k) {
+                const int o = lofs[k] < 0 ? dummy : (int)(buf - s3_lds) + d * sg.ch_stride + lofs[k];
+                s3_lds[o] = st[d][k];
+            }
+    };
+    const int nb = g.Cout / D;                      // host: Cout % D == 0
+    load_batch(0);
+    __syncthreads();                                // the zero fill is complete
+    store_batch(s3_lds);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < nb; ++kb) {
+        const float *cur = s3_lds + (kb & 1) * half;
+        // the next batch's rows are in flight while this one is multiplied (the last trip re-reads its own batch into
+        // the buffer nobody reads any more: no load under a branch)
+        load_batch(min(kb + 1, nb - 1) * D);
+        __builtin_amdgcn_sched_barrier(0);
+        // (rolled, two channels per trip: unrolled D deep the compiler issues all 6 D LDS reads first -- 200+ registers)
+#pragma unroll 2
+        for (int d = 0; d < D; ++d) {
+            const float *img = cur + d * sg.ch_stride + rd;
+            float e[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(img + r * PITCH);
+                const float2 hi = *reinterpret_cast<const float2 *>(img + r * PITCH + 2);
+                e[r][0] = lo.x; e[r][1] = lo.y; e[r][2] = hi.x; e[r][3] = hi.y;
+            }
+            const float *wc = w + (size_t)(kb * D + d) * C * 16;      // block-uniform
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float *wp = wc + c * 16;      // [kh][kw]
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) { // input column b0 + pos -> output columns 2*(b0+pos), +1
+                    const int q = pos;              // e[.][q] = column b-1, e[.][q+1] = b, e[.][q+2] = b+1
+                    auto mac4 = [](float acc0, float w0, float x0, float w1, float x1, float w2, float x2, float w3, float x3) {
+                        return fmaf(w3, x3, fmaf(w2, x2, fmaf(w1, x1, fmaf(w0, x0, acc0))));
+                    };
+                    // the tap <-> neighbour table of convT_small2_kernel
+                    acc[c][0][2 * pos] = mac4(acc[c][0][2 * pos], wp[5], e[1][q + 1], wp[7], e[1][q], wp[13], e[0][q + 1], wp[15], e[0][q]);
+                    acc[c][0][2 * pos + 1] = mac4(acc[c][0][2 * pos + 1], wp[4], e[1][q + 2], wp[6], e[1][q + 1], wp[12], e[0][q + 2], wp[14], e[0][q + 1]);
+                    acc[c][1][2 * pos] = mac4(acc[c][1][2 * pos], wp[1], e[2][q + 1], wp[3], e[2][q], wp[9], e[1][q + 1], wp[11], e[1][q]);
+                    acc[c][1][2 * pos + 1] = mac4(acc[c][1][2 * pos + 1], wp[0], e[2][q + 2], wp[2], e[2][q + 1], wp[8], e[1][q + 2], wp[10], e[1][q + 1]);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_batch(s3_lds + ((kb + 1) & 1) * half);
+        __syncthreads();
+    }
+    if (!live) return;
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t o = (((size_t)n * C + c) * H + 2 * a + ph) * W + 2 * b0;     // 16-byte aligned: b0 even, W % 4 == 0
+            float4 v = make_float4(acc[c][ph][0], acc[c][ph][1], acc[c][ph][2], acc[c][ph][3]);
+            if (dpre) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(dpre + o);
+                v.x *= swish_grad_(p4.x); v.y *= swish_grad_(p4.y); v.z *= swish_grad_(p4.z); v.w *= swish_grad_(p4.w);
+            }
+            if (out) *reinterpret_cast<float4 *>(out + o) = v;
+            if (act) *reinterpret_cast<float4 *>(act + o) = make_float4(swishf_(v.x), swishf_(v.y), swishf_(v.z), swishf_(v.w));
+        }
+    }
+}
+
+// block geometry and batch depth of convT_small3_kernel; false: the shape stays with convT_small2_kernel
+inline bool conv_small3_plan(const ConvGeom &g, Small3Geo &sg, int &depth, size_t &lds) {
+    if (!MVAE_CONVT_SMALL3 || (g.OW & 1) || g.OW / 2 > 256) return false;
+    const int OW2 = g.OW / 2;
+    sg.R = g.OH < 256 / OW2 ? g.OH : 256 / OW2;
+    sg.NI = 256 / (sg.R * OW2);
+    if (sg.NI < 1) return false;
+    if (sg.R < g.OH) sg.NI = 1;                     // bands only of single images
+    sg.bands = (g.OH + sg.R - 1) / sg.R;
+    sg.E = sg.NI * (sg.R + 2) * g.OW;
+    sg.ch_stride = sg.NI * (sg.R + 2) * (g.OW + 2);
+    if (sg.E > S3_NE * 256) return false;
+    // a block walks its channels in a few barrier-separated trips: it needs company on its CU (>= 4 blocks) to hide them.
+    // Measured hot (profiles/r04_small_conv_ab.txt): 1024 blocks 71 -> 48 us (ConvTranspose2d(64, 1), 2048 rows) and
+    // 42 -> 34 us (ConvTranspose2d(32, 3), 512 rows); 512 blocks 20.5 -> 28 us (the same at 256 rows)
+    if ((long)((g.B + sg.NI - 1) / sg.NI) * sg.bands < 1024) return false;
+    // byte offsets inside a block's images stay far below 2 GiB
+    if ((size_t)sg.NI * g.Cout * g.OH * g.OW * 4 >= ((size_t)1 << 30)) return false;
+    for (depth = 8; depth >= 1; depth >>= 1) {
+        lds = ((size_t)2 * depth * sg.ch_stride + 256) * sizeof(float);
+        if (g.Cout % depth == 0 && lds <= 48 * 1024) return true;
+    }
+    return false;
+}
+
 inline bool conv_dgrad_small_ok(const ConvGeom &g) {
     return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && g.H == 2 * g.OH && g.W == 2 * g.OW &&
            (size_t)g.Cout * g.Cin * 16 * sizeof(float) <= 48 * 1024;
@@ -1001,16 +1192,49 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
     const int total = g.B * g.OH * g.OW;
     const size_t lds = (size_t)g.Cout * g.Cin * 16 * sizeof(float);
     const dim3 grid((total + 255) / 256), blk(256);
+    {
+        Small3Geo sg; int depth; size_t lds3;
+        if (conv_small3_plan(g, sg, depth, lds3) && aligned16(dx ? dx : act) && (!dx || !act || aligned16(act)) &&
+            (!dpre || aligned16(dpre)) && (2 * g.OW) % 4 == 0) {
+            const dim3 grid3((g.B + sg.NI - 1) / sg.NI, sg.bands);
+#define MVAE_S3(CV, DV) hipLaunchKernelGGL((convT_small3_kernel<CV, DV>), grid3, blk, lds3, st, dy, w, dx, act, dpre, g, sg)
+#define MVAE_S3D(CV)                                                                                     \
+            if (depth == 8) MVAE_S3(CV, 8); else if (depth == 4) MVAE_S3(CV, 4);                         \
+            else if (depth == 2) MVAE_S3(CV, 2); else MVAE_S3(CV, 1);
+            switch (g.Cin) {
+                case 1: MVAE_S3D(1) break;
+                case 2: MVAE_S3D(2) break;
+                case 3: MVAE_S3D(3) break;
+                default: MVAE_S3D(4) break;
+            }
+#undef MVAE_S3D
+#undef MVAE_S3
+            return mvae_launch_status();
+        }
+    }
     if (MVAE_CONVT_SMALL2 && g.OW % 2 == 0 && aligned16(dx ? dx : act) && (!dx || !act || aligned16(act)) && (!dpre || aligned16(dpre)) &&
         aligned8(dy)) {
         const int total2 = total / 2;
         const dim3 grid2((total2 + 255) / 256);
-        switch (g.Cin) {
-            case 1: hipLaunchKernelGGL(convT_small2_kernel<1>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
-            case 2: hipLaunchKernelGGL(convT_small2_kernel<2>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
-            case 3: hipLaunchKernelGGL(convT_small2_kernel<3>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
-            default: hipLaunchKernelGGL(convT_small2_kernel<4>, grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); break;
+        // channels fetched per trip: MVAE_SMALL2_DEPTH, as far as it divides the channel count (8 only with one output
+        // channel: 96 registers of neighbourhoods)
+        const int want = (MVAE_SMALL2_DEPTH >= 8 && g.Cin > 1) ? 4 : MVAE_SMALL2_DEPTH;
+        const int depth = (want >= 8 && g.Cout % 8 == 0) ? 8 : ((want >= 4 && g.Cout % 4 == 0) ? 4 : ((want >= 2 && g.Cout % 2 == 0) ? 2 : 1));
+#define MVAE_S2(CV)                                                                                                         \
+        if (depth == 4) hipLaunchKernelGGL((convT_small2_kernel<CV, 4>), grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2);   \
+        else if (depth == 2) hipLaunchKernelGGL((convT_small2_kernel<CV, 2>), grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2); \
+        else hipLaunchKernelGGL((convT_small2_kernel<CV, 1>), grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2);
+        if (depth == 8) {
+            hipLaunchKernelGGL((convT_small2_kernel<1, 8>), grid2, blk, 0, st, dy, w, dx, act, dpre, g, total2);
+            return mvae_launch_status();
         }
+        switch (g.Cin) {
+            case 1: MVAE_S2(1) break;
+            case 2: MVAE_S2(2) break;
+            case 3: MVAE_S2(3) break;
+            default: MVAE_S2(4) break;
+        }
+#undef MVAE_S2
         return mvae_launch_status();
     }
     switch (g.Cin) {

@@ -392,6 +392,26 @@ def test_conv2d(B, Cin, H, Cout, s, p):
     assert_close(dw, 2 * w.grad, 'conv wgrad accumulate')
 
 
+@pytest.mark.parametrize('B,Cin,H,Cout', [(2049, 6, 14, 1), (512, 8, 32, 3), (1024, 4, 28, 2)])
+def test_small_channel_transposed_conv_through_lds(B, Cin, H, Cout):
+    """<= 4 output channels and >= 1024 blocks: the launch that stages the input rows through LDS (conv.hip:
+    convT_small3_kernel) -- whole images per block with a ragged last block, 8 / 2 / 4 channels per trip; row bands of
+    one image, the last band partial -- as a transposed conv forward and as the data gradient of the mirrored conv with
+    the producer's Swish' folded in."""
+    x = g(B, Cin, H, H, seed=40)
+    w = g(Cin, Cout, 4, 4, seed=41, scale=(Cin * 4) ** -0.5)
+    y = F.conv_transpose2d(x, w, None, 2, 1)
+    pre = torch.empty(*y.shape, device=DEV); act = torch.empty(*y.shape, device=DEV)
+    K.convT2d_fwd(dev(x), dev(w), pre, act, 2, 1)
+    assert_close(pre, y, 'convT fwd through LDS')
+    assert_close(act, swish(y), 'convT fwd through LDS, act')
+    # Conv2d(Cout, Cin): its data gradient is the same launch on dy = x
+    pre_in = g(*y.shape, seed=42)
+    dx = torch.empty(*y.shape, device=DEV)
+    K.conv2d_dgrad(dev(x), dev(w), dx, dev(pre_in), 2, 1)
+    assert_close(dx, y * swish_grad(pre_in), "conv dgrad * swish' through LDS")
+
+
 CONVT_CASES = [(3, 256, 5, 128, 1, 0), (2, 128, 8, 64, 2, 1), (2, 64, 16, 32, 2, 1), (2, 32, 32, 3, 2, 1),
                (4, 128, 7, 64, 2, 1), (3, 64, 14, 1, 2, 1), (2, 3, 2, 5, 1, 0)]
 

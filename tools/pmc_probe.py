@@ -28,6 +28,18 @@ def run():
         print(name, '%.2f GFLOP' % (fl / 1e9))
 
 
+def run_small():
+    """The <= 4-channel conv launches (tools/small_conv_probe.py) once each, three repetitions."""
+    import torch
+    import mvae_amd  # noqa: F401
+    from small_conv_probe import CASES
+    for name, fl, fn in CASES:
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        print(name, '%.2f GFLOP' % (fl / 1e9))
+
+
 def show(db):
     c = sqlite3.connect(db)
     rows = c.execute('select dispatch_id, kernel_name, counter_name, value from counters_collection '
@@ -40,7 +52,7 @@ def show(db):
     print('%-6s %-70s ' % ('id', 'kernel') + ' '.join('%16s' % n[-16:] for n in names))
     for d in sorted(disp):
         n, vals = disp[d]
-        if not re.search(r'igemm|convT', n):
+        if not re.search(r'igemm|convT|conv_small|smallcin', n):
             continue
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:70]
         print('%-6d %-70s ' % (d, short) + ' '.join('%16.0f' % vals.get(k, 0) for k in names))
@@ -50,5 +62,8 @@ if __name__ == '__main__':
     if sys.argv[1] == 'run':
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         run()
+    elif sys.argv[1] == 'run-small':
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        run_small()
     else:
         show(sys.argv[2])
