@@ -75,6 +75,16 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #else
 #define MVAE_TUNE(f) 0
 #endif
+#ifndef MVAE_EPI_BATCH
+#define MVAE_EPI_BATCH 0         // tile epilogues: the operands of eight outputs fetched together.  Off: with 3-5 blocks per CU the other
+                                 // blocks' matrix work already covers a block's epilogue -- CelebA +0.6 %, FashionMNIST +0.1 % (r04_epilogue_ab.txt)
+#endif
+#ifndef MVAE_EPI_PREFETCH_ROWRED
+#define MVAE_EPI_PREFETCH_ROWRED 1     // ... also for the loss-folding epilogues (bias, target / label, row coefficient)
+#endif
+#ifndef MVAE_EPI_PREFETCH
+#define MVAE_EPI_PREFETCH 1      // small layouts: the epilogue's operands fetched ahead of the main loop (0: rounds 1-3)
+#endif
 
 // raw buffer loads, declared on the LLVM intrinsics (see "buffer loads for the main loops" below)
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -362,7 +372,40 @@ struct EpRowMajor {
         if (out) out[idx] = v;
         if (act) act[idx] = swishf_(v) * m;
     }
+    // The same in two halves: fetch() what output (i, j) will need -- UNCONDITIONAL loads from always-legal addresses
+    // (a null operand reads the destination instead; the value is not used) that a kernel issues long before its
+    // epilogue -- and put_pre().  In put() every operand load sits under a block-uniform branch, hipcc waits for the
+    // whole memory queue behind each, and an output costs one or two full memory latencies: four outputs per thread in
+    // the small layouts' epilogue were 4-8 us of a 11-us launch (MNIST's 512-wide layers).
+    struct Pre { float b, d, m; };
+    static constexpr bool PREFETCH = true;
+    __device__ Pre fetch(int i, int j) const {
+        const int ic = min(i, I - 1), jc = min(j, J - 1);
+        const float *safe = out ? out : act;
+        const float *bp = bias ? bias + jc : safe;
+        const float *dp = dpre ? dpre + (size_t)ic * ldp + jc : safe;
+        const float *mp = mask ? mask + (size_t)ic * ldm + jc : safe;
+        Pre p;
+        p.b = *bp; p.d = *dp; p.m = *mp;
+        return p;
+    }
+    __device__ void put_pre(int i, int j, float v, const Pre &p) const {
+        if (MVAE_KO_EPI && v != MVAE_KO_MAGIC) return;
+        if (i >= I) return;
+        if (bias) v += p.b;
+        float m = 1.f;
+        if (mask) m = p.m * mask_scale;
+        if (dpre) v *= m * swish_grad_(p.d);
+        const size_t idx = (size_t)i * ld + j;
+        if (accumulate) v += out[idx];
+        if (out) out[idx] = v;
+        if (act) act[idx] = swishf_(v) * m;
+    }
 };
+template <class T, class = void> struct ep_prefetch : std::false_type {};
+template <class T> struct ep_prefetch<T, std::void_t<decltype(T::PREFETCH)>> : std::integral_constant<bool, T::PREFETCH> {};
+template <class T, bool = ep_prefetch<T>::value> struct ep_pre { struct type {}; };
+template <class T> struct ep_pre<T, true> { typedef typename T::Pre type; };
 
 // Linear forward whose only consumer is a reconstruction term of the ELBO: the logits never reach memory, the
 // epilogue emits d loss / d logits (the backward's input) and the loss itself.  ROWRED epilogues are driven through
@@ -400,6 +443,29 @@ struct EpRowBce {
         l = half_wave_sum(l);
         if ((threadIdx.x & 31) == 0 && i < I && j < J) part[(size_t)i * nparts + (j >> 5)] = l;
     }
+    // put_row in two halves (see EpRowMajor::fetch): bias, target and the row's coefficient fetched ahead of the main loop
+    struct Pre { float b, tg, dr; };
+    static constexpr bool PREFETCH = true;
+    __device__ Pre fetch(int i, int j) const {
+        const int ic = min(i, I - 1), jc = min(j, J - 1);
+        Pre p;
+        p.tg = target[(size_t)(ic % target_rows) * t_rs + jc];
+        p.b = *(bias ? bias + jc : target);
+        p.dr = drow[ic / rows_per_group];
+        return p;
+    }
+    __device__ void put_row_pre(int i, int j, float v, const Pre &p) const {
+        float l = 0.f;
+        if (i < I && j < J) {
+            if (bias) v += p.b;
+            l = bce_elem(v, p.tg);
+            const size_t idx = (size_t)i * ld + j;
+            dlogits[idx] = p.dr * 1.f * bce_grad(v, p.tg);
+            if (logits) logits[idx] = v;
+        }
+        l = half_wave_sum(l);
+        if ((threadIdx.x & 31) == 0 && i < I && j < J) part[(size_t)i * nparts + (j >> 5)] = l;
+    }
 };
 
 // Categorical term (mnist/train.py:52,77-94 on mnist/model.py:146's last Linear), J <= 32 classes: a half wavefront
@@ -432,6 +498,33 @@ struct EpRowCe {
         const int y = bad ? 0 : (int)yraw;
         if (j == y) row[i] = bad ? NAN : -(x - lse);
         const float dr = bad ? NAN : drow[i / rows_per_group];
+        const size_t idx = (size_t)i * ld + j;
+        dlogits[idx] = dr * (expf(x - lse) - (j == y ? 1.f : 0.f));
+        if (logits) logits[idx] = v;
+    }
+    struct Pre { float b, dr; int64_t y; };
+    static constexpr bool PREFETCH = true;
+    __device__ Pre fetch(int i, int j) const {
+        const int ic = min(i, I - 1), jc = min(j, J - 1);
+        Pre p;
+        p.y = label[ic % label_rows];
+        p.b = *(bias ? bias + jc : drow);
+        p.dr = drow[ic / rows_per_group];
+        return p;
+    }
+    __device__ void put_row_pre(int i, int j, float v, const Pre &p) const {
+        const bool in = i < I && j < J;
+        if (in && bias) v += p.b;
+        const float x = in ? v + 1e-6f : -INFINITY;
+        const float mx = half_wave_max(x);
+        const float se = half_wave_sum(in ? expf(x - mx) : 0.f);
+        if (!in) return;
+        const float lse = logf(se) + mx;
+        const int64_t yraw = p.y;
+        const bool bad = yraw < 0 || yraw >= J;
+        const int y = bad ? 0 : (int)yraw;
+        if (j == y) row[i] = bad ? NAN : -(x - lse);
+        const float dr = bad ? NAN : p.dr;
         const size_t idx = (size_t)i * ld + j;
         dlogits[idx] = dr * (expf(x - lse) - (j == y ? 1.f : 0.f));
         if (logits) logits[idx] = v;
@@ -680,6 +773,20 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     p.init(i0, t, cls);
     q.init(j0, t, cls);
     e.set_class(cls);
+    // the small layouts' cooperative epilogue (below): what this thread's outputs will need -- bias, the producer's
+    // pre-activation, the dropout mask -- is fetched NOW and lands behind the whole reduction (EpRowMajor::fetch)
+    // (up to four outputs per thread: the 256-thread variants would hold eight -- 24 registers, an occupancy step)
+    constexpr bool COOP_PRE = KW > 1 && WGM * WGN < 4 && ep_prefetch<E>::value && (BM * BN) % NT == 0 &&
+                              (BM * BN) / NT <= (E::ROWRED ? 8 : 4) && MVAE_EPI_PREFETCH && (!E::ROWRED || MVAE_EPI_PREFETCH_ROWRED);
+    constexpr int CNE = COOP_PRE ? (BM * BN) / NT : 1;
+    typename ep_pre<E>::type cpre[CNE];
+    if constexpr (COOP_PRE) {
+#pragma unroll
+        for (int k = 0; k < CNE; ++k) {
+            const int el = t + k * NT;
+            cpre[k] = e.fetch(i0 + el / BN, j0 + el % BN);
+        }
+    }
     typename P::Regs pr0, pr1;
     typename Q::Regs qr0, qr1;
     // db = sum over the reduction axis of P (dy^T): the bias gradient for free.  The 256 movers split the
@@ -1115,6 +1222,25 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 }
         __syncthreads();
         const bool partial_c = gridDim.z > 1;
+        if constexpr (COOP_PRE) {
+#pragma unroll
+            for (int k = 0; k < CNE; ++k) {
+                const int el = t + k * NT;
+                const int il = el / BN, jl = el % BN;
+                float v = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < KW; ++g2) v += lds_raw[g2 * (BM * TP) + il * TP + jl];
+                const int i = i0 + il, j = j0 + jl;
+                if constexpr (E::ROWRED) {
+                    e.put_row_pre(i, j, v, cpre[k]);        // (every thread takes part in every round: see below)
+                } else if (partial_c) {
+                    if (i < sink.I && j < sink.J)
+                        sink.ws[(size_t)cls * sink.cls_region + (size_t)split * sink.stride + (size_t)i * sink.J + j] = v;
+                } else if (e.col(j)) {
+                    e.put_pre(i, j, v, cpre[k]);
+                }
+            }
+        } else
         for (int el = t; el < BM * BN; el += NT) {
             const int il = el / BN, jl = el % BN;
             float v = 0.f;
@@ -1196,6 +1322,21 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
 #pragma unroll
         for (int x = 0; x < WM; ++x) {
             const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
+            if constexpr (ep_prefetch<E>::value && MVAE_EPI_BATCH) {
+                // operands of eight outputs at a time, all fetched before the first is used (see EpRowMajor::fetch: left
+                // inside put(), every output waits out its own memory latency behind a block-uniform branch)
+                if (!partial) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        typename ep_pre<E>::type pr[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) pr[r] = e.fetch(ib + (r & 3) + 8 * ((8 * h + r) >> 2), j);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) e.put_pre(ib + (r & 3) + 8 * ((8 * h + r) >> 2), j, acc[x][y][8 * h + r], pr[r]);
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = ib + (r & 3) + 8 * (r >> 2);
