@@ -36,6 +36,14 @@ def run(name, key):
     from mvae_amd import kernels as K
     dev = 'cuda'
     r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    if name == 'linear_wgrad_batched':
+        items = []
+        for (M, N, Kd) in WGRAD_BATCHES[key]:
+            items.append((r(M, N), r(M, Kd), torch.empty(N, Kd, device=dev), torch.empty(N, device=dev), False))
+        for _ in range(N_CALLS):
+            K.linear_wgrad_batched(items)
+        torch.cuda.synchronize()
+        return
     if (name, key) not in CONV_CASES:
         d = parse_key(key)
         M, N, Kd = d['M'], d['N'], d['K']
@@ -56,6 +64,10 @@ def run(name, key):
         fn()
     torch.cuda.synchronize()
 
+
+# the batched Linear weight-gradient launches of the MNIST step, by the profiler's key: (rows, out, in) per layer --
+# the image decoder's four layers over its two terms (mnist/model.py:95-104 backward, batch 512)
+WGRAD_BATCHES = {'4 layers': [(1024, 784, 512), (1024, 512, 512), (1024, 512, 512), (1024, 512, 64)]}
 
 # conv launches bench.py may name as dominant on the CelebA step: (profiler name, key) -> ConvTranspose2d / Conv2d
 # layer (B, Cin, H, Cout, stride, pad) of celeba/model.py:77-86,117-126 at 2 x 256 decoder rows / 256 encoder rows
@@ -97,6 +109,9 @@ def algorithmic_bytes(name, key):
         kind, B, Cin, H, Cout, s, p = CONV_CASES[(name, key)]
         OH = (H - 1) * s - 2 * p + 4 if kind == 'convT' else (H + 2 * p - 4) // s + 1
         return 4 * (B * Cin * H * H + B * Cout * OH * OH + Cin * Cout * 16)
+    if name == 'linear_wgrad_batched':
+        # x of layer l + 1 is the activation behind dy of layer l's producer: distinct tensors, each read once
+        return sum(4 * (M * N + M * Kd + N * Kd + N) for (M, N, Kd) in WGRAD_BATCHES[key])
     d = parse_key(key)
     M, N, Kd = d['M'], d['N'], d['K']
     return 4 * (M * N + M * Kd + N * Kd + (N if name == 'linear_wgrad' else 0))
@@ -105,7 +120,7 @@ def algorithmic_bytes(name, key):
 def _per_call_kib(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)).fetchall()
-    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_smallcin|repack_dgrad', n)]
+    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_batched|wgrad_smallcin|repack_dgrad', n)]
     per_kernel = {}
     for n, v in ours:
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:90]
