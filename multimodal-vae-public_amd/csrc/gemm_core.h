@@ -75,6 +75,11 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #else
 #define MVAE_TUNE(f) 0
 #endif
+#ifndef MVAE_PHASED_PRELOAD
+#define MVAE_PHASED_PRELOAD 0    // k-grouped blocks, two tiles really in flight (see the phased loop): 1 = every wave issues the tile loads
+                                 // (out of range for the MFMA-only waves), 2 = those waves run a load-free copy of the loop.
+                                 // 1 measured ONCE: parity green (109 tests), MNIST 0.2851 -> 0.2920 ms -- off; 2 never run
+#endif
 #ifndef MVAE_EPI_BATCH
 #define MVAE_EPI_BATCH 0         // tile epilogues: the operands of eight outputs fetched together.  Off: with 3-5 blocks per CU the other
                                  // blocks' matrix work already covers a block's epilogue -- CelebA +0.6 %, FashionMNIST +0.1 % (r04_epilogue_ab.txt)
@@ -169,6 +174,11 @@ struct LdRowsKT {
     BufBase blk;                                      //              address of (row r0, k = 0)
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
+    // a thread that fetches nothing (the MFMA-only waves of a k-grouped block): every buffer load reads out of range
+    __device__ void disable() {
+#pragma unroll
+        for (int v = 0; v < (VEC ? NV : 1); ++v) voff[v] = BUF_OOB;
+    }
     __device__ void init(int tile0, int t, int cls) {
         r0 = tile0; cls_off = (size_t)cls * cls_stride;
         if (VEC) {
@@ -266,6 +276,11 @@ struct LdRowsMNT {
     BufBase blk;                                      //              address of (k = 0, r0)
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
+    // a thread that fetches nothing (the MFMA-only waves of a k-grouped block): every buffer load reads out of range
+    __device__ void disable() {
+#pragma unroll
+        for (int v = 0; v < (VEC ? NV : 1); ++v) voff[v] = BUF_OOB;
+    }
     __device__ void init(int tile0, int t, int cls) {
         r0 = tile0; cls_off = (size_t)cls * cls_stride;
         if (VEC) {
@@ -402,6 +417,9 @@ struct EpRowMajor {
         if (act) act[idx] = swishf_(v) * m;
     }
 };
+template <class T, class = void> struct ld_can_disable : std::false_type {};
+template <class T> struct ld_can_disable<T, std::void_t<decltype(std::declval<T &>().disable())>> : std::true_type {};
+template <bool ON, class L> __device__ __forceinline__ void loader_disable(L &l) { if constexpr (ON) l.disable(); }
 template <class T, class = void> struct ep_prefetch : std::false_type {};
 template <class T> struct ep_prefetch<T, std::void_t<decltype(T::PREFETCH)>> : std::integral_constant<bool, T::PREFETCH> {};
 template <class T, bool = ep_prefetch<T>::value> struct ep_pre { struct type {}; };
@@ -1154,6 +1172,56 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                     if (mover && more) LOAD(fullc, kbeg + (s + 1) * BKK, pr0, qr0);
                     compute(s & 1, no_hook);
                     if (mover && more) STORE(fullc, (s + 1) & 1, pr0, qr0);
+                    __syncthreads();
+                }
+                return;
+            }
+            // PRELOAD (full k-tiles through the buffer path): EVERY wave issues the tile loads, unconditionally -- the
+            // MFMA-only waves with all offsets out of range, the last trips on the last tile again.  With
+            // `if (mover && s + 2 < nsteps) LOAD(...)` the waves that skip the loads reach the stores' wait with fewer
+            // operations outstanding, the compiler's wait counts are the minimum over both paths, and the movers wait
+            // for the loads they have only just issued: vmcnt(5) .. vmcnt(0) where 11 .. 6 would do -- ONE tile in flight
+            // instead of two, a full load latency per k-step (8 MFMAs per wave) in the 512-wide MLP layers.
+            constexpr bool PRELOAD = decltype(fullc)::value && ld_can_disable<P>::value && ld_can_disable<Q>::value &&
+                                     MVAE_PHASED_PRELOAD;
+            if constexpr (PRELOAD) {
+                if (nsteps <= 0) return;
+                auto tile_k = [&](int s2) { return kbeg + min(s2, nsteps - 1) * BKK; };
+                if (MVAE_PHASED_PRELOAD == 2 && !mover) {
+                    // variant 2: the MFMA-only waves run their own copy of the loop -- the same barriers, no loads --
+                    // so the movers' copy has no control-flow merge between its loads and its stores at all
+                    __syncthreads();
+                    int s = 0;
+                    for (; s + 1 < nsteps; s += 2) {
+                        compute(0, no_hook);
+                        __syncthreads();
+                        compute(1, no_hook);
+                        __syncthreads();
+                    }
+                    if (s < nsteps) {
+                        compute(0, no_hook);
+                        __syncthreads();
+                    }
+                    return;
+                }
+                if (!mover) { loader_disable<PRELOAD>(p); loader_disable<PRELOAD>(q); }     // variant 1
+                LOAD(fullc, tile_k(0), pr0, qr0);
+                LOAD(fullc, tile_k(1), pr1, qr1);
+                if (mover) STORE(fullc, 0, pr0, qr0);
+                __syncthreads();
+                int s = 0;
+                for (; s + 1 < nsteps; s += 2) {
+                    LOAD(fullc, tile_k(s + 2), pr0, qr0);
+                    compute(0, no_hook);
+                    if (mover) STORE(fullc, 1, pr1, qr1);
+                    __syncthreads();
+                    LOAD(fullc, tile_k(s + 3), pr1, qr1);
+                    compute(1, no_hook);
+                    if (mover && s + 2 < nsteps) STORE(fullc, 0, pr0, qr0);
+                    __syncthreads();
+                }
+                if (s < nsteps) {   // odd number of k-steps: the last tile sits in buffer 0
+                    compute(0, no_hook);
                     __syncthreads();
                 }
                 return;
