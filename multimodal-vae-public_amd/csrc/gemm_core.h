@@ -75,6 +75,9 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #else
 #define MVAE_TUNE(f) 0
 #endif
+#ifndef MVAE_FINISH_PREFETCH
+#define MVAE_FINISH_PREFETCH 0
+#endif
 #ifndef MVAE_PHASED_PRELOAD
 #define MVAE_PHASED_PRELOAD 0    // k-grouped blocks, two tiles really in flight (see the phased loop): 1 = every wave issues the tile loads
                                  // (out of range for the MFMA-only waves), 2 = those waves run a load-free copy of the loop.
@@ -1493,16 +1496,32 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
     }
     const int i = (int)(idx / jq), j = (int)(idx - (size_t)i * jq) * 4;
     const float *src = sink.ws + (size_t)i * sink.J + j;
+    // MVAE_FINISH_PREFETCH (off): the four outputs' bias / pre-activation / mask requested before the partial sums instead
+    // of one by one inside put() (this kernel is 2 % of the FashionMNIST and CelebA steps).  Parity green, one
+    // step pair 2.3041 -> 2.3018 ms on FashionMNIST: nothing measurable (profiles/r04_epilogue_ab.txt).
+    constexpr bool PRE = ep_prefetch<E>::value && !E::ROWRED && MVAE_FINISH_PREFETCH;
+    typename ep_pre<E>::type pre[4];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pre[c] = e.fetch(i, j + c);
+    }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int z = 0; z < splits; ++z) {       // four loads in flight, added in split order
         const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)z * sink.stride);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    if (e.col(j)) e.put(i, j, s.x);
-    if (e.col(j + 1)) e.put(i, j + 1, s.y);
-    if (e.col(j + 2)) e.put(i, j + 2, s.z);
-    if (e.col(j + 3)) e.put(i, j + 3, s.w);
+    if constexpr (PRE) {
+        if (e.col(j)) e.put_pre(i, j, s.x, pre[0]);
+        if (e.col(j + 1)) e.put_pre(i, j + 1, s.y, pre[1]);
+        if (e.col(j + 2)) e.put_pre(i, j + 2, s.z, pre[2]);
+        if (e.col(j + 3)) e.put_pre(i, j + 3, s.w, pre[3]);
+    } else {
+        if (e.col(j)) e.put(i, j, s.x);
+        if (e.col(j + 1)) e.put(i, j + 1, s.y);
+        if (e.col(j + 2)) e.put(i, j + 2, s.z);
+        if (e.col(j + 3)) e.put(i, j + 3, s.w);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
