@@ -572,13 +572,24 @@ def _expert_ld(mus, lvs):
     return ld
 
 
+_ALL_EXPERTS = {}
+
+
 def all_experts_mask(n_experts, device):
     """Device mask [1] with the low ``n_experts`` bits set -- the kernel reads it as uint32, the tensor is int32 with
     the same bits ((1 << 32) - 1 does not fit torch.int32: MVAE_MAX_EXPERTS = 32 experts is the all-ones word, -1)."""
     if not 1 <= n_experts <= _lib.MAX_EXPERTS:
         raise RuntimeError('1..%d experts, got %d' % (_lib.MAX_EXPERTS, n_experts))
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (n_experts, str(device))
+    if not capturing and key in _ALL_EXPERTS:
+        return _ALL_EXPERTS[key]          # read-only: one fill launch per (count, device), not one per model() call
     bits = (1 << n_experts) - 1
-    return torch.full((1,), bits - (1 << 32) if bits >= (1 << 31) else bits, dtype=torch.int32, device=device)
+    m = torch.full((1,), bits - (1 << 32) if bits >= (1 << 31) else bits, dtype=torch.int32, device=device)
+    m._mvae_mask_ok = m._version          # non-empty by construction: _check_no_prior_masks need not read it back
+    if not capturing:                     # (a tensor filled under capture only has its contents after a replay)
+        _ALL_EXPERTS[key] = m
+    return m
 
 
 def _check_no_prior_masks(masks_dev, variant, n_experts):
@@ -587,10 +598,18 @@ def _check_no_prior_masks(masks_dev, variant, n_experts):
     masks that only exist on the device (a captured graph's tables) are the caller's to keep non-empty."""
     if not str(variant).endswith('-noprior') or masks_dev.numel() > 64 or torch.cuda.is_current_stream_capturing():
         return
+    # the read-back below is a blocking device-to-host copy: pay it once per mask tensor CONTENT, never per launch
+    # (ADVICE r4: every model() call on the drop-in surface paid it for a mask that is non-empty by construction)
+    if getattr(masks_dev, '_mvae_mask_ok', None) == masks_dev._version:
+        return
     live = (1 << n_experts) - 1
     for t, m in enumerate(masks_dev.tolist()):
         if (m & live) == 0:
             raise RuntimeError('PoE without the built-in prior: term %d selects no expert (mask %#x)' % (t, m & 0xffffffff))
+    try:
+        masks_dev._mvae_mask_ok = masks_dev._version
+    except AttributeError:
+        pass
 
 
 def poe_fwd(mus, lvs, masks_dev, noise, mu, logvar, z, kl, variant):

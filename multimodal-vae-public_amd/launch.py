@@ -75,12 +75,23 @@ def chain_from_env():
     return parse_chain(spec) if spec else default_chain()
 
 
+FAST_FAIL_S = 20.0      # an attempt that dies this fast with rc != 0 gets one retry on a fresh port
+
+
 def free_port(host='127.0.0.1'):
     s = socket.socket()
     s.bind((host, 0))
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def _exited(pid):
+    """True once process ``pid`` (our child) has terminated; it stays a zombie -- its pid and pgid reserved."""
+    try:
+        return os.waitid(os.P_PID, pid, os.WEXITED | os.WNOHANG | os.WNOWAIT) is not None
+    except ChildProcessError:
+        return True
 
 
 def _kill_group(proc):
@@ -116,9 +127,12 @@ def run_attempt(cmd, env, budget_s, poll_s=0.2, peer_failed=None):
         deadline = time.monotonic() + budget_s
         status, polls = None, 0
         while status is None:
-            rc = proc.poll()
+            # look at the child WITHOUT reaping it (WNOWAIT): as long as the group leader is an un-reaped zombie its
+            # pid -- and with it the process-group id killpg() is about to be given -- cannot be recycled
             polls += 1
-            if rc is not None:
+            if _exited(proc.pid):
+                _kill_group(proc)      # stragglers of a finished child (none expected); reaps the leader afterwards
+                rc = proc.returncode
                 status = 'ok' if rc == 0 else 'rc=%d' % rc
             elif time.monotonic() >= deadline:
                 _kill_group(proc)
@@ -128,8 +142,6 @@ def run_attempt(cmd, env, budget_s, poll_s=0.2, peer_failed=None):
                 status = 'peer-failed'
             else:
                 time.sleep(poll_s)
-        if status not in ('timeout', 'peer-failed'):
-            _kill_group(proc)          # stragglers of a finished child (none expected)
         out.seek(0)
         return status, out.read()
 
@@ -148,10 +160,15 @@ def supervise(script, argv, attempts=None, log=None):
                                       timeout=datetime.timedelta(seconds=120)))
     store = dist.PrefixStore('mvae_bench_supervisor', base)
     tried, winner = [], None
-    for a, att in enumerate(attempts):
+    for a0, att in enumerate(attempts):
+      for retry in range(2):
+        # free_port() closes its socket before the child's store binds the port, so another process can take it in
+        # between: the attempt then dies within seconds as rc != 0 and the chain would fall back to a slower transport
+        # for no reason.  Rank 0 grants ONE retry (fresh port) to an attempt that failed that fast.
+        a = '%d.%d' % (a0, retry)
         if rank == 0:
-            store.set('port/%d' % a, str(free_port(host)))
-        child_port = int(store.get('port/%d' % a).decode())
+            store.set('port/%s' % a, str(free_port(host)))
+        child_port = int(store.get('port/%s' % a).decode())
         env = dict(os.environ)
         env.update(att.env)
         env[WORKER_ENV] = '1'
@@ -165,7 +182,7 @@ def supervise(script, argv, attempts=None, log=None):
         def peer_failed(a=a):
             try:
                 for r in range(world):
-                    key = 'out/%d/%d' % (a, r)
+                    key = 'out/%s/%d' % (a, r)
                     if r != rank and store.check([key]) and store.get(key).decode() != 'ok':
                         return True
             except Exception:
@@ -176,12 +193,12 @@ def supervise(script, argv, attempts=None, log=None):
         line = last_json_line(stdout) if rank == 0 else None
         if rank == 0 and status == 'ok' and line is None:
             status = 'no-line'
-        store.set('out/%d/%d' % (a, rank), status)
+        store.set('out/%s/%d' % (a, rank), status)
         # the verdict is collective: every rank must have finished this attempt
         verdicts = []
         deadline = time.monotonic() + att.budget_s + 60.0
         for r in range(world):
-            key = 'out/%d/%d' % (a, r)
+            key = 'out/%s/%d' % (a, r)
             v = None
             while v is None and time.monotonic() < deadline:
                 try:
@@ -193,12 +210,27 @@ def supervise(script, argv, attempts=None, log=None):
                     v = 'store-lost'
             verdicts.append(v or 'silent')
         ok = all(v == 'ok' for v in verdicts)
-        tried.append({'transport': att.name, 'budget_s': att.budget_s, 'wall_s': round(time.monotonic() - t0, 1),
+        wall = time.monotonic() - t0
+        tried.append({'transport': att.name, 'budget_s': att.budget_s, 'wall_s': round(wall, 1),
                       'ranks': verdicts if not ok else 'ok'})
-        log('attempt %d (%s): %s in %.1f s' % (a, att.name, 'ok' if ok else verdicts, time.monotonic() - t0))
+        if retry:
+            tried[-1]['retry'] = retry
+        log('attempt %s (%s): %s in %.1f s' % (a, att.name, 'ok' if ok else verdicts, wall))
         if ok:
             winner = (att, line)
             break
+        again = '0'
+        try:
+            if rank == 0:
+                fast = retry == 0 and wall < FAST_FAIL_S and any(v.startswith('rc=') for v in verdicts)
+                store.set('again/%s' % a, '1' if fast else '0')
+            again = store.get('again/%s' % a).decode()
+        except Exception:
+            pass
+        if again != '1':
+            break
+      if winner is not None:
+        break
     # leave together: the store lives in rank 0's process
     try:
         store.set('bye/%d' % rank, '1')

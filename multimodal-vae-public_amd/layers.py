@@ -613,37 +613,63 @@ class WgradBatch(list):
     def flush(self):
         items, seen = [], set()
         adam = self.adam
+        targets = [(_lin_wgrad_targets(e[1]) if isinstance(e, tuple) else None) for e in self]
+        if adam is not None:
+            # A fused launch applies Adam to the gradient it has just written, so that gradient must be FINAL: exactly
+            # one contribution in this list, not accumulated onto an earlier one, and nothing behind it (a
+            # layer used twice per step got its update on a partial gradient and rest() then skipped it).  Gradients
+            # that do not qualify leave this flush un-fused and stay with the arena-wide launch (rest()).
+            count = {}
+            for tg in targets:
+                if tg is not None:
+                    count[tg[0].data_ptr()] = count.get(tg[0].data_ptr(), 0) + 1
+            fusable = {ptr for ptr, n in count.items() if n == 1}
+        else:
+            fusable = set()
+
+        def guard(dw, db):
+            # a contribution to a gradient some EARLIER fused launch of this step has already consumed cannot be repaired
+            if self.adam is not None and (self.adam.touches(dw) or (db is not None and self.adam.touches(db))):
+                raise RuntimeError('fuse_adam: a weight gradient receives a contribution after a fused launch has '
+                                   'already applied Adam to it (a layer used twice per step): disable MVAE_FUSE_ADAM')
 
         def issue():
-            fused = adam is not None and items and not any(it[4] for it in items)
+            fused = (adam is not None and items
+                     and all((it[0] is None) or (not it[4] and it[2].data_ptr() in fusable) for it in items))
+            for it in items:
+                if it[0] is not None:
+                    guard(it[2], it[3])
             if fused:
                 for it in items:
                     adam.cover(it[2])
                     if it[3] is not None:
                         adam.cover(it[3])
                 K.linear_wgrad_batched(items, adam=adam.struct)
-            elif len(items) == 1:
-                K.linear_wgrad(*items[0][:4], accumulate=items[0][4])
-            elif items:
-                K.linear_wgrad_batched(items)
+            else:
+                real = [it for it in items if it[0] is not None]      # finished gradients wait for rest()
+                if len(real) == 1:
+                    K.linear_wgrad(*real[0][:4], accumulate=real[0][4])
+                elif real:
+                    K.linear_wgrad_batched(real)
             del items[:]
             seen.clear()
 
-        for e in self:
+        for e, tg in zip(self, targets):
             if not isinstance(e, tuple):
                 e()
                 continue
             _, op, g, x = e
-            dw, db, acc = _lin_wgrad_targets(op)
+            dw, db, acc = tg
             if dw.data_ptr() in seen:
-                issue()                     # a second contribution to the same gradient: keep the order
+                issue()                     # a second contribution to the same gradient: keep the order (grad_target made it accumulate)
             if K.wgrad_batchable(g, x):
                 seen.add(dw.data_ptr())
                 items.append((g, x, dw, db, acc))
             else:
+                guard(dw, db)
                 K.linear_wgrad(g, x, dw, db, accumulate=acc)
         if adam is not None and self._final:
-            if any(it[4] for it in items):
+            if any(it[4] or it[2].data_ptr() not in fusable for it in items):
                 issue()
             for grad in self._final:
                 items.append((None, None, grad.reshape(-1), None, False))

@@ -47,6 +47,13 @@ class AdamFusion(object):
                 raise RuntimeError('arena elements [%d, %d) would be updated twice in one step' % (max(lo, a), min(hi, b)))
         self.covered.append((lo, hi))
 
+    def touches(self, grad):
+        """True when ``grad`` overlaps a range a fused launch has ALREADY updated this step: a further contribution
+        to it would arrive after its Adam update (and ``rest()`` would skip the parameter)."""
+        lo = (grad.data_ptr() - self.arena.grad.data_ptr()) // 4
+        hi = lo + grad.numel()
+        return any(lo < b and a < hi for a, b in self.covered)
+
     def rest(self):
         """Arena ranges (whole parameters, merged) no fused launch has updated this step."""
         out, cur = [], None

@@ -269,8 +269,11 @@ def main():
             if b != 4:
                 fx.pop('image')  # regenerate from input_seed (kept for B=4 as a cross-check)
             save('%s_b%d' % (exp, b), fx, meta)
-    fx, meta = run_celeba19(4, noise_seed=1004)
-    save('celeba19_b4', fx, meta)
+    for b in (4, 8):            # B = 4 and B = 8 per experiment
+        fx, meta = run_celeba19(b, noise_seed=1000 + b)
+        if b != 4:
+            fx.pop('image', None)   # regenerated from input_seed by the tests (kept for B = 4 as a cross-check)
+        save('celeba19_b%d' % b, fx, meta)
 
 
 if __name__ == '__main__':

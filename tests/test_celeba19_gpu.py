@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def test_fused_step_matches_reference_golden(golden_dir):
-    fx, meta = load_golden(golden_dir, 'celeba19_b4')
+@pytest.mark.parametrize('batch', [4, 8])
+def test_fused_step_matches_reference_golden(golden_dir, batch):
+    fx, meta = load_golden(golden_dir, 'celeba19_b%d' % batch)
     _, model, d = build_pair('celeba19', meta['weight_seed'])
     B = meta['batch']
     image, attrs = OS.synthetic_batch('celeba19', B, meta['input_seed'])

@@ -10,7 +10,8 @@ import mvae_amd
 from mvae_amd.engine import BimodalStep
 from mvae_amd.optim import FusedAdam
 from oracle import models as OM, steps as OS
-from util import REL_TOL, assert_close, golden_noise, grad_floor, load_golden
+from util import (REL_TOL, assert_close, assert_zero_grad, golden_noise, is_zero_grad, load_golden, note_redraws,
+                  zero_grad_weight)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -33,16 +34,23 @@ def model_kind(model):
 
 def check_grads_vs_golden(model, fx):
     kind = model_kind(model)
-    gmax = max(float(v) for k, v in fx.items() if k.startswith('gnorm/'))
-    hmax = max(float(np.abs(v).max()) for k, v in fx.items() if k.startswith('ghead/'))
-    for name, p in model.named_parameters():
+    params = dict(model.named_parameters())
+    for name, p in params.items():
         assert p.grad is not None, 'no gradient for ' + name
         gv = p.grad.detach().reshape(-1).cpu()
         ref_norm = float(fx['gnorm/' + name])
-        err = abs(gv.double().norm().item() - ref_norm) / max(ref_norm, grad_floor(kind, name, gmax), 1e-30)
+        if is_zero_grad(kind, name):
+            # exactly zero in exact arithmetic: each side must be round-off of the same layer's weight gradient
+            wn = zero_grad_weight(name)
+            assert_zero_grad(name, gv.abs().max().item(), params[wn].grad.abs().max().item(), 'HIP')
+            # the fixture keeps norms, not maxima: |g|_2 <= sqrt(n) max|g| and max|g_w| >= |g_w|_2 / sqrt(n_w)
+            w_rms = float(fx['gnorm/' + wn]) / params[wn].numel() ** 0.5
+            assert_zero_grad(name, ref_norm / gv.numel() ** 0.5, w_rms * 10.0, 'reference fixture (rms)')
+            continue
+        err = abs(gv.double().norm().item() - ref_norm) / max(ref_norm, 1e-30)
         assert err <= REL_TOL, 'grad norm %s: %.3e' % (name, err)
         ref = fx['ghead/' + name]
-        scale = max(float(np.abs(ref).max()), ref_norm / max(gv.numel(), 1) ** 0.5, grad_floor(kind, name, hmax), 1e-30)
+        scale = max(float(np.abs(ref).max()), ref_norm / max(gv.numel(), 1) ** 0.5, 1e-30)
         err = np.abs(gv[:8].numpy() - ref).max() / scale
         assert err <= REL_TOL, 'grad head %s: %.3e' % (name, err)
 
@@ -50,12 +58,17 @@ def check_grads_vs_golden(model, fx):
 def check_grads_vs_oracle(model, oracle, tol=REL_TOL):
     kind = model_kind(model)
     og = dict(oracle.named_parameters())
-    gmax = max(p.grad.abs().max().item() for p in og.values())
+    params = dict(model.named_parameters())
     worst, bad = 0.0, []
-    for name, p in model.named_parameters():
+    for name, p in params.items():
         assert p.grad is not None, 'no gradient for ' + name
         ref = og[name].grad
-        scale = max(ref.abs().max().item(), grad_floor(kind, name, gmax), 1e-30)
+        if is_zero_grad(kind, name):
+            wn = zero_grad_weight(name)
+            assert_zero_grad(name, p.grad.abs().max().item(), params[wn].grad.abs().max().item(), 'HIP')
+            assert_zero_grad(name, ref.abs().max().item(), og[wn].grad.abs().max().item(), 'oracle')
+            continue
+        scale = max(ref.abs().max().item(), 1e-30)
         err = (p.grad.detach().cpu() - ref).abs().max().item() / scale
         if err > tol:
             bad.append('%s %.3e' % (name, err))
@@ -164,6 +177,7 @@ def test_fused_step_matches_live_oracle_at_baseline_batch(kind, batch):
           % (kind, batch, worst, attempt))
     # an exact zero among 10^5..10^7 fp32 logits is a rare accident of one draw; a kernel that MANUFACTURED zeros would
     # need re-draw after re-draw -- that must fail, not be retried away
+    note_redraws('engine eager %s B=%d' % (kind, batch), attempt)
     assert attempt <= 1, '%d re-draws for exactly-zero logits' % attempt
 
 

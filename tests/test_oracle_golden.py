@@ -70,11 +70,16 @@ def test_noise_replay_matches_global_generator(golden_dir):
     assert noise['mask'][2] is None
 
 
-def test_celeba19_step_matches_reference(golden_dir):
+@pytest.mark.parametrize('batch', [4, 8])
+def test_celeba19_step_matches_reference(golden_dir, batch):
     torch.set_num_threads(4)
-    fx, meta = load_golden(golden_dir, 'celeba19_b4')
+    fx, meta = load_golden(golden_dir, 'celeba19_b%d' % batch)
+    assert meta['batch'] == batch
     model = _build('celeba19', meta)
     image, attrs = OS.synthetic_batch('celeba19', meta['batch'], meta['input_seed'])
+    if 'image' in fx:
+        assert np.array_equal(image.numpy(), fx['image'])
+    assert np.array_equal(attrs.numpy(), fx['label'])
     terms = OS.celeba19_terms(fx['combos'].astype(bool))
     assert len(terms) == 20 + meta['approx_m']
     noise = golden_noise(fx, len(terms))

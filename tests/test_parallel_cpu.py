@@ -185,7 +185,9 @@ def test_transport_chain_survives_a_hang_and_a_crash():
     assert rc == 0, err[-3000:]
     assert line['n_gpus'] == 2 and line['dist']['allreduce_of_ones'] == 2.0
     tried = line['dist']['fallbacks_tried']
-    assert [t['transport'] for t in tried] == ['fake-hang', 'fake-raise']
+    # (an attempt that dies within seconds with rc != 0 is granted ONE retry on a fresh rendezvous port: launch.py)
+    assert [t['transport'] for t in tried if not t.get('retry')] == ['fake-hang', 'fake-raise']
+    assert [t['transport'] for t in tried if t.get('retry')] in ([], ['fake-raise'])
     assert 'timeout' in tried[0]['ranks'] or 'peer-failed' in tried[0]['ranks']
     assert any(v.startswith('rc=') for v in tried[1]['ranks'])
     assert line['dist']['transport_attempt'] == 'default'

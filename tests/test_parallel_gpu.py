@@ -147,7 +147,7 @@ def test_two_ranks_average_shard_gradients(kind, batch, n_buckets, tmp_path):
     reference's per-shard gradients at shared weights, each shard with its own noise."""
     import numpy as np
     import torch.multiprocessing as mp
-    from util import grad_floor
+    from util import assert_zero_grad, is_zero_grad, zero_grad_weight
     world, port = 2, _free_port()
     mp.spawn(_two_rank_worker, args=(world, port, kind, batch, str(tmp_path)), nprocs=world, join=True)
     g0 = np.load(str(tmp_path / 'grad_sum_rank0.npy')); g1 = np.load(str(tmp_path / 'grad_sum_rank1.npy'))
@@ -180,14 +180,24 @@ def test_two_ranks_average_shard_gradients(kind, batch, n_buckets, tmp_path):
         grads = {n: p.grad.clone() for n, p in oracle.named_parameters()}
         sums = grads if sums is None else {n: sums[n] + grads[n] for n in sums}
     model.finalize()
-    gmax = max(v.abs().max().item() for v in sums.values())
     flat = torch.from_numpy(g0)
     bad = []
-    for name, p in model.named_parameters():
-        off = p.data_ptr() - model.arena.flat.data_ptr()
-        got = flat[off // 4:off // 4 + p.numel()].reshape(p.shape)
+    params = dict(model.named_parameters())
+
+    def reduced(name):
+        q = params[name]
+        off = q.data_ptr() - model.arena.flat.data_ptr()
+        return flat[off // 4:off // 4 + q.numel()].reshape(q.shape)
+
+    for name, p in params.items():
+        got = reduced(name)
         ref = sums[name]
-        scale = max(ref.abs().max().item(), grad_floor(kind, name, gmax), 1e-30)
+        if is_zero_grad(kind, name):     # exactly zero in exact arithmetic: round-off on each side (tests/util.py)
+            wn = zero_grad_weight(name)
+            assert_zero_grad(name, got.abs().max().item(), reduced(wn).abs().max().item(), 'HIP, summed over ranks')
+            assert_zero_grad(name, ref.abs().max().item(), sums[wn].abs().max().item(), 'oracle, summed over shards')
+            continue
+        scale = max(ref.abs().max().item(), 1e-30)
         err = (got - ref).abs().max().item() / scale
         if err > 1e-4:
             bad.append('%s %.3e' % (name, err))

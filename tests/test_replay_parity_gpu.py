@@ -23,7 +23,7 @@ from mvae_amd.optim import FusedAdam
 from mvae_amd.parallel import DataParallel
 from oracle import steps as OS
 from test_engine_gpu import build_pair, check_bn_vs, check_grads_vs_oracle, hits_bce_jump
-from util import ZERO_GRAD_PARAMS, assert_close
+from util import ZERO_GRAD_PARAMS, assert_close, note_redraws
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -164,6 +164,7 @@ def test_replayed_step_matches_oracle_at_baseline_batch(rccl_world1, kind, batch
     _check_adam(kind, model, oracle, w0, g_hip, w1)
     print('%s B=%d %s: replayed step vs oracle, worst gradient rel err %.2e, %d input re-draw(s) for an exact-zero '
           'logit' % (kind, batch, 'dp (collectives in the graph)' if use_dp else 'one graph', worst, redraws))
+    note_redraws('replay %s B=%d %s' % (kind, batch, 'dp' if use_dp else 'one graph'), redraws)
     assert redraws <= 1, '%d re-draws for exactly-zero logits: a kernel manufacturing zeros must fail, not be retried away' % redraws
 
 
