@@ -571,6 +571,14 @@ const char *mvae_comm_last_error(const mvae_comm_t *comm);
 int mvae_comm_broadcast(mvae_comm_t *comm, void *buf, size_t bytes, int root, mvae_stream_t stream);
 int mvae_comm_allreduce_async(mvae_comm_t *comm, float *buf, size_t count, mvae_stream_t stream, int *ticket);
 int mvae_comm_wait(mvae_comm_t *comm, int ticket /* < 0: everything issued so far */, mvae_stream_t stream);
+/* Failure detection (ABI 5).  mvae_comm_async_error: MVAE_ERR_COMM once a collective of this communicator has failed
+ * asynchronously (ncclCommGetAsyncError; MVAE_OK when the bound library has no such entry).  mvae_comm_synchronize is
+ * the watchdog a host puts where it would otherwise call hipStreamSynchronize: it blocks until everything enqueued
+ * on `stream` so far -- after mvae_comm_wait that includes the collectives -- has finished, for at most timeout_ms,
+ * polling the asynchronous error state meanwhile; MVAE_ERR_COMM = a peer failed or the budget ran out (the
+ * collective of a dead peer never completes), after which the communicator must be abandoned.  Not capturable. */
+int mvae_comm_async_error(mvae_comm_t *comm);
+int mvae_comm_synchronize(mvae_comm_t *comm, mvae_stream_t stream, int timeout_ms);
 int mvae_comm_destroy(mvae_comm_t *comm);
 
 #ifdef MVAE_TUNING

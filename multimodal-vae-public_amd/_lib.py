@@ -167,6 +167,8 @@ _SIGNATURES = {
     'mvae_comm_broadcast': (c_int, [P, P, c_size_t, c_int, P]),
     'mvae_comm_allreduce_async': (c_int, [P, P, c_size_t, P, ctypes.POINTER(c_int)]),
     'mvae_comm_wait': (c_int, [P, c_int, P]),
+    'mvae_comm_async_error': (c_int, [P]),
+    'mvae_comm_synchronize': (c_int, [P, P, c_int]),
     'mvae_comm_destroy': (c_int, [P]),
 }
 
@@ -207,7 +209,7 @@ def lib():
             if fn is not None:
                 fn.restype = res
                 fn.argtypes = args
-        if handle.mvae_abi_version() != 4:
+        if handle.mvae_abi_version() != 5:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle
     return _lib

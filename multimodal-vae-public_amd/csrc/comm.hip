@@ -17,10 +17,12 @@
 // never loads it, and a PyTorch host can point MVAE_RCCL_LIB (or mvae_comm_use_library) at the librccl.so its
 // torch already loaded so the process holds one copy.  No global mutable state other than that binding.
 #include <dlfcn.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 
 #include <rccl/rccl.h>      // types and enums only; every call goes through the table below
@@ -38,6 +40,7 @@ struct RcclApi {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;     // optional (mvae_comm_async_error)
     char path[512] = {0};
 };
 
@@ -57,6 +60,7 @@ bool bind_all(RcclApi &a, void *h) {
     MVAE_BIND(GetVersion, "ncclGetVersion")
     MVAE_BIND(GetErrorString, "ncclGetErrorString")
 #undef MVAE_BIND
+    *(void **)(&a.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");      // absent: async errors are not observable
     return true;
 }
 
@@ -242,6 +246,54 @@ MVAE_EXPORT int mvae_comm_broadcast(mvae_comm_t *c, void *buf, size_t bytes, int
     if (rc == MVAE_OK) rc = hip_check(c, hipEventRecord(c->done[slot], c->stream), "hipEventRecord(done)");
     if (rc == MVAE_OK) rc = hip_check(c, hipStreamWaitEvent((hipStream_t)stream, c->done[slot], 0), "hipStreamWaitEvent(consumer)");
     if (rc == MVAE_OK) c->issued++;
+    return rc;
+}
+
+// Has a collective of this communicator failed asynchronously (a peer died, a link error)?  MVAE_OK / MVAE_ERR_COMM.
+MVAE_EXPORT int mvae_comm_async_error(mvae_comm_t *c) {
+    if (!c) return MVAE_ERR_ARG;
+    const RcclApi *api = rccl();
+    if (!api) return MVAE_ERR_COMM;
+    if (!api->CommGetAsyncError) return MVAE_OK;
+    ncclResult_t async = ncclSuccess;
+    const ncclResult_t r = api->CommGetAsyncError(c->nccl, &async);
+    if (r != ncclSuccess) return nccl_check(c, api, r, "ncclCommGetAsyncError");
+    if (async == ncclSuccess || async == ncclInProgress) return MVAE_OK;
+    return nccl_check(c, api, async, "asynchronous communicator error");
+}
+
+// The watchdog: block the HOST until everything enqueued on `stream` so far has finished -- which, after
+// mvae_comm_wait, includes the collectives -- but for at most `timeout_ms`, polling the communicator's asynchronous
+// error state meanwhile.  A collective whose peer is gone never completes; hipStreamSynchronize would hang for good.
+// MVAE_OK: finished, no error.  MVAE_ERR_COMM: a peer failed or the budget ran out (text: mvae_comm_last_error);
+// the communicator must then be abandoned (the process cannot cancel the work still enqueued).  Not capturable.
+MVAE_EXPORT int mvae_comm_synchronize(mvae_comm_t *c, mvae_stream_t stream, int timeout_ms) {
+    if (!c || timeout_ms < 0) return MVAE_ERR_ARG;
+    hipEvent_t ev;
+    int rc = hip_check(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate(watchdog)");
+    if (rc != MVAE_OK) return rc;
+    rc = hip_check(c, hipEventRecord(ev, (hipStream_t)stream), "hipEventRecord(watchdog)");
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned polls = 0;
+    while (rc == MVAE_OK) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) { rc = mvae_comm_async_error(c); break; }      // done: but did it finish by giving up on a peer?
+        if (q != hipErrorNotReady) { rc = hip_check(c, q, "hipEventQuery(watchdog)"); break; }
+        if ((++polls & 63u) == 0) {
+            rc = mvae_comm_async_error(c);
+            if (rc != MVAE_OK) break;
+            const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > timeout_ms) {
+                char msg[96];
+                snprintf(msg, sizeof(msg), "stream work incl. collectives not finished within %d ms", timeout_ms);
+                rc = comm_fail(c, "watchdog", msg);
+                break;
+            }
+        }
+        sched_yield();
+    }
+    // an event with work still pending behind it is released by the runtime when that work retires
+    (void)hipEventDestroy(ev);
     return rc;
 }
 

@@ -11,7 +11,7 @@
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-MVAE_EXPORT int mvae_abi_version(void) { return 4; }
+MVAE_EXPORT int mvae_abi_version(void) { return 5; }
 
 #ifdef MVAE_TUNING
 // tuning build only (libmvae_hip_tuning.so): force tile shapes / split counts for tools/gemm_bench.py

@@ -246,6 +246,269 @@ template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(
     else wgrad_direct_tile<false, KW, 0, ADAM>(w.dy, w.lddy, w.x, w.ldx, e, w.I, w.J, w.M, nullptr, 0, tile_i, tile_j, af);
 }
 
+// ------------------------------------------------------------------------------------------
+// Version 2 of the batched launch (round 5).  What was wrong with the one above, measured
+// (profiles/r04_mnist_by_shape.txt, r04_traffic.json, r04_mnist_step_timeline.txt):
+//   * 25-28 us per launch for 12.5 us of matrix time, while the launch moved 74.7 MB through the fabric for 19.9 MB of
+//     operands -- the tiles of a layer went round-robin over the 8 XCDs, so every L2 pulled (nearly) every row band of
+//     dy, and a 32 x 32 tile fed straight from global memory is two loads per MFMA (8 FLOP per byte at the cache);
+//   * 936 blocks of 256 threads hold every CU slot for the whole launch: the 512^3 data gradient that starts 3 us
+//     later on the other stream -- and IS on the critical chain -- waits for them (27.9 us instead of 7-9).
+// Here
+//   * a wave owns FM x FN MFMA tiles (64 x 64 or 64 x 32 outputs): an A fragment feeds FN MFMAs and a B fragment FM,
+//     1 - 1.5 loads per MFMA instead of 2;
+//   * fragments arrive through raw buffer loads whose descriptor covers exactly the operand: rows beyond the batch,
+//     surplus chunks and the last row's columns beyond the matrix read as zero in hardware -- the main loop has no
+//     clamp, no select and no multiply by a 0/1 flag left (a VALU instruction costs fp32-MFMA throughput);
+//   * the tile list -- (layer, i band, j band), i-major -- is cut into 8 contiguous segments and XCD x (blocks
+//     x, x + 8, ... of the launch order) walks segment x: a layer's tiles sit on as few XCDs as its share of the work,
+//     an XCD's resident blocks share one or two row bands of dy and sweep x together;
+//   * fewer, larger blocks (<= 2 per CU through the LDS footprint of the final reduction) leave wave slots, registers
+//     and LDS on every CU for a chain kernel that arrives while the batch is running.
+constexpr int WB2_SEGS = 8;
+struct WgradBatch2Args { WgradBatchItem it[WGRAD_BATCH_MAX]; int n; int seg[WB2_SEGS + 1]; };
+
+// descriptor of `extent` bytes at b + off (off, extent: wave-uniform); nothing is readable when off >= extent
+__device__ __forceinline__ i32x4_t wb2_rsrc(BufBase b, unsigned off, unsigned extent) {
+    const unsigned long long a = (((unsigned long long)b.hi << 32) | b.lo) + off;
+    i32x4_t r;
+    r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    // signed (the host keeps extents and offsets below 2^31): `off < extent ? extent - off : 0` on unsigned values becomes a
+    // saturating subtract, which only the VECTOR ALU has -- the descriptor then lives in vector registers and every load
+    // in a waterfall loop
+    const int left = (int)extent - (int)off;
+    r.z = left > 0 ? left : 0; r.w = 0x00020000;
+    return r;
+}
+
+template <int KW, int FM, int FN, int PD>
+__device__ __forceinline__ void wgrad_tile2(const WgradBatchItem &w, int tile_i, int tile_j) {
+    extern __shared__ __attribute__((aligned(16))) float wd_lds[];
+    constexpr int TM = 32 * FM, TN = 32 * FN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int kg = __builtin_amdgcn_readfirstlane(t >> 6);          // wave-uniform, and provably so
+    const int lcol = lane & 31, lrow = lane >> 5;
+    const int i0 = tile_i * TM, j0 = tile_j * TN;
+    const BufBase ba = buf_base(w.dy), bb = buf_base(w.x);
+    // the table entry was picked with a run-time index: the compiler holds its fields in vector registers and would wrap
+    // every buffer load in a waterfall loop -- everything a descriptor is built from goes through readfirstlane once
+    const int M = __builtin_amdgcn_readfirstlane(w.M), I = __builtin_amdgcn_readfirstlane(w.I), J = __builtin_amdgcn_readfirstlane(w.J);
+    const unsigned ulda = (unsigned)__builtin_amdgcn_readfirstlane(w.lddy) * 4u;    // row strides in bytes
+    const unsigned uldb = (unsigned)__builtin_amdgcn_readfirstlane(w.ldx) * 4u;
+    // the operands end with the last row's last REAL column (a [M, ld] view of a wider tensor owns nothing behind it)
+    const unsigned ext_a = (unsigned)(M - 1) * ulda + (unsigned)I * 4u;
+    const unsigned ext_b = (unsigned)(M - 1) * uldb + (unsigned)J * 4u;
+    // lane (c, h) supplies rows 4 h + q of a chunk of 8 to MFMA q, column c of fragment f (+ 128 f bytes: an immediate).
+    // A column beyond the matrix is NOT clamped: it reads a neighbour (finite or not) and only reaches outputs the
+    // epilogue drops -- column i of dy feeds row i of the product and nothing else.
+    int va[4], vb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        va[q] = (int)((unsigned)(4 * lrow + q) * ulda + (unsigned)(i0 + lcol) * 4u);
+        vb[q] = (int)((unsigned)(4 * lrow + q) * uldb + (unsigned)(j0 + lcol) * 4u);
+    }
+    const bool rs_block = w.db != nullptr && tile_j == 0;           // block-uniform: this tile also sums dy's columns
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float rs[FM];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) rs[a] = 0.f;
+
+    const int nchunks = (M + 7) >> 3;
+    const int n_it = (nchunks + KW - 1) / KW;                       // per wave; chunks kg, kg + KW, ... (surplus ones read zeros)
+    float a0[PD][FM][4], b0[PD][FN][4], a1[PD][FM][4], b1[PD][FN][4];
+    auto load_set = [&](int first, float (&as)[PD][FM][4], float (&bs)[PD][FN][4]) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const unsigned c = (unsigned)(kg + (first + p) * KW);    // chunk index (scalar)
+            const i32x4_t ra = wb2_rsrc(ba, c * 8u * ulda, ext_a), rb = wb2_rsrc(bb, c * 8u * uldb, ext_b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) as[p][f][q] = buf_load1(ra, va[q] + 128 * f);
+#pragma unroll
+                for (int f = 0; f < FN; ++f) bs[p][f][q] = buf_load1(rb, vb[q] + 128 * f);
+            }
+        }
+    };
+    auto use_set = [&](const float (&as)[PD][FM][4], const float (&bs)[PD][FN][4]) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+#pragma unroll
+                    for (int g = 0; g < FN; ++g)
+                        acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[p][f][q], bs[p][g][q], acc[f][g], 0, 0, 0);
+            if (rs_block) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f) rs[f] += (as[p][f][0] + as[p][f][1]) + (as[p][f][2] + as[p][f][3]);
+            }
+        }
+    };
+    // two register sets: one is multiplied while the other is in flight (see wgrad_direct_tile on why not a rotating one)
+    load_set(0, a0, b0);
+    for (int it = 0; it < n_it; it += 2 * PD) {
+        load_set(it + PD, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        use_set(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set(it + 2 * PD, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        use_set(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the KW partial tiles through LDS in halves (the upper half of the waves parks, the lower half adds: a fixed
+    //      tree), the last sum back to LDS, epilogue with every thread
+    constexpr int TP = TN + 1;
+    constexpr int WTILE = TM * TP;                                  // floats per parked wave tile
+    auto park = [&](float *dst) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f)
+#pragma unroll
+            for (int g = 0; g < FN; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dst[(32 * f + 4 * lrow + (r & 3) + 8 * (r >> 2)) * TP + 32 * g + lcol] = acc[f][g][r];
+    };
+    float *rsl = wd_lds + (KW > 1 ? KW / 2 : 1) * WTILE;           // [KW][2][TM] partial column sums of dy
+    if (rs_block) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) rsl[(kg * 2 + lrow) * TM + 32 * f + lcol] = rs[f];
+    }
+#pragma unroll
+    for (int half = KW / 2; half >= 1; half >>= 1) {
+        if (kg >= half && kg < 2 * half) park(wd_lds + (kg - half) * WTILE);
+        __syncthreads();
+        if (kg < half) {
+            const float *src = wd_lds + kg * WTILE;
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int g = 0; g < FN; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[f][g][r] += src[(32 * f + 4 * lrow + (r & 3) + 8 * (r >> 2)) * TP + 32 * g + lcol];
+        }
+        __syncthreads();
+    }
+    if (kg == 0) park(wd_lds);
+    __syncthreads();
+    float *dw = w.dw;
+    const int acc_flag = w.accumulate;
+    constexpr int NE = TM * TN / (64 * KW);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int el = t + k * 64 * KW;
+        const int il = el / TN, jl = el % TN;
+        const int i = i0 + il, j = j0 + jl;
+        if (i < I && j < J) {
+            float v = wd_lds[il * TP + jl];
+            float *dst = dw + (size_t)i * J + j;
+            if (acc_flag) v += *dst;
+            *dst = v;
+        }
+    }
+    if (rs_block && t < TM && i0 + t < I) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 2 * KW; ++g2) s2 += rsl[g2 * TM + t];
+        if (acc_flag) s2 += w.db[i0 + t];
+        w.db[i0 + t] = s2;
+    }
+}
+
+template <int KW, int FM, int FN, int PD>
+__global__ __launch_bounds__(64 * KW) void wgrad_batched2_kernel(WgradBatch2Args a) {
+    // XCD x = blocks x, x + 8, ... of the launch order; it walks segment x of the tile list
+    const int xcd = blockIdx.x & (WB2_SEGS - 1), slot = blockIdx.x >> 3;
+    const int tile = a.seg[xcd] + slot;
+    if (tile >= a.seg[xcd + 1]) return;
+    int p = 0, first = 0;
+#pragma unroll 1
+    for (int q = 0; q < a.n - 1; ++q) {
+        if (tile >= a.it[q].tile_end) { p = q + 1; first = a.it[q].tile_end; }
+    }
+    const WgradBatchItem &w = a.it[p];
+    const int local = tile - first;
+    const int tile_i = local / w.tiles_j, tile_j = local - tile_i * w.tiles_j;
+    wgrad_tile2<KW, FM, FN, PD>(w, tile_i, tile_j);
+}
+
+#ifndef MVAE_WGRAD2
+#define MVAE_WGRAD2 1            // 0: the round-4 batch kernel (wgrad_batched_kernel) for every launch
+#endif
+#ifndef MVAE_WGRAD2_SHAPE
+#define MVAE_WGRAD2_SHAPE 0      // 0: by tile count; 22 / 21 / 11: force the 64 x 64 / 64 x 32 / 32 x 32 wave tile (A/B builds)
+#endif
+
+// Re-tile the table for FM x FN wave tiles, cut it into XCD segments, launch.  Returns false when the batch has an
+// item the v2 tile code does not take (none today: kept for the Adam-fused form, which stays on the old kernel).
+inline bool wgrad_batched2_launch(const WgradBatchArgs &a, hipStream_t st, int *status) {
+    if (!MVAE_WGRAD2) return false;
+    long t22 = 0, t21 = 0, t11 = 0;
+    int max_m = 0;
+    for (int q = 0; q < a.n; ++q) {
+        const WgradBatchItem &w = a.it[q];
+        if (!w.dy) return false;
+        t22 += cdiv(w.I, 64) * cdiv(w.J, 64); t21 += cdiv(w.I, 64) * cdiv(w.J, 32); t11 += cdiv(w.I, 32) * cdiv(w.J, 32);
+        if (w.M > max_m) max_m = w.M;
+        // byte offsets of (surplus) chunks stay below 2^31 (signed in wb2_rsrc): the prefetch runs up to 8 * 16 * 5 rows past the batch
+        const long over = (long)w.M + 8 * 16 * 5;
+        if (over * w.lddy * 4 >= (1L << 31) || over * w.ldx * 4 >= (1L << 31)) return false;
+    }
+    // wave tile: the largest whose tiles still give every CU a block; waves per tile: ~2 per SIMD over the launch, at
+    // least 4 chunks of 8 rows each
+    int shape = t22 >= 200 ? 22 : (t21 >= 200 ? 21 : 11);
+    if (MVAE_WGRAD2_SHAPE) shape = MVAE_WGRAD2_SHAPE;
+    const long tiles = shape == 22 ? t22 : (shape == 21 ? t21 : t11);
+    const int fm = shape == 11 ? 1 : 2, fn = shape == 22 ? 2 : 1;
+    int kw = tiles >= 1024 ? 2 : (tiles >= 400 ? 4 : (tiles >= 160 ? 8 : 16));
+    if (shape == 22 && kw < 4) kw = 4;
+    while (kw > 2 && max_m < 8 * 4 * kw) kw >>= 1;
+    if (shape == 11 && kw < 4) kw = 4;
+    WgradBatch2Args b;
+    b.n = a.n;
+    int total = 0;
+    for (int q = 0; q < a.n; ++q) {
+        b.it[q] = a.it[q];
+        b.it[q].tiles_j = (int)cdiv(a.it[q].J, 32 * fn);
+        total += (int)cdiv(a.it[q].I, 32 * fm) * b.it[q].tiles_j;
+        b.it[q].tile_end = total;
+    }
+    int longest = 0;
+    for (int x = 0; x <= WB2_SEGS; ++x) b.seg[x] = (int)((long)total * x / WB2_SEGS);
+    for (int x = 0; x < WB2_SEGS; ++x) if (b.seg[x + 1] - b.seg[x] > longest) longest = b.seg[x + 1] - b.seg[x];
+    const dim3 grid((unsigned)(longest * WB2_SEGS));
+#define MVAE_WB2(KWV, FMV, FNV, PDV)                                                                          \
+    {                                                                                                         \
+        constexpr size_t lds = ((size_t)(KWV > 1 ? KWV / 2 : 1) * (32 * FMV) * (32 * FNV + 1) + (size_t)KWV * 2 * 32 * FMV) * sizeof(float); \
+        auto kern = wgrad_batched2_kernel<KWV, FMV, FNV, PDV>;                                                \
+        static bool attr_done = false;                                                                        \
+        if (!attr_done) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_done = true;                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * KWV), lds, st, b);                                           \
+    }
+    if (shape == 22) {
+        if (kw >= 16) MVAE_WB2(16, 2, 2, 1) else if (kw == 8) MVAE_WB2(8, 2, 2, 2) else MVAE_WB2(4, 2, 2, 2)
+    } else if (shape == 21) {
+        if (kw >= 16) MVAE_WB2(16, 2, 1, 2) else if (kw == 8) MVAE_WB2(8, 2, 1, 2) else if (kw == 4) MVAE_WB2(4, 2, 1, 3) else MVAE_WB2(2, 2, 1, 3)
+    } else {
+        if (kw >= 16) MVAE_WB2(16, 1, 1, 4) else if (kw == 8) MVAE_WB2(8, 1, 1, 4) else MVAE_WB2(4, 1, 1, 4)
+    }
+#undef MVAE_WB2
+    *status = mvae_launch_status();
+    return true;
+}
+
 // shapes the direct tile code serves well on its own merits (32-bit byte offsets inside the operands included)
 inline bool wgrad_batch_item_ok(int I, int J, int M, int lddy, int ldx) {
     const long tiles = cdiv(I, 32) * cdiv(J, 32);
@@ -253,6 +516,10 @@ inline bool wgrad_batch_item_ok(int I, int J, int M, int lddy, int ldx) {
 }
 
 inline int wgrad_batched_launch(WgradBatchArgs &a, hipStream_t st, const AdamFuse *adam = nullptr) {
+    if (!adam) {
+        int status = MVAE_OK;
+        if (wgrad_batched2_launch(a, st, &status)) return status;
+    }
     const int total = a.it[a.n - 1].tile_end;
     // waves per tile: enough blocks x waves to put ~4 waves on every SIMD, a reduction slice of >= 4 chunks each
     const int kw = total >= 768 ? 4 : (total >= 256 ? 8 : 16);

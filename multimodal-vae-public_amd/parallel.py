@@ -221,6 +221,23 @@ class RcclComm(object):
         if not bool((y == expect).all().item()):
             raise RuntimeError('captured all-reduce self-check: got %r, expected %r' % (y[0].item(), expect))
 
+    def async_error(self):
+        """Raise if a collective of this communicator has failed asynchronously (a peer died, a link error)."""
+        self._check(self._lib.mvae_comm_async_error(self._h), 'mvae_comm_async_error')
+
+    def synchronize(self, timeout_s=60.0):
+        """The watchdog (``mvae_comm_synchronize``): block until the current stream's work -- after ``wait`` that
+        includes the collectives -- has finished, for at most ``timeout_s``; raises RuntimeError when a peer failed or
+        the budget ran out (a collective whose peer is gone never completes: ``torch.cuda.synchronize`` would hang
+        for good).  After a raise the communicator must be abandoned (``abandon()``), not destroyed."""
+        self._check(self._lib.mvae_comm_synchronize(self._h, self._stream(), int(timeout_s * 1000.0)),
+                    'mvae_comm_synchronize')
+
+    def abandon(self):
+        """Forget the communicator without draining its stream (``destroy`` would wait for a collective that can
+        never finish)."""
+        self._h = None
+
     def destroy(self):
         if self._h is not None:
             self._lib.mvae_comm_destroy(self._h)
@@ -278,7 +295,11 @@ class DataParallel(object):
                              'across processes is expected to fail with hipIpcGetMemHandle: invalid argument; export '
                              'HSA_ENABLE_IPC_MODE_LEGACY=0 before the process first touches the GPU\n'
                              % os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])
-        if want == 'rccl' and dist.get_backend(group) == 'nccl' and arena.flat.is_cuda:
+        # the communicator needs torch.distributed only to carry its 128-byte id, so an EXPLICIT ``transport='rccl'``
+        # also works over a gloo group (tests/test_comm_world2_gpu.py: two ranks on one GPU over a stand-in library);
+        # the MVAE_COMM default only applies where torch.distributed itself runs on RCCL
+        explicit = transport == 'rccl'
+        if want == 'rccl' and (explicit or dist.get_backend(group) == 'nccl') and arena.flat.is_cuda:
             why = None
             try:
                 self.comm = RcclComm.from_process_group(arena.flat.device, group)
@@ -325,6 +346,15 @@ class DataParallel(object):
 
     def wait(self, k=None):
         self.buckets.wait(k)
+
+    def synchronize(self, timeout_s=60.0):
+        """Host-side fence with a watchdog: like ``torch.cuda.synchronize()`` but raises RuntimeError when a peer has
+        failed or the step has not finished within ``timeout_s`` (only the library's communicator can tell; the
+        torch.distributed transport falls back to its own process-group timeout)."""
+        if self.comm is not None:
+            self.comm.synchronize(timeout_s)
+        else:
+            torch.cuda.synchronize()
 
     def finish(self, optimizer):
         """The optimizer step of a data-parallel replica: per bucket, fence its all-reduce and run Adam on

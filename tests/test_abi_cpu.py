@@ -32,7 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
-    assert handle.mvae_abi_version() == 4
+    assert handle.mvae_abi_version() == 5
+
+
+def test_shared_memory_nccl_stand_in_exports_what_the_communicator_binds():
+    """tests/shm_nccl (test infrastructure for the world-2 GPU test): every symbol csrc/comm.hip resolves with dlsym."""
+    path = os.path.join(ROOT, 'tests', 'shm_nccl', 'libshm_nccl.so')
+    assert os.path.exists(path), 'libshm_nccl.so is not built: run __graft_entry__.build()'
+    text = open(os.path.join(ROOT, 'multimodal-vae-public_amd', 'csrc', 'comm.hip')).read()
+    wanted = sorted(set(re.findall(r'"(nccl[A-Za-z]+)"', text)))
+    assert 'ncclAllReduce' in wanted and 'ncclCommGetAsyncError' in wanted and len(wanted) == 8
+    handle = ctypes.CDLL(path)
+    for name in wanted:
+        assert hasattr(handle, name), name
+    v = ctypes.c_int(0)
+    assert handle.ncclGetVersion(ctypes.byref(v)) == 0 and v.value == 10000
 
 
 def test_product_library_has_no_tuning_state():
