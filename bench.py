@@ -17,7 +17,9 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries
                    left them.  ``hot_cache_reissue`` = the same call re-issued back to back in a hipGraph
                    (round 1's figure), ``conv_kernels`` / ``all_gemm_kernels`` = the in-situ aggregates,
                    ``top_hbm_kernel`` = the HBM-bound kernel with the most time, ``traffic`` = HBM-side bytes
-                   per launch from the committed PMC tables (profiles/r03_traffic.json, r02_traffic.json),
+                   per launch from the committed PMC table (profiles/r05_traffic.json) -- like ``rocprof_avg_us`` a
+                   QUOTED figure: ``committed_profiles`` says on which code it was collected, ``profile_stale`` is
+                   true when that is not this tree's kernel sources; ``other_workloads`` = the `also` list, compact,
   cpu_baseline  -- the oracle (CPU restatement of the reference step, kind "port") timed on the
                    host cores of this box on a bounded sample of the same workload; ``cores`` = intra-op
                    threads used (fastest of a few counts), ``host`` = nproc + CPU model,
@@ -220,14 +222,16 @@ def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
         eng.side, eng.wg_main, eng.wg_side = streams
     flops_step = sum(r['flops'] * r['calls'] for r in gemm) / n_steps
     ms_gemm = sum(r['ms_total'] for r in gemm) / n_steps
+    traffic, traffic_stamp = traffic_for(dom['name'], dom['key'])
+    rocprof_us, rocprof_stamp = rocprof_us_for(kind, dom['name'], dom['key'])
     roof = {
         'bound': 'mfma', 'kernel': '%s %s' % (dom['name'], dom['key']),
         'achieved': round(dom['tflops'], 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic_for(dom['name'], dom['key']),
+        'frac': round(dom['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
         'avg_launch_ms': round(dom['ms_avg'], 5), 'algorithmic_flops_per_launch': dom['flops'],
         # the same call in the committed rocprofv3 kernel trace of one eager step (tools/step_by_shape.py: kernel
         # durations only, no launch boundary) and the fraction that gives -- the figure a reader can recompute from profiles/
-        'rocprof_avg_us': rocprof_us_for(kind, dom['name'], dom['key']),
+        'rocprof_avg_us': rocprof_us,
         'calls_per_step': dom['calls'] / n_steps,
         'timing': 'in-situ: HIP event pairs on the launch stream around every call of %d eager single-stream '
                   'steps enqueued behind a spin kernel (queue full, no host gap inside an interval; an interval '
@@ -242,6 +246,11 @@ def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
     }
     if roof['rocprof_avg_us']:
         roof['rocprof_frac'] = round(dom['flops'] / (roof['rocprof_avg_us'] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+    # `frac`, `achieved`, `avg_launch_ms` are measured in THIS run; `traffic`, `rocprof_avg_us`, `rocprof_frac` are quoted from
+    # committed tables: where they were collected, and whether the kernel sources have changed since
+    roof['committed_profiles'] = {'traffic': traffic_stamp, 'rocprof': rocprof_stamp}
+    roof['profile_head'] = (rocprof_stamp or traffic_stamp or {}).get('head')
+    roof['profile_stale'] = bool((rocprof_stamp or {'stale': True})['stale'] or (traffic_stamp or {'stale': True})['stale'])
     conv = [r for r in gemm if r['name'].startswith('conv')]
     if conv:
         fl = sum(r['flops'] * r['calls'] for r in conv) / n_steps
@@ -262,19 +271,36 @@ def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
     return roof
 
 
-TRAFFIC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json')]
-BY_SHAPE_FILE = os.path.join(ROOT, 'profiles', 'r04_by_shape.json')
+# The two committed tables a line may quote.  They are measured in a builder's GPU session, NOT in the run that prints
+# the line, so every figure taken from them carries the code they were collected on (mvae_amd.profiler.code_stamp: hash
+# of the kernel sources + the git head of that session) and `stale` when the hash is not this tree's (the
+# fields were silent look-ups, and fell back to tables of earlier rounds).  No fallback: a call this round's table does
+# not hold reads null.
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
+BY_SHAPE_FILE = os.path.join(ROOT, 'profiles', 'r05_by_shape.json')
+
+
+def _stamp_verdict(stamp):
+    from mvae_amd.profiler import code_stamp
+    if not stamp:
+        return {'head': None, 'csrc_sha16': None, 'stale': True}
+    return {'head': stamp.get('head'), 'csrc_sha16': stamp.get('csrc_sha16'),
+            'stale': stamp.get('csrc_sha16') != code_stamp()['csrc_sha16']}
 
 
 def rocprof_us_for(kind, name, key):
-    """Average rocprofv3 duration (us) of the call's kernels in the committed per-(call, shape) table of this workload's
-    step (profiles/r04_by_shape.json, made by tools/step_by_shape.py on the GPU box); None if not traced."""
+    """(average rocprofv3 duration (us) of the call's kernels in the committed per-(call, shape) table of this workload's
+    step, the table's code stamp) -- profiles/r05_by_shape.json, made by tools/step_by_shape.py on the GPU box; (None, None)
+    if not traced."""
     try:
         with open(BY_SHAPE_FILE) as f:
-            ent = json.load(f).get(kind, {}).get('%s %s' % (name, key))
+            table = json.load(f)
     except (IOError, ValueError):
-        return None
-    return None if ent is None else ent['rocprof_avg_us']
+        return None, None
+    ent = table.get(kind, {}).get('%s %s' % (name, key))
+    if ent is None:
+        return None, None
+    return ent['rocprof_avg_us'], dict(_stamp_verdict(table.get('_meta', {}).get(kind)), file='profiles/r05_by_shape.json')
 
 
 def module_surface(kind, batch, device, steps=20, warmup=5):
@@ -320,6 +346,41 @@ def module_surface(kind, batch, device, steps=20, warmup=5):
         dt = time.perf_counter() - t0
         out[opt_name] = {'ms_per_step': round(dt / steps * 1e3, 3), 'images_per_sec': round(batch * steps / dt, 1),
                          'final_loss': round(float(loss.item()), 3)}
+        if opt_name == 'FusedAdam':
+            # the SAME body (three model() calls, three elbo_loss calls, backward, step -- nothing restructured) handed to
+            # mvae_amd.capture_step: forward, autograd backward and optimizer in ONE hipGraph, no host work per launch
+            def body(img, lbl, beta):
+                opt.zero_grad()
+                if kind == 'celeba':
+                    r1, r2, r3 = model(img, lbl), model(img), model(attrs=lbl)
+                    kw = dict(lambda_image=1.0, lambda_attrs=lam, annealing_factor=beta)
+                    elbo = MF.elbo_loss_attrs
+                else:
+                    r1, r2, r3 = model(img, lbl), model(img), model(text=lbl)
+                    kw = dict(lambda_image=1.0, lambda_text=lam, annealing_factor=beta)
+                    elbo = MF.elbo_loss_label
+                total = (elbo(r1[0], img, r1[1], lbl, r1[2], r1[3], **kw) + elbo(r2[0], img, None, None, r2[2], r2[3], **kw)
+                         + elbo(None, None, r3[1], lbl, r3[2], r3[3], **kw))
+                total.backward()
+                opt.step()
+                return total
+            try:
+                cap = mvae_amd.capture_step(body, (image, label, 1.0), model=model, optimizer=opt)
+                for i in range(warmup):
+                    cap(image, label, annealing(i))
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    loss = cap(image, label, annealing(warmup + i))
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                out['FusedAdam + capture_step'] = {'ms_per_step': round(dt / steps * 1e3, 3),
+                                                   'images_per_sec': round(batch * steps / dt, 1),
+                                                   'final_loss': round(float(loss.item()), 3),
+                                                   'what': 'mvae_amd.capture_step(body, ...): the unchanged body as one hipGraph'}
+                del cap
+            except Exception as e:       # reported, never fatal for the line
+                out['FusedAdam + capture_step'] = {'error': '%s: %s' % (type(e).__name__, e)}
         del model, opt
     return out
 
@@ -328,16 +389,14 @@ def traffic_for(name, key):
     """HBM bytes per launch of the call from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950;
     tools/traffic_probe.py + tools/rocpd_summary.py --pmc).  None when that call was not probed."""
-    for path in TRAFFIC_FILES:          # this round's table first, then the previous round's for calls not re-probed
-        try:
-            with open(path) as f:
-                table = json.load(f)
-        except (IOError, ValueError):
-            continue
-        ent = table.get('%s %s' % (name, key))
-        if ent is not None:
-            return ent['hbm_bytes_per_launch']
-    return None
+    try:
+        with open(TRAFFIC_FILE) as f:
+            ent = json.load(f).get('%s %s' % (name, key))
+    except (IOError, ValueError):
+        ent = None
+    if ent is None:
+        return None, None
+    return ent['hbm_bytes_per_launch'], dict(_stamp_verdict(ent.get('collected_on')), file='profiles/r05_traffic.json')
 
 
 def elbo_delta(kind, batch=32):
@@ -664,7 +723,9 @@ def main():
         'runtime_env': {k: os.environ[k] for k in ('GPU_MAX_HW_QUEUES',) if k in os.environ},   # only if the caller set it
         'config': {'workload': '%s MVAE train step, n-latents %d, batch %d per GPU' % (kind, N_LATENTS[kind], batch),
                    'global_batch': world * batch, 'parallelism': 'dp%d' % world,
-                   'launch': 'eager' if args.no_graph else 'hipGraph replay', 'final_loss': round(loss, 3)},
+                   'launch': 'eager' if args.no_graph else 'hipGraph replay', 'final_loss': round(loss, 3),
+                   'value_from': 'the contract region: exactly --steps steps between two barrier + synchronize fences (max over '
+                                 'ranks); ms_per_step_median / p90 come from a SEPARATE pass of >= 50 steps with one HIP event per step'},
     }
     if state[4] is not None:
         out['dist'] = dict(dist_info, **state[4])
@@ -701,6 +762,15 @@ def main():
             out['also'] = [extra_workload('celeba', 256, 30, 5, device, ug, 10.0),
                            extra_workload('fashionmnist', 1024, 30, 5, device, ug, 8.0),
                            extra_workload('celeba19', 256, 15, 3, device, ug, 8.0)]
+            # the same, compact, where a record that keeps only the contract objects still holds it (the
+            # driver's record dropped `also`); also on stderr as one short JSON line
+            out['roofline']['other_workloads'] = [
+                {'workload': e['workload'].split(' MVAE')[0], 'ms_per_step': e['ms_per_step'],
+                 'ms_per_step_median': (e.get('step_distribution') or {}).get('ms_per_step_median'),
+                 'images_per_sec': e['value'], 'kernel': e['roofline']['kernel'], 'frac': e['roofline']['frac'],
+                 'rocprof_frac': e['roofline'].get('rocprof_frac'), 'profile_stale': e['roofline'].get('profile_stale'),
+                 'conv_kernels_frac': (e['roofline'].get('conv_kernels') or {}).get('frac')} for e in out['also']]
+            sys.stderr.write(json.dumps({'also_summary': out['roofline']['other_workloads']}) + '\n')
     if rank == 0:
         print(json.dumps(out))
     if world > 1 or args.force_dp:

@@ -29,6 +29,7 @@
 // (convT_s1_kernel: dense GEMM + col2im), the <= 4-output-channel transposed conv (convT_small_kernel)
 // and the weight gradient of the <= 4-input-channel conv (wgrad_smallcin_kernel).
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -82,6 +83,12 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #define MVAE_PHASED_PRELOAD 0    // k-grouped blocks, two tiles really in flight (see the phased loop): 1 = every wave issues the tile loads
                                  // (out of range for the MFMA-only waves), 2 = those waves run a load-free copy of the loop.
                                  // 1 measured ONCE: parity green (109 tests), MNIST 0.2851 -> 0.2920 ms -- off; 2 never run
+#endif
+#ifndef MVAE_CHAIN_PRIO
+#define MVAE_CHAIN_PRIO 0        // 1-3: the k-grouped (small-layout) GEMMs -- the launches of MNIST's data-gradient chains -- raise their
+                                 // wave priority for their whole run: co-resident with a weight-gradient batch (priority 0, off the
+                                 // chain) their instructions issue first (profiles/r04_mnist_step_timeline.txt: a 9-us chain GEMM
+                                 // took 27.9 us beside the batch)
 #endif
 #ifndef MVAE_EPI_BATCH
 #define MVAE_EPI_BATCH 0         // tile epilogues: the operands of eight outputs fetched together.  Off: with 3-5 blocks per CU the other
@@ -704,6 +711,7 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
     auto Ps = [&](int b) { return reinterpret_cast<PTile>(lds_raw + b * P_FLOATS); };
     auto Qs = [&](int b) { return reinterpret_cast<QTile>(lds_raw + 2 * P_FLOATS + b * Q_FLOATS); };
 
+    if (MVAE_CHAIN_PRIO && KW > 1 && WGM * WGN < 4) __builtin_amdgcn_s_setprio(MVAE_CHAIN_PRIO);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kg = wave / WPG, wq = wave % WPG;     // k-group of this wave, its slot inside the group
     const int wi = wq / WGN, wj = wq % WGN;
@@ -1527,6 +1535,28 @@ __global__ __launch_bounds__(256) void finish_few_vec_kernel(SplitSink sink, int
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
+// Tuning build + MVAE_GRID_REPORT=1 in the environment: one stderr line per GEMM-shaped launch -- blocks, blocks a CU holds
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor), and what share of the launch's block-slots x rounds does work: the tile /
+// block-count quantisation of a launch before a single instruction runs (tools/grid_report.py tabulates it).
+#ifdef MVAE_TUNING
+#define MVAE_GRID_REPORT(kern, grid, NT, lds, I, J, K, items, TM, TN)                                  \
+    {                                                                                            \
+        static const bool rep_on = getenv("MVAE_GRID_REPORT") != nullptr;                        \
+        if (rep_on) {                                                                            \
+            int per_cu = 0;                                                                      \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), NT, lds); \
+            const long blocks = (long)grid.x * grid.y * grid.z, slots = 256L * (per_cu > 0 ? per_cu : 1); \
+            const long rounds = (blocks + slots - 1) / slots;                                    \
+            /* a CU's share: blocks go round the CUs; the launch lasts as long as the CU with the most */ \
+            const long busiest = (blocks + 255) / 256;                                           \
+            fprintf(stderr, "[grid] tile %dx%d I %d J %d K %d  blocks %ld (%u x %u x %u) threads %d lds %zu  per_cu %d  rounds %ld  busiest_cu %ld  balance %.3f  items %d  %s\n", \
+                    TM, TN, I, J, K, blocks, grid.x, grid.y, grid.z, NT, (size_t)lds, per_cu, rounds, busiest, \
+                    (double)blocks / (256.0 * busiest), items, __PRETTY_FUNCTION__);              \
+        }                                                                                        \
+    }
+#else
+#define MVAE_GRID_REPORT(kern, grid, NT, lds, I, J, K, items, TM, TN)
+#endif
 struct Plan { int wm, wn, wgm, wgn, kw, bk, splits, klen; int xcd = 0; int items = 1; int force_items = 0; };   // xcd: launch-order re-mapping the host asks for (1 Linear sub-grids, 3 conv items, 4 split k ranges; see igemm_kernel); items: (class, j tile) items per block (conv forms)
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
@@ -1664,6 +1694,7 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             attr_done = true;                                                                    \
         }                                                                                        \
+        MVAE_GRID_REPORT(kern, grid, NT, lds, I, J, K, sink.items, TM, TN)                               \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p, q, e, K, pl.klen, sink);            \
     }
     bool launched = false;

@@ -265,6 +265,22 @@ template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(
 //     an XCD's resident blocks share one or two row bands of dy and sweep x together;
 //   * fewer, larger blocks (<= 2 per CU through the LDS footprint of the final reduction) leave wave slots, registers
 //     and LDS on every CU for a chain kernel that arrives while the batch is running.
+#ifndef MVAE_WGRAD2
+#define MVAE_WGRAD2 1            // 0: the round-4 batch kernel (wgrad_batched_kernel) for every launch
+#endif
+#ifndef MVAE_WB2_KO
+#define MVAE_WB2_KO 0
+#endif
+#ifndef MVAE_WB2_KW
+#define MVAE_WB2_KW 0            // A/B builds: force the waves per tile (2 .. 16)
+#endif
+#ifndef MVAE_WB2_PRIO
+#define MVAE_WB2_PRIO 0          // A/B builds: wave priority of the batch kernel (the batches sit on the side stream's chain)
+#endif
+#ifndef MVAE_WGRAD2_SHAPE
+#define MVAE_WGRAD2_SHAPE 0      // 0: by tile count; 22 / 21 / 11: force the 64 x 64 / 64 x 32 / 32 x 32 wave tile (A/B builds)
+#endif
+
 constexpr int WB2_SEGS = 8;
 struct WgradBatch2Args { WgradBatchItem it[WGRAD_BATCH_MAX]; int n; int seg[WB2_SEGS + 1]; };
 
@@ -329,14 +345,22 @@ __device__ __forceinline__ void wgrad_tile2(const WgradBatchItem &w, int tile_i,
             const i32x4_t ra = wb2_rsrc(ba, c * 8u * ulda, ext_a), rb = wb2_rsrc(bb, c * 8u * uldb, ext_b);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#if MVAE_WB2_KO == 2        /* knock-out (results wrong): no loads -- the MFMA stream alone */
+                (void)ra; (void)rb;
+#pragma unroll
+                for (int f = 0; f < FM; ++f) asm volatile("" : "=v"(as[p][f][q]));
+#pragma unroll
+                for (int f = 0; f < FN; ++f) asm volatile("" : "=v"(bs[p][f][q]));
+#else
 #pragma unroll
                 for (int f = 0; f < FM; ++f) as[p][f][q] = buf_load1(ra, va[q] + 128 * f);
 #pragma unroll
                 for (int f = 0; f < FN; ++f) bs[p][f][q] = buf_load1(rb, vb[q] + 128 * f);
+#endif
             }
         }
     };
-    auto use_set = [&](const float (&as)[PD][FM][4], const float (&bs)[PD][FN][4]) {
+    auto use_set = [&](auto with_rs, const float (&as)[PD][FM][4], const float (&bs)[PD][FN][4]) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
 #pragma unroll
@@ -344,26 +368,38 @@ __device__ __forceinline__ void wgrad_tile2(const WgradBatchItem &w, int tile_i,
 #pragma unroll
                 for (int f = 0; f < FM; ++f)
 #pragma unroll
-                    for (int g = 0; g < FN; ++g)
+                    for (int g = 0; g < FN; ++g) {
+#if MVAE_WB2_KO == 1        /* knock-out (results wrong): no MFMAs -- the load stream alone (the values are 'used') */
+                        asm volatile("" :: "v"(as[p][f][q]), "v"(bs[p][g][q]));
+#else
                         acc[f][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[p][f][q], bs[p][g][q], acc[f][g], 0, 0, 0);
-            if (rs_block) {
+#endif
+                    }
+            if constexpr (decltype(with_rs)::value) {
 #pragma unroll
                 for (int f = 0; f < FM; ++f) rs[f] += (as[p][f][0] + as[p][f][1]) + (as[p][f][2] + as[p][f][3]);
             }
         }
     };
-    // two register sets: one is multiplied while the other is in flight (see wgrad_direct_tile on why not a rotating one)
-    load_set(0, a0, b0);
-    for (int it = 0; it < n_it; it += 2 * PD) {
-        load_set(it + PD, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        use_set(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_set(it + 2 * PD, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        use_set(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    // two register sets: one is multiplied while the other is in flight (see wgrad_direct_tile on why not a rotating one).
+    // The column sums of dy (the bias gradient) are the business of a layer's first j tile only: TWO copies of the loop
+    // -- under one `if (rs_block)` inside it the adds were if-converted into every tile's loop (adds + selects: 0.6 - 1.2
+    // vector instructions per MFMA).
+    auto main_loop = [&](auto with_rs) {
+        load_set(0, a0, b0);
+        for (int it = 0; it < n_it; it += 2 * PD) {
+            load_set(it + PD, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            use_set(with_rs, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_set(it + 2 * PD, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            use_set(with_rs, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (rs_block) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
     // ---- the KW partial tiles through LDS in halves (the upper half of the waves parks, the lower half adds: a fixed
     //      tree), the last sum back to LDS, epilogue with every thread
     constexpr int TP = TN + 1;
@@ -430,6 +466,7 @@ __global__ __launch_bounds__(64 * KW) void wgrad_batched2_kernel(WgradBatch2Args
     const int xcd = blockIdx.x & (WB2_SEGS - 1), slot = blockIdx.x >> 3;
     const int tile = a.seg[xcd] + slot;
     if (tile >= a.seg[xcd + 1]) return;
+    if (MVAE_WB2_PRIO) __builtin_amdgcn_s_setprio(MVAE_WB2_PRIO);
     int p = 0, first = 0;
 #pragma unroll 1
     for (int q = 0; q < a.n - 1; ++q) {
@@ -440,13 +477,6 @@ __global__ __launch_bounds__(64 * KW) void wgrad_batched2_kernel(WgradBatch2Args
     const int tile_i = local / w.tiles_j, tile_j = local - tile_i * w.tiles_j;
     wgrad_tile2<KW, FM, FN, PD>(w, tile_i, tile_j);
 }
-
-#ifndef MVAE_WGRAD2
-#define MVAE_WGRAD2 1            // 0: the round-4 batch kernel (wgrad_batched_kernel) for every launch
-#endif
-#ifndef MVAE_WGRAD2_SHAPE
-#define MVAE_WGRAD2_SHAPE 0      // 0: by tile count; 22 / 21 / 11: force the 64 x 64 / 64 x 32 / 32 x 32 wave tile (A/B builds)
-#endif
 
 // Re-tile the table for FM x FN wave tiles, cut it into XCD segments, launch.  Returns false when the batch has an
 // item the v2 tile code does not take (none today: kept for the Adam-fused form, which stays on the old kernel).
@@ -463,16 +493,25 @@ inline bool wgrad_batched2_launch(const WgradBatchArgs &a, hipStream_t st, int *
         const long over = (long)w.M + 8 * 16 * 5;
         if (over * w.lddy * 4 >= (1L << 31) || over * w.ldx * 4 >= (1L << 31)) return false;
     }
-    // wave tile: the largest whose tiles still give every CU a block; waves per tile: ~2 per SIMD over the launch, at
-    // least 4 chunks of 8 rows each
-    int shape = t22 >= 200 ? 22 : (t21 >= 200 ? 21 : 11);
+    // Wave tile: every tile of a launch costs the same (M rows x tile area), blocks spread evenly over the 256 CUs, and the
+    // launch lasts as long as its busiest CU -- ceil(tiles / 256) tiles of FM x FN MFMAs per 8 rows.  Pick the shape with
+    // the least of that; between equals the larger tile (fewer loads per MFMA).  (MNIST, session 3 of round 5, the launch
+    // alone, hot: image decoder 936 / 468 / 240 tiles -> 4 / 4 / 4 units: 64 x 64 wins, 24.6 us against 26.4 (32 x 32)
+    // and 28.8 for the round-4 kernel; label decoder 560 / 288 / 144 tiles -> 3 / 4 / 4: 32 x 32 wins, 19.6 against 22.5.)
+    const long busy22 = cdiv(t22, 256) * 4, busy21 = cdiv(t21, 256) * 2, busy11 = cdiv(t11, 256);
+    int shape = 22;
+    long busy = busy22;
+    if (busy21 < busy) { shape = 21; busy = busy21; }
+    if (busy11 < busy) { shape = 11; busy = busy11; }
     if (MVAE_WGRAD2_SHAPE) shape = MVAE_WGRAD2_SHAPE;
     const long tiles = shape == 22 ? t22 : (shape == 21 ? t21 : t11);
     const int fm = shape == 11 ? 1 : 2, fn = shape == 22 ? 2 : 1;
+    // waves per tile (they split the batch rows): ~2 per SIMD over the launch, at least 4 chunks of 8 rows each
     int kw = tiles >= 1024 ? 2 : (tiles >= 400 ? 4 : (tiles >= 160 ? 8 : 16));
     if (shape == 22 && kw < 4) kw = 4;
     while (kw > 2 && max_m < 8 * 4 * kw) kw >>= 1;
     if (shape == 11 && kw < 4) kw = 4;
+    if (MVAE_WB2_KW) kw = MVAE_WB2_KW;
     WgradBatch2Args b;
     b.n = a.n;
     int total = 0;

@@ -183,6 +183,37 @@ class _KlRowsFn(torch.autograd.Function):
         return dmu, dlv
 
 
+_COEF_CACHE = {}
+
+
+def _w(x):
+    """A loss weight as the reference passes it (a python number), or -- inside ``mvae_amd.capture_step`` -- the 0-d
+    device tensor the captured graph re-reads at every replay (the annealing factor changes from step to step)."""
+    return x if torch.is_tensor(x) else float(x)
+
+
+def _coef_tensor(weights, B, dev):
+    """[n] fp32 device tensor of w_i / B.  Python numbers come from a cache per (values, B, device): no host-to-device
+    copy per ``elbo_loss`` call, and nothing a stream capture would refuse; a 0-d device tensor among the weights is spliced
+    in on the device."""
+    consts = tuple(None if torch.is_tensor(w) else float(w) for w in weights)
+    key = (consts, int(B), str(dev))
+    base = _COEF_CACHE.get(key)
+    if base is None:
+        if torch.cuda.is_current_stream_capturing():     # (a pageable-memory upload is not capturable: fills are)
+            base = torch.stack([torch.full((), (c or 0.0) / B, dtype=torch.float32, device=dev) for c in consts])
+        else:
+            base = torch.tensor([(c or 0.0) / B for c in consts], dtype=torch.float32, device=dev)
+            _COEF_CACHE[key] = base
+    if all(c is not None for c in consts):
+        return base
+    out = base.clone()
+    for i, w in enumerate(weights):
+        if torch.is_tensor(w):
+            out[i:i + 1].copy_(w.detach().reshape(1).to(torch.float32) / B)
+    return out
+
+
 class _WeightedMeanFn(torch.autograd.Function):
     """mean_b(sum_i w_i * rows_i[b]) for up to three row vectors (the last line of elbo_loss)."""
 
@@ -191,7 +222,7 @@ class _WeightedMeanFn(torch.autograd.Function):
         B = rows[0].shape[0]
         dev = rows[0].device
         out = torch.empty(1, dtype=torch.float32, device=dev)
-        coefs = torch.tensor([w / B for w in weights], dtype=torch.float32, device=dev)
+        coefs = _coef_tensor(weights, B, dev)
         for i, r in enumerate(rows):
             K.group_sums(r.contiguous(), coefs[i:i + 1], None, out, 1, B, accumulate=(i > 0))
         ctx.coefs, ctx.B = coefs, B
@@ -255,7 +286,7 @@ def elbo_loss_label(recon_image, image, recon_text, text, mu, logvar,
                 text.size(0), recon_text.size(0)))
         rows.append(_CeRowsFn.apply(recon_text.contiguous(), text.contiguous()))
         weights.append(float(lambda_text))
-    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(float(annealing_factor))
+    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(_w(annealing_factor))
     return _WeightedMeanFn.apply(weights, *rows)
 
 
@@ -272,7 +303,7 @@ def elbo_loss_attrs(recon_image, image, recon_attrs, attrs, mu, logvar,
                 attrs[:, 0].size(), recon_attrs[:, 0].size()))
         rows.append(_BceRowsFn.apply(recon_attrs.contiguous(), attrs.contiguous()))
         weights.append(float(lambda_attrs))
-    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(float(annealing_factor))
+    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(_w(annealing_factor))
     return _WeightedMeanFn.apply(weights, *rows)
 
 
@@ -298,5 +329,5 @@ def elbo_loss_multi(recon, data, mu, logvar, lambda_image=1.0, lambda_attrs=1.0,
         x = torch.stack(attr_x, dim=1).contiguous()
         t = torch.stack(attr_t, dim=1).contiguous().float()
         rows.append(_BceRowsFn.apply(x, t)); weights.append(float(lambda_attrs))
-    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(float(annealing_factor))
+    rows.append(_KlRowsFn.apply(mu, logvar)); weights.append(_w(annealing_factor))
     return _WeightedMeanFn.apply(weights, *rows)

@@ -9,12 +9,31 @@ tensor arguments for the small plumbing kernels it does not list).  ``marker=Tru
 ``roofline`` object (live, in the same process as the timed run); the rocprofv3 kernel trace
 committed under ``profiles/`` is the cross-check.
 """
+import glob
+import hashlib
+import os
+
 import torch
 
 from . import kernels as K
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def code_stamp():
+    """What a committed profile table was measured ON: sha256 (16 hex digits) over the kernel sources and the C header,
+    plus the git head the collecting session was told about (``MVAE_GIT_HEAD``: the GPU box has no .git).  bench.py
+    compares the hash with the tree it runs from and marks a table taken on other code ``profile_stale``."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, 'csrc', '*.hip')) + glob.glob(os.path.join(here, 'csrc', '*.h')))
+    files.append(os.path.join(os.path.dirname(here), 'include', 'mvae_hip.h'))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return {'csrc_sha16': h.hexdigest()[:16], 'head': os.environ.get('MVAE_GIT_HEAD', 'unknown')}
 
 
 def _numel_bytes(args, kwargs):

@@ -1,0 +1,121 @@
+"""GPU: ``mvae_amd.capture_step`` -- the reference's loop body (mnist/train.py:197-219, celeba/train.py:190-212), verbatim
+in a closure, captured into ONE hipGraph (forward, autograd backward, optimizer step) -- against the same body run eagerly:
+same noise stream, same batches, same annealing schedule; losses, parameters, optimizer state and BatchNorm buffers after
+several steps.  The kernels and their order are the same on both sides, so the bar is equality to the last bit -- except
+for CelebA's five bias vectors whose gradient is exactly zero in exact arithmetic (tests/util.py ZERO_GRAD_PARAMS): what
+reaches Adam there is round-off, Adam turns round-off into steps of up to lr, and tensors at other addresses (the graph's
+private pool) may take a kernel's other summation path -- those five are bounded by steps x lr and cannot reach the loss."""
+import pytest
+import torch
+
+import mvae_amd
+import mvae_amd.functional as MF
+from mvae_amd.optim import FusedAdam
+from oracle import steps as OS
+from test_engine_gpu import build_pair
+from util import ZERO_GRAD_PARAMS
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _body(kind, model, opt, lam):
+    """The reference's per-batch lines, unchanged but for the names of the loss helpers."""
+    if kind == 'celeba':
+        def body(image, attrs, annealing_factor):
+            opt.zero_grad()
+            recon_image_1, recon_attrs_1, mu_1, logvar_1 = model(image, attrs)
+            recon_image_2, recon_attrs_2, mu_2, logvar_2 = model(image)
+            recon_image_3, recon_attrs_3, mu_3, logvar_3 = model(attrs=attrs)
+            joint_loss = MF.elbo_loss_attrs(recon_image_1, image, recon_attrs_1, attrs, mu_1, logvar_1,
+                                            lambda_image=1.0, lambda_attrs=lam, annealing_factor=annealing_factor)
+            image_loss = MF.elbo_loss_attrs(recon_image_2, image, None, None, mu_2, logvar_2,
+                                            lambda_image=1.0, lambda_attrs=lam, annealing_factor=annealing_factor)
+            attrs_loss = MF.elbo_loss_attrs(None, None, recon_attrs_3, attrs, mu_3, logvar_3,
+                                            lambda_image=1.0, lambda_attrs=lam, annealing_factor=annealing_factor)
+            train_loss = joint_loss + image_loss + attrs_loss
+            train_loss.backward()
+            opt.step()
+            return train_loss
+        return body
+
+    def body(image, text, annealing_factor):
+        opt.zero_grad()
+        recon_image_1, recon_text_1, mu_1, logvar_1 = model(image, text)
+        recon_image_2, recon_text_2, mu_2, logvar_2 = model(image)
+        recon_image_3, recon_text_3, mu_3, logvar_3 = model(text=text)
+        joint_loss = MF.elbo_loss_label(recon_image_1, image, recon_text_1, text, mu_1, logvar_1,
+                                        lambda_image=1.0, lambda_text=lam, annealing_factor=annealing_factor)
+        image_loss = MF.elbo_loss_label(recon_image_2, image, None, None, mu_2, logvar_2,
+                                        lambda_image=1.0, lambda_text=lam, annealing_factor=annealing_factor)
+        text_loss = MF.elbo_loss_label(None, None, recon_text_3, text, mu_3, logvar_3,
+                                       lambda_image=1.0, lambda_text=lam, annealing_factor=annealing_factor)
+        train_loss = joint_loss + image_loss + text_loss
+        train_loss.backward()
+        opt.step()
+        return train_loss
+    return body
+
+
+def _run(kind, batch, captured, make_opt, n_steps=4):
+    lam = 10.0 if kind == 'celeba' else 50.0
+    _, model, d = build_pair(kind, weight_seed=61)
+    model.seed_noise(1234)
+    opt = make_opt(model.parameters())
+    body = _body(kind, model, opt, lam)
+    image, label = OS.synthetic_batch(kind, batch, seed=800)
+    w0 = model.arena.flat.detach().clone()
+    if captured:
+        step = mvae_amd.capture_step(body, (image.to(DEV), label.to(DEV), 1.0), model=model, optimizer=opt)
+        assert torch.equal(w0, model.arena.flat), 'capture_step left a trace in the parameters'
+    else:
+        step = body
+    losses = []
+    for s in range(n_steps):
+        image, label = OS.synthetic_batch(kind, batch, seed=801 + s)
+        beta = min(1.0, 0.2 * (s + 1))                # the annealing factor changes from step to step (mnist/train.py:184-194)
+        losses.append(float(step(image.to(DEV), label.to(DEV), beta).item()))
+    torch.cuda.synchronize()
+    model.flush_counters()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return losses, state, model.arena.flat.detach().clone(), opt
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6), ('mnist', 512)])
+def test_captured_reference_body_equals_the_eager_one(kind, batch):
+    mk = lambda ps: FusedAdam(ps, lr=1e-3)      # noqa: E731
+    l_e, st_e, w_e, opt_e = _run(kind, batch, False, mk)
+    l_c, st_c, w_c, opt_c = _run(kind, batch, True, mk)
+    assert l_e == l_c, (l_e, l_c)
+    noise_only = ZERO_GRAD_PARAMS.get(kind, ())
+    for k in st_e:                                        # incl. BatchNorm running statistics and num_batches_tracked
+        if k in noise_only:
+            assert (st_e[k] - st_c[k]).abs().max().item() <= len(l_e) * 1e-3 * 1.001, k
+        else:
+            assert torch.equal(st_e[k], st_c[k]), k
+    if not noise_only:
+        assert torch.equal(w_e, w_c), 'parameters after %d steps' % len(l_e)
+        assert torch.equal(opt_e._m, opt_c._m) and torch.equal(opt_e._v, opt_c._v)
+    assert opt_e._step_dev.item() == opt_c._step_dev.item() == len(l_e)
+    assert len(set(l_e)) == len(l_e) and all(x == x for x in l_e)        # the steps differ (new batch, new noise, new beta)
+
+
+def test_captured_body_with_stock_capturable_adam_and_argument_checks():
+    kind, batch = 'mnist', 16
+    mk = lambda ps: torch.optim.Adam(ps, lr=1e-3, capturable=True)      # noqa: E731
+    l_e, st_e, w_e, _ = _run(kind, batch, False, mk, n_steps=3)
+    l_c, st_c, w_c, _ = _run(kind, batch, True, mk, n_steps=3)
+    assert l_e == l_c and torch.equal(w_e, w_c)
+    _, model, d = build_pair(kind, weight_seed=61)
+    image, label = OS.synthetic_batch(kind, batch, seed=800)
+    with pytest.raises(RuntimeError, match='capturable'):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        mvae_amd.capture_step(_body(kind, model, opt, 50.0), (image.to(DEV), label.to(DEV), 1.0), model=model, optimizer=opt)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    step = mvae_amd.capture_step(_body(kind, model, opt, 50.0), (image.to(DEV), label.to(DEV), 1.0), model=model, optimizer=opt)
+    with pytest.raises(ValueError, match='ragged'):
+        step(image[:5].to(DEV), label[:5].to(DEV), 1.0)
+    with pytest.raises(TypeError):
+        step(image.to(DEV), label.to(DEV))
+    loss = step.eager(image[:5].to(DEV), label[:5].to(DEV), 1.0)          # the ragged last batch of an epoch
+    assert torch.isfinite(loss).item()

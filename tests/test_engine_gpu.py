@@ -220,17 +220,27 @@ def test_paired_encoder_launches_match_live_oracle(batch, monkeypatch):
     assert BimodalStep(other, 8, 1.0, 50.0).pair_enc == 0
 
 
-@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6)])
+# ... and at BASELINE.json's per-GPU batches ("What's missing" 3): the reference-shaped loop on the drop-in modules
+# is what bench.py's `module_surface` times, and 512 / 1024 / 256 rows are where its split reductions are longest
+@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6),
+                                        ('mnist', 512), ('fashionmnist', 1024), ('celeba', 256)])
 def test_module_surface_matches_live_oracle(kind, batch):
     """The reference's own call pattern: three model() calls, three elbo_loss calls, backward
     (mnist/train.py:200-218) on the drop-in nn.Module + functional surface."""
     import mvae_amd.functional as MF
-    oracle, model, d = build_pair(kind, weight_seed=13)
-    image, label = OS.synthetic_batch(kind, batch, seed=78)
-    torch.manual_seed(6)
-    noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
-    lam_i, lam_l, beta = 1.0, 10.0, 0.5
-    total, terms, lat = OS.bimodal_step(oracle, kind, image, label, noise, lam_i, lam_l, beta)
+    for attempt in range(3):
+        oracle, model, d = build_pair(kind, weight_seed=13)
+        image, label = OS.synthetic_batch(kind, batch, seed=78 + attempt)
+        torch.manual_seed(6)
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=(kind == 'celeba'))
+        lam_i, lam_l, beta = 1.0, 10.0, 0.5
+        total, terms, lat, recon = OS.bimodal_step(oracle, kind, image, label, noise, lam_i, lam_l, beta, return_recon=True)
+        # an exactly-zero logit sits on the reference BCE's gradient jump (SURVEY App. B-3): only the large batches ever hit one
+        logits = [r[0] for r in recon if r[0] is not None] + ([r[1] for r in recon if r[1] is not None] if kind == 'celeba' else [])
+        if not any(bool((x == 0).any()) for x in logits):
+            break
+    note_redraws('module surface %s B=%d' % (kind, batch), attempt)
+    assert attempt <= 1
     total.backward()
 
     img, lbl = image.to(DEV), label.to(DEV)
@@ -347,7 +357,10 @@ def test_weight_gradient_launches_that_update_their_parameters(kind, batch, monk
     """MVAE_FUSE_ADAM=1: the Linear weight-gradient batches of the captured single-GPU step run optimizer.step() on
     their own outputs (FashionMNIST's conv / BatchNorm parameters stay with the launch at the end of the chain).  Same
     parameters, moments and counter, bit for bit, as the arena-wide update -- and on MNIST nothing is left for a launch
-    at the end.  (Off by default: measured slower, profiles/r04_fuse_adam_ab.txt.)"""
+    at the end.  (Off by default: measured slower, profiles/r04_fuse_adam_ab.txt.)  Since round 5 the plain batches run on
+    another tile code than the fused ones (64-wide wave tiles, a different summation tree): the two runs agree to fp32
+    round-off, not bit for bit -- the bit-exact statement lives in tests/test_kernels_gpu.py (Adam on the gradients the
+    fused launch produced)."""
     finals = []
     for fuse in ('1', '0'):
         monkeypatch.setenv('MVAE_FUSE_ADAM', fuse)
@@ -371,5 +384,11 @@ def test_weight_gradient_launches_that_update_their_parameters(kind, batch, monk
         torch.cuda.synchronize()
         assert opt._step_dev.item() == 3
         finals.append((model.arena.flat.clone(), opt._m.clone(), opt._v.clone(), model.arena.grad.clone()))
+    lr, steps = 1e-3, 3
     for a, b, what in zip(finals[0], finals[1], ('parameters', 'exp_avg', 'exp_avg_sq', 'gradients')):
-        assert torch.equal(a, b), what
+        if what == 'parameters':
+            # an Adam step is lr * m / (sqrt(v) + eps): round-off in g moves it by O(1e-6 lr), up to a few % of lr where |g| ~ eps
+            assert (a - b).abs().max().item() <= 0.05 * lr * steps, what
+        else:
+            scale = max(b.abs().max().item(), 1e-30)
+            assert (a - b).abs().max().item() <= 1e-5 * scale, what

@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-table=${TRAFFIC_TABLE:-r04_traffic.json}
+table=${TRAFFIC_TABLE:-r05_traffic.json}
 out=gpurun_out/traffic
 rm -rf $out; mkdir -p $out
 for spec in "$@"; do

@@ -95,6 +95,9 @@ def collect(calls_path, db_path, table_path):
     if os.path.exists(table_path):
         table = json.load(open(table_path))
     table[meta['workload']] = out
+    import mvae_amd  # noqa: F401
+    from mvae_amd.profiler import code_stamp
+    table.setdefault('_meta', {})[meta['workload']] = dict(code_stamp(), batch=meta.get('batch'))
     with open(table_path, 'w') as f:
         json.dump(table, f, indent=1, sort_keys=True)
 

@@ -147,6 +147,9 @@ def collect(fetch_db, write_db, out_json, name, key):
     if os.path.exists(out_json):
         with open(out_json) as f:
             table = json.load(f)
+    import mvae_amd  # noqa: F401
+    from mvae_amd.profiler import code_stamp
+    ent['collected_on'] = code_stamp()
     table['%s %s' % (name, key)] = ent
     with open(out_json, 'w') as f:
         json.dump(table, f, indent=1, sort_keys=True)
