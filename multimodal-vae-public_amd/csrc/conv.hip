@@ -54,6 +54,16 @@
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ f32x2_t llvm_raw_buffer_load_f32x2(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 
+#ifndef MVAE_WIDE_BLOCKS
+#define MVAE_WIDE_BLOCKS (1 << 30)   // conv-forward-form launches with >= 128 output channels took 128 x 64 tiles from 384 blocks on
+                                     // (rounds 2-4).  With the gather loaders' one-offset-per-tap form and the buffer-store epilogue
+                                     // the 64 x 64 kernels run four blocks of ~100 registers per CU and WIN: CelebA -1.6 %,
+                                     // FashionMNIST -5.1 %, CelebA-19 -0.7 % (x3 interleaved, profiles/r05_conv_retune_ab.txt); 384: A/B
+#endif
+#ifndef MVAE_GATHER_COMPACT
+#define MVAE_GATHER_COMPACT 1    // gather loaders: one per-lane offset per TAP + the channel on the scalar offset (see LdIm2colT)
+#endif
+
 namespace {
 
 // Geometry of a 4x4 convolution y[B,Cout,OH,OW] = conv(x[B,Cin,H,W], w[Cout,Cin,4,4]).
@@ -96,7 +106,12 @@ struct LdIm2colT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *x; ConvGeom g; int Mtot;
     int base, kq; unsigned vh, vwq;
-    BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
+    // full k-tiles: buffer base (first image of the tile) + byte offsets.  MVAE_GATHER_COMPACT: an element's offset is
+    // (tap part, per lane) + (channel part, the same for every lane), and its validity depends on the tap alone -- so a
+    // thread keeps ONE offset per distinct tap among its elements (4 - 8 instead of 16, out-of-range when the tap is outside
+    // the image) and the channel part rides the instruction's SCALAR offset: per (re-)initialisation a handful of vector
+    // instructions instead of ~6 per element, and 8 - 12 registers fewer (the multi-item blocks re-initialise per item)
+    BufBase blk; int voff[MVAE_GATHER_COMPACT ? 16 : NV];
     static constexpr bool fast = true;
     __device__ void begin(int, int) {}
     __device__ void init(int tile0, int t, int) {
@@ -124,6 +139,14 @@ struct LdIm2colT {
         vwq = vw >> kq;
         // element v of a full k-tile: channel (KSTEP*v >> 4) of the tile's channel group, tap (kh, kw); a tap
         // outside the image (or a lane without an output position) reads as zero through BUF_OOB
+        if (MVAE_GATHER_COMPACT) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {          // tap (kh, kwl) = (p >> 2, p & 3); the taps no element has are dead code
+                const bool ok = ((vh >> (p >> 2)) & 1u) && ((vwq >> (p & 3)) & 1u);
+                voff[p] = ok ? (rel + (p >> 2) * g.W + (p & 3)) * 4 : BUF_OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = KSTEP * v;
@@ -167,9 +190,17 @@ struct LdIm2colT {
     static constexpr bool PARTS = true, TAIL = false;
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> 4) * (g.H * g.W));
+        const int hw4 = g.H * g.W * 4;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load1(rs, voff[v]);
+            if (MVAE_IN_PART(v, NV, part, nparts)) {
+                if (MVAE_GATHER_COMPACT) {
+                    const int c = KSTEP * v;        // tap = c & 15, channel of the tile's group = c >> 4 (scalar offset)
+                    rg.v[v] = llvm_raw_buffer_load_f32(rs, voff[c & 15], (c >> 4) * hw4, 0);
+                } else {
+                    rg.v[v] = buf_load1(rs, voff[v]);
+                }
+            }
     }
     __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int m = t % TILE, kb = t / TILE;
@@ -305,7 +336,8 @@ struct LdDgradDyT {
     struct Regs { float v[NV]; unsigned ok; };        // raw data + validity bits (applied when staged)
     const float *dy; ConvGeom g; int Mtot; int H2, W2;
     int base, kq; unsigned vhq, vwq;
-    BufBase blk; int voff[NV];                        // full k-tiles: buffer base (first image of the tile) + byte offsets
+    static constexpr int NPAT = (TMASK + 1) * (TMASK + 1);      // taps (a, b) per class
+    BufBase blk; int voff[MVAE_GATHER_COMPACT ? NPAT : NV];     // full k-tiles: buffer base (first image of the tile) + byte offsets (see LdIm2colT)
     // The column -> (image, row', col') decode of a tile (two run-time divisions per thread) is the same for every
     // parity class of that tile, and a multi-item block walks the classes of ONE tile back to back (class-minor
     // order): kept across init() calls.  The (stride, pad) pair is the template's: 4x4 convs here are (2, 1) or (1, 0).
@@ -349,6 +381,14 @@ struct LdDgradDyT {
             }
         }
         vhq = vh >> aq; vwq = vw >> bq;
+        if (MVAE_GATHER_COMPACT) {
+#pragma unroll
+            for (int p = 0; p < NPAT; ++p) {        // tap (al, bl) = (p >> TLOG, p & TMASK)
+                const bool ok = ((vhq >> (p >> TLOG)) & 1u) && ((vwq >> (p & TMASK)) & 1u);
+                voff[p] = ok ? (rel - (p >> TLOG) * g.OW - (p & TMASK)) * 4 : BUF_OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int c = KSTEP * v;
@@ -391,9 +431,17 @@ struct LdDgradDyT {
     static constexpr bool PARTS = true, TAIL = false;               // slices of a FULL k-tile: buffer loads, nothing on the vector ALU
     __device__ __forceinline__ void load_part(int k0, int, int, Regs &rg, int part, int nparts) const {
         const i32x4_t rs = buf_rsrc(blk, (size_t)(k0 >> (2 * TLOG)) * (g.OH * g.OW));
+        const int ohw4 = g.OH * g.OW * 4;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            if (MVAE_IN_PART(v, NV, part, nparts)) rg.v[v] = buf_load1(rs, voff[v]);
+            if (MVAE_IN_PART(v, NV, part, nparts)) {
+                if (MVAE_GATHER_COMPACT) {
+                    const int c = KSTEP * v;        // tap = low 2 TLOG bits, output channel of the tile's group above them
+                    rg.v[v] = llvm_raw_buffer_load_f32(rs, voff[c & (NPAT - 1)], (c >> (2 * TLOG)) * ohw4, 0);
+                } else {
+                    rg.v[v] = buf_load1(rs, voff[v]);
+                }
+            }
     }
     __device__ __forceinline__ void store_part(Tile L, int t, const Regs &rg, int part, int nparts) const {
         const int m = t % TILE, kb = t / TILE;
@@ -883,7 +931,7 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     // every gathered fragment (dec2 / dec1 dgrad at 512 images: 91 -> 99 and 77 -> 80 TFLOP/s; at 256 images the
     // grid would be one block per CU and 64 x 64 tiles win)
     if (pl.wm == 1 && pl.wn == 1 && pl.kw == 1 && pl.wgn == 2 && I >= 128 && !MVAE_TUNE(wm) && !MVAE_TUNE(wn) &&
-        cdiv(I, 128) * cdiv(J, 64) >= 384)
+        cdiv(I, 128) * cdiv(J, 64) >= MVAE_WIDE_BLOCKS)
         pl.wm = 2;
     if (K <= MVAE_MULTI_MAXK) pl.items = MVAE_MULTI_ITEMS;      // short reductions: pipeline across consecutive tiles
     pl.xcd = MVAE_CONV_XCD ? 3 : 0;                             // the bands of one column tile on one XCD (igemm_kernel)

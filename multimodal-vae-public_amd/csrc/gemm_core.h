@@ -90,6 +90,10 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
                                  // chain) their instructions issue first (profiles/r04_mnist_step_timeline.txt: a 9-us chain GEMM
                                  // took 27.9 us beside the batch)
 #endif
+#ifndef MVAE_EP_BUFFER
+#define MVAE_EP_BUFFER 1         // NCHW tile epilogues through buffer stores: per-lane column offset + SCALAR row offset, no 64-bit
+                                 // address arithmetic per element (0: the round-4 pointer form)
+#endif
 #ifndef MVAE_EPI_BATCH
 #define MVAE_EPI_BATCH 0         // tile epilogues: the operands of eight outputs fetched together.  Off: with 3-5 blocks per CU the other
                                  // blocks' matrix work already covers a block's epilogue -- CelebA +0.6 %, FashionMNIST +0.1 % (r04_epilogue_ab.txt)
@@ -106,6 +110,10 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float llvm_raw_buffer_load_f32(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+typedef float f32x2_ep_t __attribute__((ext_vector_type(2)));
+__device__ f32x2_ep_t llvm_raw_buffer_load_f32x2_ep(i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ void llvm_raw_buffer_store_f32(float v, i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void llvm_raw_buffer_store_f32x2(f32x2_ep_t v, i32x4_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 namespace {
 
@@ -588,7 +596,7 @@ struct EpNCHW {
     int lg_hw2 = -1, lg_w2 = -1;   // log2(H2 * W2), log2(W2) when both are powers of two (host), else -1: col() shifts instead of dividing
     __device__ void set_class(int cls) { if (sy > 1) { py = cls / sy; px = cls % sy; } }
     __device__ bool col(int j) {
-        if (j >= J) return false;
+        if (j >= J) { voff = BUF_OOB; return BUFFER; }            // buffer form: the lane takes part, its accesses fall out of range
         int n, rem, r, c;
         if (lg_w2 >= 0) {           // block-uniform
             n = j >> lg_hw2; rem = j & ((1 << lg_hw2) - 1);
@@ -598,7 +606,11 @@ struct EpNCHW {
             n = j / hw2; rem = j - n * hw2;
             r = rem / W2; c = rem - r * W2;
         }
-        off = n * C * HW + (r * sy + py) * Wfull + c * sy + px;
+        const int in_img = (r * sy + py) * Wfull + c * sy + px;
+        off = n * C * HW + in_img;
+        // buffer form: bytes from the tile's first image (tile()); the rows of the upper half wavefront (4 further down:
+        // the 32x32 MFMA result layout) ride the per-lane offset, so that a row's offset is the same for the whole wave
+        voff = ((n - n0) * C * HW + in_img + ((threadIdx.x & 32) ? 4 * HW : 0)) * 4;
         return true;
     }
     __device__ void put(int i, int, float v) const {
@@ -607,6 +619,57 @@ struct EpNCHW {
         if (dpre) v *= swish_grad_(dpre[idx]);
         if (out) out[idx] = v;
         if (act) act[idx] = swishf_(v);
+    }
+    // ---- the same through buffer instructions (tile epilogues of igemm_kernel).  put() forms a 64-bit address per stored
+    //      element (v_lshl_add_u64 and friends: 3-4 vector instructions per access, 16-32 accesses per tile and wave --
+    //      profiles/r04_celeba_sq_counters.txt read 2-4 VALU per MFMA over whole conv launches whose main loops issue 0.2-0.8,
+    //      and on fp32 MFMA a vector instruction is matrix time).  Here an access is  descriptor(tile's first image) +
+    //      per-lane byte offset (col(), once per column) + SCALAR row offset: no vector arithmetic at all.  A lane without
+    //      a column carries BUF_OOB: its loads read 0, its stores are dropped -- no divergent branch around the tile either.
+    static constexpr bool BUFFER = MVAE_EP_BUFFER != 0;
+    int n0 = 0, voff = 0;
+    i32x4_t r_out, r_act, r_dpre;
+    __device__ void tile(int j0) {          // j0: the tile's first column (block-uniform)
+        const int hw2 = H2 * W2;
+        n0 = __builtin_amdgcn_readfirstlane(lg_w2 >= 0 ? j0 >> lg_hw2 : j0 / hw2);
+        const size_t el = (size_t)n0 * C * HW;
+        // (a null tensor borrows another's address: its branch is never taken)
+        r_out = buf_rsrc(buf_base(out ? out : act), el);
+        r_act = buf_rsrc(buf_base(act ? act : out), el);
+        r_dpre = buf_rsrc(buf_base(dpre ? dpre : (out ? out : act)), el);
+    }
+    // rb: first row of the wave's 32-row fragment (wave-uniform); r: accumulator register 0 .. 15
+    __device__ __forceinline__ void put_b(int rb, int r, float v) const {
+        if (MVAE_KO_EPI && v != MVAE_KO_MAGIC) return;
+        const int is = rb + (r & 3) + 8 * (r >> 2);             // row of the LOWER half wavefront
+        int vo = voff;
+        if (C & 7) {                                            // block-uniform; channel counts here are multiples of 8
+            if (is + ((threadIdx.x & 32) ? 4 : 0) >= C) vo = BUF_OOB;
+        } else if (is >= C) {
+            return;                                             // wave-uniform: both halves are on the same side of C
+        }
+        const int so = is * HW * 4;
+        if (dpre) v *= swish_grad_(llvm_raw_buffer_load_f32(r_dpre, vo, so, 0));
+        if (out) llvm_raw_buffer_store_f32(v, r_out, vo, so, 0);
+        if (act) llvm_raw_buffer_store_f32(swishf_(v), r_act, vo, so, 0);
+    }
+    __device__ __forceinline__ void put2_b(int rb, int r, float v0, float v1) const {      // col() ran for px = 0
+        if (MVAE_KO_EPI && !(v0 == MVAE_KO_MAGIC && v1 == MVAE_KO_MAGIC)) return;
+        const int is = rb + (r & 3) + 8 * (r >> 2);
+        int vo = voff;
+        if (C & 7) {
+            if (is + ((threadIdx.x & 32) ? 4 : 0) >= C) vo = BUF_OOB;
+        } else if (is >= C) {
+            return;
+        }
+        const int so = is * HW * 4;
+        if (dpre) {
+            const f32x2_ep_t d = llvm_raw_buffer_load_f32x2_ep(r_dpre, vo, so, 0);
+            v0 *= swish_grad_(d.x); v1 *= swish_grad_(d.y);
+        }
+        f32x2_ep_t o; o.x = v0; o.y = v1;
+        if (out) llvm_raw_buffer_store_f32x2(o, r_out, vo, so, 0);
+        if (act) { f32x2_ep_t a; a.x = swishf_(v0); a.y = swishf_(v1); llvm_raw_buffer_store_f32x2(a, r_act, vo, so, 0); }
     }
 };
 
@@ -635,6 +698,8 @@ struct EpStats {
     __device__ bool col(int j) const { return j < J; }
     __device__ void put(int, int, float) const {}
 };
+template <class T, class = void> struct ep_buffer : std::false_type {};
+template <class T> struct ep_buffer<T, std::void_t<decltype(T::BUFFER)>> : std::integral_constant<bool, T::BUFFER> {};
 template <class T, class = void> struct ep_stats : std::false_type {};
 template <class T> struct ep_stats<T, std::void_t<decltype(T::STATS)>> : std::integral_constant<bool, T::STATS> {};
 
@@ -950,41 +1015,54 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             //  finished pair's stores over the next item's first k-step (+16 registers), measured 0 and -3 %: not kept.)
             // statistics-only destination (EpStats; one-tile waves): per-lane sums of v and v^2 over the block's items
             constexpr bool STATK = ep_stats<E>::value && WM * WN == 1;
-            std::conditional_t<STATK, f32x16, char> st1, st2;
+            // Sums are taken around a SHIFT -- the first value a half wavefront's lane 0 sees of each row -- so that
+            // M2 = sum((v - s)^2) - (sum(v - s))^2 / n does not cancel when a channel's mean is large against its spread
+            // (sum(v^2) - sum(v) * mean in fp32 loses every digit of the variance at |mean| / std ~ 1e3, and the
+            // clamp at 0 hid it; the two-pass BatchNorm kernels this path replaces have no such limit).  One subtract more
+            // per value; any s is exact in exact arithmetic, a sample of the row is close to its mean.
+            std::conditional_t<STATK, f32x16, char> st1, st2, shf;
+            bool have_shift = false;
             if constexpr (STATK) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st1[r] = 0.f; st2[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { st1[r] = 0.f; st2[r] = 0.f; shf[r] = 0.f; }
             }
             auto stats_flush = [&]() {
                 if constexpr (STATK) {
-                    // lanes of one half wave hold the 32 columns of rows (r & 3) + 8 * (r >> 2) + 4 * lrow
+                    // lanes of one half wave hold the 32 columns of rows (r & 3) + 8 * (r >> 2) + 4 * lrow, and share the shift
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { st1[r] = half_wave_sum(st1[r]); st2[r] = half_wave_sum(st2[r]); }
                     __syncthreads();                    // the tile buffers are free
-                    float *red = lds_raw;               // [wave][32 rows][2]
+                    float *red = lds_raw;               // [wave][32 rows][3]: sum(v - s), sum((v - s)^2), s
                     if (lcol == 0) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                            red[(wq * 32 + row) * 2 + 0] = st1[r];
-                            red[(wq * 32 + row) * 2 + 1] = st2[r];
+                            red[(wq * 32 + row) * 3 + 0] = st1[r];
+                            red[(wq * 32 + row) * 3 + 1] = st2[r];
+                            red[(wq * 32 + row) * 3 + 2] = shf[r];
                         }
                     }
                     __syncthreads();
-                    if (t < BM) {                       // row t of the block tile: its WGN column waves, in order
+                    if (t < BM) {                       // row t of the block tile: its WGN column waves, merged in order
                         const int band = t >> 5, row = t & 31;
-                        float a = 0.f, b = 0.f;
+                        const float nw = (float)(n_items * 32);         // values per (wave, row)
+                        float mw[WGN], m2w[WGN], mean = 0.f;
 #pragma unroll
                         for (int w2 = 0; w2 < WGN; ++w2) {
-                            a += red[((band * WGN + w2) * 32 + row) * 2 + 0];
-                            b += red[((band * WGN + w2) * 32 + row) * 2 + 1];
+                            const float *rr = red + ((band * WGN + w2) * 32 + row) * 3;
+                            const float d = rr[0] / nw;
+                            mw[w2] = rr[2] + d;
+                            m2w[w2] = fmaxf(rr[1] - rr[0] * d, 0.f);
+                            mean += mw[w2];
                         }
-                        const float n = (float)(n_items * BN);
-                        const float mean = a / n;
+                        mean /= (float)WGN;
+                        float m2 = 0.f;
+#pragma unroll
+                        for (int w2 = 0; w2 < WGN; ++w2) m2 += m2w[w2] + nw * (mw[w2] - mean) * (mw[w2] - mean);
                         if (i0 + t < e.C) {
                             float *dst = e.part + ((size_t)(first_item / sink.ncls) * e.C + i0 + t) * 2;
                             dst[0] = mean;
-                            dst[1] = fmaxf(b - a * mean, 0.f);
+                            dst[1] = m2;
                         }
                     }
                 }
@@ -992,11 +1070,21 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             auto finish_item = [&](int w) {             // epilogue of item w, accumulators cleared for the next
                 int c, jt; item_tile(w, c, jt);
                 if constexpr (STATK) {                  // every column is real (host: J % BN == 0)
+                    if (!have_shift) {                  // block-uniform: the first item
+                        have_shift = true;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int bits = __float_as_int(acc[0][0][r]);
+                            const float lo = __int_as_float(__builtin_amdgcn_readlane(bits, 0));
+                            const float hi = __int_as_float(__builtin_amdgcn_readlane(bits, 32));
+                            shf[r] = lrow ? hi : lo;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[0][0][r];
-                        st1[r] += v;
-                        st2[r] = fmaf(v, v, st2[r]);
+                        const float d = acc[0][0][r] - shf[r];
+                        st1[r] += d;
+                        st2[r] = fmaf(d, d, st2[r]);
                         acc[0][0][r] = 0.f;
                     }
                     return;
@@ -1011,7 +1099,13 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                     } else {
                         e.set_class(c - 1);
                         const int j = jt + wj * 32 + lcol;
-                        if (e.col(j)) {
+                        if constexpr (ep_buffer<E>::value) {
+                            e.tile(jt);
+                            (void)e.col(j);
+                            const int rb = __builtin_amdgcn_readfirstlane(i0 + wi * 32);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) e.put2_b(rb, r, hold[r], acc[0][0][r]);
+                        } else if (e.col(j)) {
                             const int ib = i0 + wi * 32 + 4 * lrow;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) e.put2(ib + (r & 3) + 8 * (r >> 2), hold[r], acc[0][0][r]);
@@ -1022,10 +1116,19 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                     return;
                 }
                 e.set_class(c);
+                if constexpr (ep_buffer<E>::value) e.tile(jt);
 #pragma unroll
                 for (int y = 0; y < WN; ++y) {
                     const int j = jt + (wj * WN + y) * 32 + lcol;
-                    if (e.col(j)) {
+                    if constexpr (ep_buffer<E>::value) {
+                        (void)e.col(j);
+#pragma unroll
+                        for (int x = 0; x < WM; ++x) {
+                            const int rb = __builtin_amdgcn_readfirstlane(i0 + (wi * WM + x) * 32);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) e.put_b(rb, r, acc[x][y][r]);
+                        }
+                    } else if (e.col(j)) {
 #pragma unroll
                         for (int x = 0; x < WM; ++x) {
                             const int ib = i0 + (wi * WM + x) * 32 + 4 * lrow;
@@ -1389,6 +1492,22 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
             }
         }
         return;
+    }
+    if constexpr (ep_buffer<E>::value) {
+        if (!partial) {         // block-uniform
+            e.tile(j0);
+#pragma unroll
+            for (int y = 0; y < WN; ++y) {
+                (void)e.col(j0 + (wj * WN + y) * 32 + lcol);
+#pragma unroll
+                for (int x = 0; x < WM; ++x) {
+                    const int rb = __builtin_amdgcn_readfirstlane(i0 + (wi * WM + x) * 32);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) e.put_b(rb, r, acc[x][y][r]);
+                }
+            }
+            return;             // (ROWSUM launches never carry an NCHW epilogue)
+        }
     }
 #pragma unroll
     for (int y = 0; y < WN; ++y) {

@@ -36,7 +36,36 @@ __global__ __launch_bounds__(256) void bce_row_block_kernel(BceArgs a) {
                      (!dx || aligned16_dev(dx));
     if (vec) {
         const int p4 = a.P / 4;
-        for (int i = threadIdx.x; i < p4; i += 256) {
+        // FOUR float4 groups per trip, all their loads issued before the first is used: one block per row leaves 512 - 2048
+        // blocks of 256 threads, and with one dependent load -> exp / log -> store chain per thread the launch moved 75 MB at
+        // 2.95 TB/s (image BCE of CelebA, 512 x 12288: profiles/r04_celeba_by_shape.txt); the sums keep their order
+        // (element i, i + 256, ... of a thread, as before)
+        constexpr int U = 4;
+        int i = threadIdx.x;
+        // (only without column weights -- the image terms: a load under the block-uniform `if (w)` would make hipcc drain the
+        //  memory queue behind it and undo the batching; weighted rows take the one-group loop below.  `1.f *` keeps the bits.)
+        for (; !w && i + 256 * (U - 1) < p4; i += 256 * U) {
+            float4 xv[U], tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = reinterpret_cast<const float4 *>(x)[i + 256 * u];
+                tv[u] = reinterpret_cast<const float4 *>(t)[i + 256 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s += 1.f * bce_elem(xv[u].x, tv[u].x) + 1.f * bce_elem(xv[u].y, tv[u].y) +
+                     1.f * bce_elem(xv[u].z, tv[u].z) + 1.f * bce_elem(xv[u].w, tv[u].w);
+                if (dx) {
+                    float4 gv;
+                    gv.x = dr * 1.f * bce_grad(xv[u].x, tv[u].x);
+                    gv.y = dr * 1.f * bce_grad(xv[u].y, tv[u].y);
+                    gv.z = dr * 1.f * bce_grad(xv[u].z, tv[u].z);
+                    gv.w = dr * 1.f * bce_grad(xv[u].w, tv[u].w);
+                    reinterpret_cast<float4 *>(dx)[i + 256 * u] = gv;
+                }
+            }
+        }
+        for (; i < p4; i += 256) {
             const float4 xv = reinterpret_cast<const float4 *>(x)[i];
             const float4 tv = reinterpret_cast<const float4 *>(t)[i];
             float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);

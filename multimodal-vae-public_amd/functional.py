@@ -13,6 +13,7 @@ directly with the loss gradient folded into the forward pass.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -200,17 +201,23 @@ def _coef_tensor(weights, B, dev):
     key = (consts, int(B), str(dev))
     base = _COEF_CACHE.get(key)
     if base is None:
+        # w * (1 / B), both in fp32 -- the arithmetic the device applies to a tensor weight below (a MULTIPLY by the rounded
+        # reciprocal: torch's division of a CUDA tensor by a host scalar is one too) -- so that a python number and the same
+        # number arriving as a device scalar (capture_step) give the same bits (0.6 / 6 rounds differently in each of:
+        # double division, fp32 division, fp32 multiply by 1/6)
+        inv_b = np.float32(1.0) / np.float32(B)
+        vals = [float(np.float32(c or 0.0) * inv_b) for c in consts]
         if torch.cuda.is_current_stream_capturing():     # (a pageable-memory upload is not capturable: fills are)
-            base = torch.stack([torch.full((), (c or 0.0) / B, dtype=torch.float32, device=dev) for c in consts])
+            base = torch.stack([torch.full((), v, dtype=torch.float32, device=dev) for v in vals])
         else:
-            base = torch.tensor([(c or 0.0) / B for c in consts], dtype=torch.float32, device=dev)
+            base = torch.tensor(vals, dtype=torch.float32, device=dev)
             _COEF_CACHE[key] = base
     if all(c is not None for c in consts):
         return base
     out = base.clone()
     for i, w in enumerate(weights):
         if torch.is_tensor(w):
-            out[i:i + 1].copy_(w.detach().reshape(1).to(torch.float32) / B)
+            out[i:i + 1].copy_(w.detach().reshape(1).to(torch.float32) * float(np.float32(1.0) / np.float32(B)))
     return out
 
 

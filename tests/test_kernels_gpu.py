@@ -979,6 +979,38 @@ def test_convT_stats_only_matches_conv_then_batchnorm(G, B, Cin, H, Cout):
     assert_close(rvd, rv2, 'running_var vs sweep', tol=1e-5)
 
 
+def test_convT_stats_only_with_a_channel_mean_far_from_zero():
+    """the statistics-only epilogue took M2 as sum(v^2) - sum(v) * mean in fp32 -- at |mean| / std ~ 1e3 every
+    digit of the variance cancels (and a clamp at 0 hid it), while the two-pass BatchNorm kernels it replaces have no such
+    limit.  Sums are now taken around a sample of the row.  Here every output sits near 640 with a spread of ~0.1."""
+    G, B, Cin, H, Cout = 1, 8, 64, 16, 32
+    x = g(G * B, Cin, H, H, seed=64).abs() * 0.01 + 5.0
+    w = 0.5 + 0.002 * g(Cin, Cout, 4, 4, seed=65)
+    y = F.conv_transpose2d(x.double(), w.double(), None, 2, 1)
+    mean = y.mean(dim=(0, 2, 3))
+    var = y.var(dim=(0, 2, 3), unbiased=False)
+    assert (mean.abs() / var.sqrt()).min().item() > 1e3           # the hard regime
+    xd, wd = dev(x), dev(w)
+    part = K.convT2d_fwd_stats(xd, wd, 2, 1)
+    sm = torch.empty(G, Cout, device=DEV); si = torch.empty(G, Cout, device=DEV)
+    rmd, rvd = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    K.bn_stats_merge(part, G, sm, si, rmd, rvd, n_updates=1)
+    n = y.numel() // Cout
+    rv_ref = 0.9 + 0.1 * var * n / (n - 1)
+    assert_close(sm[0], mean.float(), 'mean', tol=1e-6)
+    # the conv's own fp32 round-off (~4e-5 absolute on values of 640) bounds what any variance estimate can reach here
+    assert_close(si[0], (var + 1e-5).rsqrt().float(), 'invstd at mean/std > 1e3', tol=2e-2)
+    assert_close(rvd, rv_ref.float(), 'running_var at mean/std > 1e3', tol=2e-2)
+    # ... and the storing launch + two-pass sweep agree with it as closely
+    pre = torch.empty(G * B, Cout, 2 * H, 2 * H, device=DEV)
+    K.convT2d_fwd(xd, wd, pre, None, 2, 1)
+    rm2, rv2 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    sm2 = torch.empty(G, Cout, device=DEV); si2 = torch.empty(G, Cout, device=DEV)
+    K.bn_train_fwd(pre, torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV), None, sm2, si2, rm2, rv2, G,
+                   n_updates=1, swish=False)
+    assert_close(rvd, rv2, 'running_var vs the two-pass sweep', tol=2e-2)
+
+
 def test_convT_stats_only_refuses_what_it_does_not_cover():
     xd = torch.zeros(4, 64, 16, 16, device=DEV)
     assert K.convT2d_stats_tiles(xd, torch.zeros(64, 64, 4, 4, device=DEV), 2, 1) == 0       # 64 output channels
