@@ -51,14 +51,21 @@ __device__ __forceinline__ float half_wave_max(float v) {
 }
 
 // Bernoulli reconstruction term on a logit: clamp(x,0) - x*t + log(1 + exp(-|x|))   (mnist/train.py:73-74)
+// exp / log through the hardware's base-2 instructions (v_exp_f32 / v_log_f32, ~1 ulp) like the sigmoid above: libm's expf +
+// logf + an IEEE divide were ~85 vector instructions per element for value + gradient -- 13.6 us of pure ALU time in the
+// 25.6-us image term of CelebA (512 x 12288 logits, profiles/r04_celeba_by_shape.txt), and 1.7 us inside the epilogue of
+// MNIST's loss-carrying last Linear, which sits on the step's critical chain.  The argument of the exp is <= 0 and that of
+// the log in (1, 2]: no range handling is needed.  Relative error of a term ~1e-7, against the 1e-4 the step is graded at.
+__device__ __forceinline__ float bce_exp_(float x) { return __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896340736f); }
 __device__ __forceinline__ float bce_elem(float x, float t) {
-    return fmaxf(x, 0.f) - x * t + logf(1.0f + expf(-fabsf(x)));
+    return fmaxf(x, 0.f) - x * t + __builtin_amdgcn_logf(1.0f + bce_exp_(x)) * 0.69314718055994530942f;
 }
 // autograd of the expression above, term by term: 1[x>=0] - t - sign(x) * e/(1+e), e = exp(-|x|)
+// (at x == 0 the reference's sub-gradient: 1 - t, SURVEY Appendix B-3 -- the comparisons below keep it)
 __device__ __forceinline__ float bce_grad(float x, float t) {
-    const float e = expf(-fabsf(x));
+    const float e = bce_exp_(x);
     const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-    return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e / (1.0f + e));
+    return ((x >= 0.f) ? 1.f : 0.f) - t - sgn * (e * __builtin_amdgcn_rcpf(1.0f + e));
 }
 
 // One element of torch.optim.Adam (defaults: no weight decay, no amsgrad; mnist/train.py:168,219), shared by the

@@ -80,15 +80,18 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
 #define MVAE_FINISH_PREFETCH 0
 #endif
 #ifndef MVAE_PHASED_PRELOAD
-#define MVAE_PHASED_PRELOAD 0    // k-grouped blocks, two tiles really in flight (see the phased loop): 1 = every wave issues the tile loads
-                                 // (out of range for the MFMA-only waves), 2 = those waves run a load-free copy of the loop.
-                                 // 1 measured ONCE: parity green (109 tests), MNIST 0.2851 -> 0.2920 ms -- off; 2 never run
+#define MVAE_PHASED_PRELOAD 2    // k-grouped blocks, two tiles really in flight (see the phased loop): 1 = every wave issues the tile loads
+                                 // (out of range for the MFMA-only waves), 2 = those waves run a load-free copy of the loop, 0 = rounds 1-4.
+                                 // Round 4 measured 1 once (+2.4 %) and never ran 2.  Round 5, x3 interleaved on one box
+                                 // (profiles/r05_mnist_switches_ab.txt): 0: 0.2874 / 0.2897 / 0.2854 ms, 1: 0.2918 / 0.2928 / 0.2896,
+                                 // 2: 0.2780 / 0.2837 / 0.2837 -- the movers' copy has no control-flow merge between its loads and its
+                                 // stores, the compiler's wait counts are the two-tiles-in-flight ones, and the MFMA-only waves issue
+                                 // no dummy loads: MNIST -2 %; 111 parity tests green on that build.  Adopted.
 #endif
 #ifndef MVAE_CHAIN_PRIO
 #define MVAE_CHAIN_PRIO 0        // 1-3: the k-grouped (small-layout) GEMMs -- the launches of MNIST's data-gradient chains -- raise their
-                                 // wave priority for their whole run: co-resident with a weight-gradient batch (priority 0, off the
-                                 // chain) their instructions issue first (profiles/r04_mnist_step_timeline.txt: a 9-us chain GEMM
-                                 // took 27.9 us beside the batch)
+                                 // wave priority for their whole run.  Measured x3 (profiles/r05_wgrad_ab.txt): nothing -- beside a
+                                 // weight-gradient batch the two launches share the MFMA pipes whatever their priority.  Off.
 #endif
 #ifndef MVAE_EP_BUFFER
 #define MVAE_EP_BUFFER 1         // NCHW tile epilogues through buffer stores: per-lane column offset + SCALAR row offset, no 64-bit

@@ -391,10 +391,22 @@ class _StepBase(object):
         if self._fusion is not None:
             self._fusion.begin()
             self._adam_prepare = lambda: optimizer.prepare_counted(self._fusion)
+        # MVAE_SPLIT_ADAM=1: the decoders' parameters (the front of the arena) are updated on the MAIN stream as soon as
+        # their weight-gradient batches -- on the side stream -- are final, beside the encoders' backward; only the encoders'
+        # range is left for the end of the chain (see BimodalStep._phase_b)
+        self._adam_split = None
+        if (early and self._fusion is None and os.environ.get('MVAE_SPLIT_ADAM', '0') == '1'
+                and hasattr(optimizer, 'step_counted_range') and getattr(self, 'supports_split_adam', False)):
+            from .parallel import bucket_ranges
+            ranges = bucket_ranges(self.model, self.model.arena)
+            if len(ranges) >= 2:
+                self._adam_split = (optimizer, ranges[0][1], self.model.arena.numel)
         try:
             self._body_a()
             self._phase_b('all')
-            if early:
+            if self._adam_split is not None and self._carry.get('adam_dec_done'):
+                optimizer.step_counted_range(self._adam_split[1], self._adam_split[2], last=True)
+            elif early:
                 optimizer.step_counted(self._fusion) if self._fusion is not None else optimizer.step_counted()
             else:
                 optimizer.step()
@@ -402,6 +414,7 @@ class _StepBase(object):
             self._step_end()
             self._adam_counter = None
             self._fusion = None
+            self._adam_split = None
 
     def _dp_step(self, optimizer):
         """One data-parallel step as a plain launch sequence (capturable when the communicator is): bucket k's
@@ -512,6 +525,7 @@ class _StepBase(object):
 
 
 class BimodalStep(_StepBase):
+    supports_split_adam = True
     """Fused step for ``mnist`` / ``fashionmnist`` / ``celeba`` MVAEs."""
 
     def __init__(self, model, batch_size, lambda_image=1.0, lambda_label=1.0, seed=0):
@@ -995,6 +1009,10 @@ class BimodalStep(_StepBase):
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev_img)
                     wi.flush()
+                    if getattr(self, '_adam_split', None) is not None:
+                        ev_dec = torch.cuda.Event()
+                        ev_dec.record()              # every decoder weight gradient is final behind this
+                        c['ev_dec_grads'] = ev_dec
                     if dp_side:
                         self._comm.launch(0)         # every decoder gradient is final here, on THIS stream
                         self._bucket0_done = True
@@ -1091,6 +1109,11 @@ class BimodalStep(_StepBase):
             if fork is not None:
                 label_encoder_backward(fork)
             self._late_elbo()
+            if getattr(self, '_adam_split', None) is not None and c.get('ev_dec_grads') is not None:
+                opt, split, _ = self._adam_split
+                torch.cuda.current_stream(self.dev).wait_event(c['ev_dec_grads'])
+                opt.step_counted_range(0, split)     # the main stream waits for the side stream here anyway
+                c['adam_dec_done'] = True
             self._join()
             if wi is not None:
                 fns = wi + wl

@@ -164,6 +164,21 @@ class FusedAdam(torch.optim.Optimizer):
         self._host_step += 1
 
     @torch.no_grad()
+    def step_counted_range(self, lo, hi, last=False):
+        """``step_counted()`` in pieces: Adam on arena elements [lo, hi) at t = the (already advanced) counter.  A fused
+        step updates its decoders' range as soon as their weight gradients are final -- beside the encoders' backward --
+        and only the encoders' range at the end of the chain; ``last`` closes the step on the host side."""
+        arena = self._arena
+        g = self.param_groups[0]
+        K.adam_apply_at(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, 0,
+                        g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+        if last:
+            for p in arena.params:
+                if p.grad is None:
+                    raise RuntimeError('a parameter received no gradient this step')
+            self._host_step += 1
+
+    @torch.no_grad()
     def step_range(self, lo, hi):
         """Adam on arena elements [lo, hi) at the CURRENT step (counter not advanced): data-parallel
         replicas call this per gradient bucket as its all-reduce lands, then ``advance()`` once."""

@@ -352,6 +352,29 @@ def test_captured_step_with_early_counter_equals_update_plus_counter_launch(monk
     assert torch.equal(finals[0], finals[1])
 
 
+@pytest.mark.parametrize('kind,batch', [('mnist', 24), ('celeba', 6)])
+def test_decoders_updated_early_is_the_same_update(kind, batch, monkeypatch):
+    """MVAE_SPLIT_ADAM=1: the captured step runs Adam on the decoders' arena range as soon as their weight gradients are
+    final (main stream, beside the encoders' backward) and on the encoders' range at the end -- element for element the
+    arithmetic of the one arena-wide launch: parameters, moments and counter equal to the last bit after 3 replays."""
+    finals = []
+    for split in ('1', '0'):
+        monkeypatch.setenv('MVAE_SPLIT_ADAM', split)
+        _, model, _ = build_pair(kind, weight_seed=31)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        eng = BimodalStep(model, batch, 1.0, 10.0 if kind == 'celeba' else 50.0, seed=9)
+        image, label = OS.synthetic_batch(kind, batch, seed=720)
+        eng.capture(opt, image.shape[1:], label)
+        for step in range(3):
+            image, label = OS.synthetic_batch(kind, batch, seed=730 + step)
+            eng.replay(image.to(DEV), label.to(DEV), 0.5)
+        torch.cuda.synchronize()
+        assert opt._step_dev.item() == 3
+        finals.append((model.arena.flat.clone(), opt._m.clone(), opt._v.clone()))
+    for a, b, what in zip(finals[0], finals[1], ('parameters', 'exp_avg', 'exp_avg_sq')):
+        assert torch.equal(a, b), what
+
+
 @pytest.mark.parametrize('kind,batch', [('mnist', 24), ('mnist', 512), ('fashionmnist', 8)])
 def test_weight_gradient_launches_that_update_their_parameters(kind, batch, monkeypatch):
     """MVAE_FUSE_ADAM=1: the Linear weight-gradient batches of the captured single-GPU step run optimizer.step() on

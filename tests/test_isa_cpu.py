@@ -64,9 +64,13 @@ def test_small_layout_epilogue_loads_only_the_accumulate_operand(linear_kernels,
     lines = linear_kernels[kernel]
     # one optional load per output is left behind the reduction: `if (accumulate) v += out[idx]`
     assert _loads_behind_last_mfma(lines) <= outputs, kernel
-    # ... and the pre-activation / mask (and bias) of every output were requested before the first matrix instruction,
-    # next to the first tiles' own loads (with the operands fetched inside the epilogue the count is tile_loads)
-    assert _loads_ahead_of_first_mfma(lines) >= tile_loads + 2 * outputs, kernel
+    # ... and the pre-activation / mask (and bias) of every output were requested before the first matrix instruction.
+    # (Since MVAE_PHASED_PRELOAD=2 the MFMA-only waves' load-free copy of the loop comes first in the text, so the movers'
+    # first tile loads are no longer textually ahead of the first v_mfma: what IS ahead of it is exactly the epilogue's
+    # operand prefetch, issued before the waves part ways; the tile loads are counted over the whole kernel.)
+    assert _loads_ahead_of_first_mfma(lines) >= 2 * outputs, kernel
+    total = sum(1 for l in lines if re.match(r'(global_load|buffer_load|flat_load)', l))
+    assert total >= tile_loads + 2 * outputs, kernel
 
 
 @pytest.mark.parametrize('epilogue', ['EpRowBce', 'EpRowCe'])
