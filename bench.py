@@ -250,7 +250,9 @@ def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
     # committed tables: where they were collected, and whether the kernel sources have changed since
     roof['committed_profiles'] = {'traffic': traffic_stamp, 'rocprof': rocprof_stamp}
     roof['profile_head'] = (rocprof_stamp or traffic_stamp or {}).get('head')
-    roof['profile_stale'] = bool((rocprof_stamp or {'stale': True})['stale'] or (traffic_stamp or {'stale': True})['stale'])
+    stamps = [st for st in (rocprof_stamp, traffic_stamp) if st]
+    # true: a quoted table was collected on other kernel sources than this tree's; null: nothing is quoted for this call
+    roof['profile_stale'] = any(st['stale'] for st in stamps) if stamps else None
     conv = [r for r in gemm if r['name'].startswith('conv')]
     if conv:
         fl = sum(r['flops'] * r['calls'] for r in conv) / n_steps

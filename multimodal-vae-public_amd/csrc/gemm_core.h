@@ -88,6 +88,14 @@ extern MvaeTune g_mvae_tune;      // defined in linear.hip
                                  // stores, the compiler's wait counts are the two-tiles-in-flight ones, and the MFMA-only waves issue
                                  // no dummy loads: MNIST -2 %; 111 parity tests green on that build.  Adopted.
 #endif
+#ifndef MVAE_PHASED_DEPTH
+#define MVAE_PHASED_DEPTH 2      // register sets (k-tiles in flight) of the movers in the k-grouped layouts' loop: 2, or 4 (A/B).  FOUR
+                                 // tiles in flight make the launch itself faster (MNIST's 1024 x 512 x 512: 13.2 -> 12.4 us by rocprof,
+                                 // single stream) and the STEP 9 % slower (0.3067-0.3077 vs 0.2808-0.2812 ms, x3 interleaved,
+                                 // profiles/r05_mnist_switches_ab.txt): the movers then hold 171 registers, a 512-thread block fills
+                                 // half of every SIMD's register file, and the two chain kernels the step's two streams run side
+                                 // by side no longer share a CU.  Two tiles: 116-122 registers, two blocks per CU.
+#endif
 #ifndef MVAE_CHAIN_PRIO
 #define MVAE_CHAIN_PRIO 0        // 1-3: the k-grouped (small-layout) GEMMs -- the launches of MNIST's data-gradient chains -- raise their
                                  // wave priority for their whole run.  Measured x3 (profiles/r05_wgrad_ab.txt): nothing -- beside a
@@ -1316,6 +1324,57 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                         __syncthreads();
                     }
                     if (s < nsteps) {
+                        compute(0, no_hook);
+                        __syncthreads();
+                    }
+                    return;
+                }
+                if constexpr (MVAE_PHASED_PRELOAD == 2 && MVAE_PHASED_DEPTH == 4 && P::TAIL && Q::TAIL) {
+                    // FOUR tiles in flight in the movers' registers (only movers get here).  A k-step of these layouts is 8
+                    // MFMAs per wave -- 0.2 us -- against ~1 us for an L2 / fabric round trip: with two tiles ahead a step
+                    // still ends waiting for its successor's loads (MNIST's 1024 x 512 x 512 launches: 13.2 us for 3.4 us
+                    // of matrix time, profiles/r05_mnist_by_shape.txt).  A 512-thread block runs two waves per SIMD, so a
+                    // mover may hold 256 registers: four (P, Q) register sets.  Tiles beyond the reduction are requested
+                    // at their own k: the row loaders' TAIL rule turns every such load into an out-of-range one -- no
+                    // traffic, zeros nobody stages.  Same barriers as the load-free copy above: 1 + nsteps.
+                    typename P::Regs pr2, pr3;
+                    typename Q::Regs qr2, qr3;
+                    auto tk = [&](int s2) { return kbeg + s2 * BKK; };
+                    LOAD(fullc, tk(0), pr0, qr0); LOAD(fullc, tk(1), pr1, qr1);
+                    LOAD(fullc, tk(2), pr2, qr2); LOAD(fullc, tk(3), pr3, qr3);
+                    STORE(fullc, 0, pr0, qr0);
+                    __syncthreads();
+                    int s = 0;
+                    for (; s + 3 < nsteps; s += 4) {
+                        LOAD(fullc, tk(s + 4), pr0, qr0);
+                        compute(0, no_hook);
+                        STORE(fullc, 1, pr1, qr1);
+                        __syncthreads();
+                        LOAD(fullc, tk(s + 5), pr1, qr1);
+                        compute(1, no_hook);
+                        STORE(fullc, 0, pr2, qr2);
+                        __syncthreads();
+                        LOAD(fullc, tk(s + 6), pr2, qr2);
+                        compute(0, no_hook);
+                        STORE(fullc, 1, pr3, qr3);
+                        __syncthreads();
+                        LOAD(fullc, tk(s + 7), pr3, qr3);
+                        compute(1, no_hook);
+                        if (s + 4 < nsteps) STORE(fullc, 0, pr0, qr0);
+                        __syncthreads();
+                    }
+                    const int left = nsteps - s;        // 0 .. 3 steps: tile s sits in buffer 0, s + 1 / s + 2 in sets 1 / 2
+                    if (left >= 1) {
+                        compute(0, no_hook);
+                        if (left >= 2) STORE(fullc, 1, pr1, qr1);
+                        __syncthreads();
+                    }
+                    if (left >= 2) {
+                        compute(1, no_hook);
+                        if (left >= 3) STORE(fullc, 0, pr2, qr2);
+                        __syncthreads();
+                    }
+                    if (left >= 3) {
                         compute(0, no_hook);
                         __syncthreads();
                     }

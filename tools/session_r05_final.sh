@@ -11,7 +11,7 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 
 timeout 600 bash tools/collect_by_shape.sh > $out/by_shape.log 2>&1
 cp gpurun_out/by_shape/r05_* $out/ 2>/dev/null
 cp gpurun_out/by_shape/r05_by_shape.json profiles/r05_by_shape.json 2>/dev/null
-TRAFFIC_TABLE=r05_traffic.json timeout 600 bash tools/collect_traffic.sh "linear_wgrad_batched|4 layers" "linear_dgrad|M1024 N512 K512" "convT2d_dgrad|512x256x5x5" "convT2d_dgrad|2048x128x7x7" "convT2d_fwd|4608x128x8x8" "convT2d_wgrad|256x128x4x4" > $out/traffic.log 2>&1
+TRAFFIC_TABLE=r05_traffic.json timeout 600 bash tools/collect_traffic.sh "linear_fwd|M1024 N512 K512" "linear_wgrad_batched|4 layers" "linear_dgrad|M1024 N512 K512" "convT2d_fwd|2048x64x14x14" "convT2d_dgrad|512x256x5x5" "convT2d_dgrad|2048x128x7x7" "convT2d_fwd|4608x128x8x8" "convT2d_wgrad|256x128x4x4" > $out/traffic.log 2>&1
 cp gpurun_out/r05_traffic.json $out/ 2>/dev/null; cp gpurun_out/r05_traffic.json profiles/r05_traffic.json 2>/dev/null
 t0=$(date +%s); timeout 600 python bench.py > $out/r05_bench_default.json 2> $out/bench.err; echo "bench rc=$? wall=$(( $(date +%s) - t0 ))s" >> $out/status.txt
 timeout 600 bash tools/collect_profiles.sh > $out/collect_profiles.log 2>&1
