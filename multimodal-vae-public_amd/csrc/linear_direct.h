@@ -274,6 +274,12 @@ template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(
 #ifndef MVAE_WB2_KW
 #define MVAE_WB2_KW 0            // A/B builds: force the waves per tile (2 .. 16)
 #endif
+#ifndef MVAE_WB2_PD22
+#define MVAE_WB2_PD22 1          // chunks of 8 rows per register set of the 64 x 64 wave tile.  2: ~150 registers; 1: 121 -- a chain kernel's
+#endif                           // 512-thread block (116-122 registers) then FITS BESIDE a batch block on a CU.  The launch alone is
+                                 // the same (24.5 vs 24.8 us), the MNIST step 2 % faster (0.2789-0.2802 vs 0.2844-0.2860 ms, x4
+                                 // interleaved, profiles/r05_wgrad_ab.txt): sharing a CU is what the step's two streams need,
+                                 // the same effect that makes four k-tiles in flight lose (gemm_core.h MVAE_PHASED_DEPTH)
 #ifndef MVAE_WB2_PRIO
 #define MVAE_WB2_PRIO 0          // A/B builds: wave priority of the batch kernel (the batches sit on the side stream's chain)
 #endif
@@ -537,7 +543,7 @@ inline bool wgrad_batched2_launch(const WgradBatchArgs &a, hipStream_t st, int *
         hipLaunchKernelGGL(kern, grid, dim3(64 * KWV), lds, st, b);                                           \
     }
     if (shape == 22) {
-        if (kw >= 16) MVAE_WB2(16, 2, 2, 1) else if (kw == 8) MVAE_WB2(8, 2, 2, 2) else MVAE_WB2(4, 2, 2, 2)
+        if (kw >= 16) MVAE_WB2(16, 2, 2, 1) else if (kw == 8) MVAE_WB2(8, 2, 2, MVAE_WB2_PD22) else MVAE_WB2(4, 2, 2, MVAE_WB2_PD22)
     } else if (shape == 21) {
         if (kw >= 16) MVAE_WB2(16, 2, 1, 2) else if (kw == 8) MVAE_WB2(8, 2, 1, 2) else if (kw == 4) MVAE_WB2(4, 2, 1, 3) else MVAE_WB2(2, 2, 1, 3)
     } else {
