@@ -280,6 +280,10 @@ template <int KW, bool ADAM> __device__ __forceinline__ void wgrad_batched_body(
                                  // the same (24.5 vs 24.8 us), the MNIST step 2 % faster (0.2789-0.2802 vs 0.2844-0.2860 ms, x4
                                  // interleaved, profiles/r05_wgrad_ab.txt): sharing a CU is what the step's two streams need,
                                  // the same effect that makes four k-tiles in flight lose (gemm_core.h MVAE_PHASED_DEPTH)
+#ifndef MVAE_WB2_PD11
+#define MVAE_WB2_PD11 2          // chunks per register set of the 32 x 32 wave tile: 2 (48-63 registers) instead of 4 (82-98): the launch
+                                 // alone 19.8 -> 18.9 us (label decoder), 12.9 -> 11.8 us (image encoder); the step unchanged (x4)
+#endif
 #ifndef MVAE_WB2_PRIO
 #define MVAE_WB2_PRIO 0          // A/B builds: wave priority of the batch kernel (the batches sit on the side stream's chain)
 #endif
@@ -547,7 +551,7 @@ inline bool wgrad_batched2_launch(const WgradBatchArgs &a, hipStream_t st, int *
     } else if (shape == 21) {
         if (kw >= 16) MVAE_WB2(16, 2, 1, 2) else if (kw == 8) MVAE_WB2(8, 2, 1, 2) else if (kw == 4) MVAE_WB2(4, 2, 1, 3) else MVAE_WB2(2, 2, 1, 3)
     } else {
-        if (kw >= 16) MVAE_WB2(16, 1, 1, 4) else if (kw == 8) MVAE_WB2(8, 1, 1, 4) else MVAE_WB2(4, 1, 1, 4)
+        if (kw >= 16) MVAE_WB2(16, 1, 1, MVAE_WB2_PD11) else if (kw == 8) MVAE_WB2(8, 1, 1, MVAE_WB2_PD11) else MVAE_WB2(4, 1, 1, MVAE_WB2_PD11)
     }
 #undef MVAE_WB2
     *status = mvae_launch_status();
