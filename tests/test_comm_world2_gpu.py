@@ -107,7 +107,10 @@ def _worker(rank, world, port, kind, batch, input_seed, out_dir, die_after):
 
 
 def _spawn(kind, batch, input_seed, out_dir, die_after=-1, timeout=600):
+    import subprocess
     import torch.multiprocessing as mp
+    if not os.path.exists(STUB):        # normally built by __graft_entry__.build(); the box has the same toolchain
+        subprocess.run(['make', '-C', os.path.dirname(STUB)], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert os.path.exists(STUB), '%s is not built: run __graft_entry__.build()' % STUB
     ctx = mp.get_context('spawn')
     port = _free_port()
