@@ -1163,10 +1163,10 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                     const int kn = kof(g + 1), nb = (g + 1) & 1;
                     compute(g & 1, [&](int st, int ns) {
                         const int nl = (WM * WN >= 4) ? ns / 4 : ns / 8;
-                        if (st < nl) { p.load_part(kn, kend, t, pr0, st, nl); q.load_part(kn, kend, t, qr0, st, nl); }
-                        if (st >= ns - nl) { p.store_part(Ps(nb), t, pr0, st - (ns - nl), nl); q.store_part(Qs(nb), t, qr0, st - (ns - nl), nl); }
+                        if (MVAE_KO < 1 && st < nl) { p.load_part(kn, kend, t, pr0, st, nl); q.load_part(kn, kend, t, qr0, st, nl); }
+                        if (MVAE_KO < 2 && st >= ns - nl) { p.store_part(Ps(nb), t, pr0, st - (ns - nl), nl); q.store_part(Qs(nb), t, qr0, st - (ns - nl), nl); }
                     });
-                    __syncthreads();
+                    if (MVAE_KO < 3) __syncthreads();
                     if (last) finish_item(g / nsteps);
                 }
                 compute((G - 1) & 1, no_hook);
@@ -1186,10 +1186,10 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 const int k2 = kof(g + 2);
                 compute(0, [&](int st, int ns) {
                     const int nl = ns / 2;
-                    if (st < nl) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); }
-                    else { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
+                    if (st < nl) { if (MVAE_KO < 1) { p.load_part(k2, kend, t, pr0, st, nl); q.load_part(k2, kend, t, qr0, st, nl); } }
+                    else if (MVAE_KO < 2) { p.store_part(Ps(1), t, pr1, st - nl, ns - nl); q.store_part(Qs(1), t, qr1, st - nl, ns - nl); }
                 });
-                __syncthreads();
+                if (MVAE_KO < 3) __syncthreads();
                 if ((g + 1) % nsteps == 0) finish_item(g / nsteps);
                 // odd step g+1 on buffer 1: fetch tile g+3 into set 1 (the last tile again when there is none), stage
                 // tile g+2 (set 0) in buffer 0
@@ -1198,10 +1198,10 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
                 const int k3 = kof(more3 ? g + 3 : g + 2);
                 compute(1, [&](int st, int ns) {
                     const int nl = ns / 2;
-                    if (st < nl) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); }
-                    else { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
+                    if (st < nl) { if (MVAE_KO < 1) { p.load_part(k3, kend, t, pr1, st, nl); q.load_part(k3, kend, t, qr1, st, nl); } }
+                    else if (MVAE_KO < 2) { p.store_part(Ps(0), t, pr0, st - nl, ns - nl); q.store_part(Qs(0), t, qr0, st - nl, ns - nl); }
                 });
-                __syncthreads();
+                if (MVAE_KO < 3) __syncthreads();
                 if ((g + 2) % nsteps == 0) finish_item((g + 1) / nsteps);
             }
             // tail: tile g is staged in buffer 0; tile g+1 (if any) waits in register set 1
