@@ -79,6 +79,7 @@ CONV_CASES = {
     ('conv2d_fwd', '256x64x16x16'): ('conv', 256, 32, 32, 64, 2, 1),
     # FashionMNIST B = 1024 (two image-decoder terms): ConvTranspose2d(128, 64) on 7x7 maps, fashionmnist/model.py:112
     ('convT2d_dgrad', '2048x128x7x7'): ('convT', 2048, 128, 7, 64, 2, 1),
+    ('convT2d_fwd', '2048x64x14x14'): ('convT', 2048, 128, 7, 64, 2, 1),
     # CelebA-19 B = 256: the 18 statistics-only decodes of ConvTranspose2d(256, 128) 5x5 -> 8x8, celeba19/model.py:143
     ('convT2d_fwd', '4608x128x8x8'): ('convT', 4608, 256, 5, 128, 1, 0),
 }
