@@ -82,6 +82,8 @@ CONV_CASES = {
     ('convT2d_fwd', '2048x64x14x14'): ('convT', 2048, 128, 7, 64, 2, 1),
     # CelebA-19 B = 256: the 18 statistics-only decodes of ConvTranspose2d(256, 128) 5x5 -> 8x8, celeba19/model.py:143
     ('convT2d_fwd', '4608x128x8x8'): ('convT', 4608, 256, 5, 128, 1, 0),
+    # ... and its ConvTranspose2d(128, 64) 8x8 -> 16x16: the 16x16 sibling of FashionMNIST's 7x7 -> 14x14 launch (L2 comparison)
+    ('convT2d_fwd', '4608x64x16x16'): ('convT', 4608, 128, 8, 64, 2, 1),
 }
 
 
@@ -157,8 +159,28 @@ def collect(fetch_db, write_db, out_json, name, key):
     print(json.dumps(ent, indent=1))
 
 
+def counters(db):
+    """Any --pmc pass over ``run``: every counter, per launch, of the kernels one call launches (L2 hit / miss, fabric requests)."""
+    c = sqlite3.connect(db)
+    rows = c.execute('select kernel_name, counter_name, value from counters_collection').fetchall()
+    acc = {}
+    for n, cn, v in rows:
+        if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_batched|wgrad_smallcin', n):
+            short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:100]
+            acc.setdefault(short, {}).setdefault(cn, 0.0)
+            acc[short][cn] += v / N_CALLS
+    for k, d in acc.items():
+        print(k)
+        for cn in sorted(d):
+            print('    %-26s %14.0f' % (cn, d[cn]))
+        if 'TCC_HIT_sum' in d and 'TCC_MISS_sum' in d:
+            print('    %-26s %14.3f' % ('L2 hit rate', d['TCC_HIT_sum'] / max(1.0, d['TCC_HIT_sum'] + d['TCC_MISS_sum'])))
+
+
 if __name__ == '__main__':
     if sys.argv[1] == 'run':
         run(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'counters':
+        counters(sys.argv[2])
     else:
         collect(*sys.argv[2:7])
