@@ -11,6 +11,7 @@ the latent path of ``MVAE.forward``.  Every ``Function`` is a thin shell over HI
 The fused train step (``engine.py``) does not go through these: it launches the same kernels
 directly with the loss gradient folded into the forward pass.
 """
+import collections
 import ctypes
 
 import numpy as np
@@ -184,7 +185,10 @@ class _KlRowsFn(torch.autograd.Function):
         return dmu, dlv
 
 
-_COEF_CACHE = {}
+# bounded: an annealing schedule hands elbo_loss a new factor every step (mnist/train.py:184-194: ~10^5 distinct values
+# over a run), and each entry pins a device allocation
+_COEF_CACHE = collections.OrderedDict()
+_COEF_CACHE_MAX = 128
 
 
 def _w(x):
@@ -200,18 +204,22 @@ def _coef_tensor(weights, B, dev):
     consts = tuple(None if torch.is_tensor(w) else float(w) for w in weights)
     key = (consts, int(B), str(dev))
     base = _COEF_CACHE.get(key)
-    if base is None:
+    if base is not None:
+        _COEF_CACHE.move_to_end(key)
+    else:
         # w * (1 / B), both in fp32 -- the arithmetic the device applies to a tensor weight below (a MULTIPLY by the rounded
         # reciprocal: torch's division of a CUDA tensor by a host scalar is one too) -- so that a python number and the same
         # number arriving as a device scalar (capture_step) give the same bits (0.6 / 6 rounds differently in each of:
         # double division, fp32 division, fp32 multiply by 1/6)
         inv_b = np.float32(1.0) / np.float32(B)
         vals = [float(np.float32(c or 0.0) * inv_b) for c in consts]
-        if torch.cuda.is_current_stream_capturing():     # (a pageable-memory upload is not capturable: fills are)
+        if torch.device(dev).type == 'cuda' and torch.cuda.is_current_stream_capturing():     # (a pageable-memory upload is not capturable: fills are)
             base = torch.stack([torch.full((), v, dtype=torch.float32, device=dev) for v in vals])
         else:
             base = torch.tensor(vals, dtype=torch.float32, device=dev)
             _COEF_CACHE[key] = base
+            if len(_COEF_CACHE) > _COEF_CACHE_MAX:
+                _COEF_CACHE.popitem(last=False)       # least recently used; a graph or an autograd node keeps its own reference
     if all(c is not None for c in consts):
         return base
     out = base.clone()

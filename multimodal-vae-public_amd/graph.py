@@ -72,7 +72,8 @@ class CapturedStep(object):
                 self.static.append(None)
             else:
                 raise TypeError('capture_step arguments are tensors, python numbers or None (got %s)' % type(a).__name__)
-        model.finalize()
+        if hasattr(model, 'finalize'):
+            model.finalize()
         bns = [m for m in model.modules() if isinstance(m, L._BatchNormMixin)]
         # ---- everything the warm-up passes mutate, to be put back: the capture must leave no trace
         params = [p.detach().clone() for p in model.parameters()]
@@ -80,8 +81,9 @@ class CapturedStep(object):
         pend = [m._nbt_pending for m in bns]
         rng = model.__dict__.get('_rng')
         rng_ctr = None if rng is None else rng[1].clone()
-        had_state = len(_optimizer_tensors(optimizer)) > 0
-        opt_state = [t.detach().clone() for t in _optimizer_tensors(optimizer)] if had_state else None
+        # optimizer state is updated in place (FusedAdam, capturable Adam): a tensor that exists now is put back, one the
+        # warm-up creates is what a fresh optimizer would hold -- zeros
+        opt_state = {id(t): (t, t.detach().clone()) for t in _optimizer_tensors(optimizer)}
         host_step = getattr(optimizer, '_host_step', None)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
@@ -108,12 +110,11 @@ class CapturedStep(object):
                 rng[1].copy_(rng_ctr)
             elif model.__dict__.get('_rng') is not None:
                 model.__dict__['_rng'][1].zero_()
-            now = _optimizer_tensors(optimizer)
-            if opt_state is not None and len(opt_state) == len(now):
-                for t, s in zip(now, opt_state):
-                    t.copy_(s)
-            else:                                           # state was created by the warm-up: a fresh optimizer has zeros
-                for t in now:
+            for t in _optimizer_tensors(optimizer):
+                saved = opt_state.get(id(t))
+                if saved is not None and saved[0] is t:
+                    t.copy_(saved[1])
+                else:
                     t.zero_()
             if host_step is not None:
                 optimizer._host_step = host_step

@@ -265,3 +265,26 @@ def test_adam_fusion_rest_ranges():
         f.cover(G(offs[2] + 5, 3))
     with pytest.raises(RuntimeError):
         f.cover(G(off - 2, 8))
+
+
+def test_loss_coefficient_cache_is_bounded_and_exact():
+    """elbo_loss's w_i / B coefficients (functional._coef_tensor): an annealing schedule passes a new factor every step
+    (mnist/train.py:184-194), so the per-value cache must not grow with the run; a value that falls out is rebuilt to the
+    same bits -- f32(w) * f32(1 / B), the arithmetic the device applies to a weight that arrives as a tensor."""
+    from mvae_amd import functional as F
+    dev = torch.device('cpu')
+    F._COEF_CACHE.clear()
+    first = F._coef_tensor((1.0, 10.0, 0.0), 6, dev).clone()
+    for i in range(4 * F._COEF_CACHE_MAX):
+        F._coef_tensor((1.0, 10.0, i / 1000.0), 6, dev)
+    assert len(F._COEF_CACHE) == F._COEF_CACHE_MAX
+    again = F._coef_tensor((1.0, 10.0, 0.0), 6, dev)                     # evicted long ago: rebuilt
+    assert torch.equal(first, again)
+    inv = np.float32(1.0) / np.float32(6)
+    want = np.array([np.float32(1.0) * inv, np.float32(10.0) * inv, np.float32(0.0)], dtype=np.float32)
+    assert np.array_equal(again.numpy(), want)
+    hot = F._coef_tensor((1.0, 10.0, 0.5), 6, dev)
+    assert F._coef_tensor((1.0, 10.0, 0.5), 6, dev) is hot               # a hit returns the cached tensor itself
+    w = torch.tensor(0.6)                                                # a device-scalar weight is spliced in, same bits
+    mixed = F._coef_tensor((1.0, 10.0, w), 6, dev)
+    assert mixed[2].item() == float(np.float32(0.6) * inv) and torch.equal(mixed[:2], hot[:2])
