@@ -288,3 +288,44 @@ def test_loss_coefficient_cache_is_bounded_and_exact():
     w = torch.tensor(0.6)                                                # a device-scalar weight is spliced in, same bits
     mixed = F._coef_tensor((1.0, 10.0, w), 6, dev)
     assert mixed[2].item() == float(np.float32(0.6) * inv) and torch.equal(mixed[:2], hot[:2])
+
+
+def test_committed_profile_tables_carry_this_trees_code_stamp(tmp_path, monkeypatch):
+    """bench.py quotes rocprofv3 durations and PMC traffic from two committed tables; each carries the hash of the kernel
+    sources it was collected on (profiler.code_stamp) and the line says ``profile_stale`` when that is not this tree's.
+    (1) the verdict logic; (2) the tables committed with this tree ARE this tree's: a kernel-source change without a new
+    collection fails here, not silently in a bench line."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from mvae_amd.profiler import code_stamp
+    mine = code_stamp()
+    assert len(mine['csrc_sha16']) == 16 and int(mine['csrc_sha16'], 16) >= 0
+    assert bench._stamp_verdict(None)['stale'] is True
+    assert bench._stamp_verdict({'csrc_sha16': '0' * 16, 'head': 'x'})['stale'] is True
+    assert bench._stamp_verdict({'csrc_sha16': mine['csrc_sha16'], 'head': 'x'}) == {'head': 'x', 'csrc_sha16': mine['csrc_sha16'], 'stale': False}
+    # a table that does not hold the call reads (None, None): no fall-back to another table
+    assert bench.rocprof_us_for('mnist', 'linear_fwd', 'M7 N7 K7') == (None, None)
+    assert bench.traffic_for('linear_fwd', 'M7 N7 K7') == (None, None)
+    with open(bench.BY_SHAPE_FILE) as f:
+        by_shape = json.load(f)
+    for kind in ('mnist', 'fashionmnist', 'celeba', 'celeba19'):
+        assert by_shape['_meta'][kind]['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r05_by_shape.json [%s] was collected on other kernel sources' % kind
+    with open(bench.TRAFFIC_FILE) as f:
+        traffic = json.load(f)
+    assert len(traffic) >= 8
+    for call, ent in traffic.items():
+        assert ent['collected_on']['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r05_traffic.json [%s] was collected on other kernel sources' % call
+        assert ent['hbm_bytes_per_launch'] >= 0.9 * ent['algorithmic_bytes_per_launch'], call     # a launch cannot move less than it must
+    us, st = bench.rocprof_us_for('mnist', 'linear_fwd', 'M1024 N512 K512')
+    assert 5.0 < us < 50.0 and st['stale'] is False and st['file'] == 'profiles/r05_by_shape.json'
+    # a stamp from other sources is reported stale
+    other = dict(traffic)
+    k0 = sorted(other)[0]
+    other[k0] = dict(other[k0], collected_on={'csrc_sha16': 'f' * 16, 'head': 'elsewhere'})
+    p = tmp_path / 't.json'
+    p.write_text(json.dumps(other))
+    monkeypatch.setattr(bench, 'TRAFFIC_FILE', str(p))
+    name, key = k0.split(' ', 1)
+    assert bench.traffic_for(name, key)[1]['stale'] is True
