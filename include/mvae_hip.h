@@ -443,6 +443,14 @@ int mvae_adam_apply_at(float *param, const float *grad, float *exp_avg, float *e
 int mvae_adam_prepare(int64_t *step_dev, int64_t delta, double lr, double beta1, double beta2, float *coef2,
                       mvae_stream_t stream);
 int mvae_counter_add(int64_t *counter_dev, int64_t delta, mvae_stream_t stream);
+/* mvae_adam_apply_at(..., step_add = 0) with the step's two bias-correction factors READ from coef2 instead of recomputed
+ * from the counter (ABI 6): the fused step's counter launch is mvae_adam_prepare -- early in the step, off the critical
+ * chain -- and the update at the end of the chain (mnist/train.py:219) starts streaming at once: the two double-precision
+ * pow() behind the factors were ~300 fp64 instructions in front of every wavefront of the 72-MB MNIST update.  Same
+ * arithmetic as mvae_adam_apply_at, bit for bit. */
+int mvae_adam_apply_coef(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                         const float *coef2, double beta1, double beta2, double eps, float grad_scale,
+                         mvae_stream_t stream);
 
 /* Measurement aid (no reference counterpart): an EMPTY kernel on `stream`.  A profiling host launches one in front of
  * every call of a single-stream step; in the rocprofv3 kernel trace the k-th marker dispatch then separates the kernels

@@ -136,6 +136,7 @@ _SIGNATURES = {
     'mvae_adam_apply': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P, P]),
     'mvae_adam_apply_at': (c_int, [P, P, P, P, c_size_t, c_double, c_double, c_double, c_double, c_float, P,
                                    ctypes.c_int64, P]),
+    'mvae_adam_apply_coef': (c_int, [P, P, P, P, c_size_t, P, c_double, c_double, c_double, c_float, P]),
     'mvae_counter_add': (c_int, [P, ctypes.c_int64, P]),
     'mvae_trace_marker': (c_int, [c_int, P]),
     'mvae_fill': (c_int, [P, c_size_t, c_float, P]),
@@ -209,7 +210,7 @@ def lib():
             if fn is not None:
                 fn.restype = res
                 fn.argtypes = args
-        if handle.mvae_abi_version() != 5:
+        if handle.mvae_abi_version() != 6:
             raise RuntimeError('libmvae_hip.so ABI version mismatch')
         _lib = handle
     return _lib

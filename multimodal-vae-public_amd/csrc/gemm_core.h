@@ -54,6 +54,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MVAE_KO
 #define MVAE_KO 0               // knock-out experiments on the interleaved loop (results are wrong): 1 no global loads,
 #endif                          // 2 + no LDS stores, 3 + no barrier, 4 + no fragment reads (MFMAs only)
+#ifndef MVAE_PAIR_NEIGH
+#define MVAE_PAIR_NEIGH 1       // pair-storing transposed-conv launches: the two class PAIRS of a j tile on neighbouring blocks of one XCD
+                                // (2 items per block) instead of four consecutive items of one block: the second pair re-reads the
+                                // tile's input microseconds -- not ~45 us -- after the first, and the 128-byte output lines the pairs
+                                // share meet in the L2.  profiles/r05_convT_class_ab.txt (x2 interleaved, outputs identical to the last
+                                // digit): FashionMNIST's dominant launch -2.8 %, its step -0.5 / -0.7 %, CelebA-19 -0.2 %, CelebA -0.1 ... -0.4 %.
+                                // (Non-temporal stores for the output, measured beside it, LOSE: that launch +4 %.)  0: A/B
+#endif
 #ifndef MVAE_MULTI_MINBLOCKS
 #define MVAE_MULTI_MINBLOCKS 1024   // a multi-item launch keeps at least this many column blocks (4 per CU)
 #endif
@@ -607,7 +615,9 @@ struct EpNCHW {
     int lg_hw2 = -1, lg_w2 = -1;   // log2(H2 * W2), log2(W2) when both are powers of two (host), else -1: col() shifts instead of dividing
     __device__ void set_class(int cls) { if (sy > 1) { py = cls / sy; px = cls % sy; } }
     __device__ bool col(int j) {
-        if (j >= J) { voff = BUF_OOB; return BUFFER; }            // buffer form: the lane takes part, its accesses fall out of range
+        // no column: false for the pointer forms (`if (e.col(j)) e.put(...)` must not store through a stale `off`: ADVICE r5);
+        // the buffer forms ignore the result -- the lane takes part and its accesses fall out of range
+        if (j >= J) { voff = BUF_OOB; return false; }
         int n, rem, r, c;
         if (lg_w2 >= 0) {           // block-uniform
             n = j >> lg_hw2; rem = j & ((1 << lg_hw2) - 1);
@@ -800,7 +810,11 @@ void igemm_kernel(P p, Q q, E e, int K, int klen, SplitSink sink) {
         // fabric for 5 MB of operands).  Re-map the launch order so that XCD x owns a (tiles_i / 4) x (tiles_j / 2)
         // sub-grid of the output: P is fetched by 2 XCDs, Q by 4 (host checks divisibility, one class, no split).
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), xcd = lin & 7u, slot = lin >> 3;
-        if (sink.xcd_map == 4) {
+        if (MVAE_PAIR_NEIGH && sink.xcd_map == 5) {
+            // experiment: XCD x owns j tiles x, x + 8, ...; the two class pairs of a tile sit in consecutive slots
+            bx = (int)((((slot >> 1) * 8u + xcd) << 1) | (slot & 1u));
+            if ((long)bx * sink.items >= (long)sink.tiles_j * sink.ncls) return;
+        } else if (sink.xcd_map == 4) {
             // split reductions (the conv weight gradients: 16 .. 128 k ranges x a few output tiles).  In launch order
             // the tiles of ONE k range -- which share its rows of both operands -- spread over all 8 XCDs, and every
             // L2 fetched every k range: 122.7 MB for 30 MB of operands on ConvTranspose2d(256, 128)'s weight gradient
@@ -1862,6 +1876,11 @@ int launch_igemm_impl(Plan pl, PF make_p, QF make_q, E e, int I, int J, int K, S
         }                                                                                        \
         if (pl.xcd == 3 && pl.splits == 1 && grid.y > 1 && grid.x >= 64) {                      \
             sink.xcd_map = 3; grid.x = (grid.x + 7) / 8 * 8;    /* (class, j tile) items XCD-local */ \
+        }                                                                                        \
+        if (MVAE_PAIR_NEIGH && E::PAIR && WM * WN == 1 && sink.items > 1 && sink.ncls == 4 && sink.cls_minor && grid.y == 1 && \
+            pl.splits == 1 && sink.xcd_map == 0) {                                                \
+            sink.items = 2; sink.xcd_map = 5;                                                    \
+            grid.x = ((unsigned)sink.tiles_j * 2u + 15u) / 16u * 16u;                            \
         }                                                                                        \
         constexpr size_t tile_b = 2 * (PLD<TM>::ROWS * PLD<TM>::PITCH + QLD<TN>::ROWS * QLD<TN>::PITCH) * sizeof(float); \
         constexpr size_t red_b = (WGM * WGN < 4 && KW > 1)                                       \

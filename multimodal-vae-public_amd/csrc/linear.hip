@@ -1,6 +1,7 @@
 // linear.hip -- Linear layers (forward, data gradient, weight gradient; single and grouped) on the GEMM
 // kernel of gemm_core.h, and the library-wide entry points.
 #include "gemm_core.h"
+#include "gemm2.h"
 #include "linear_direct.h"
 
 #ifndef MVAE_XCD_MAP
@@ -11,7 +12,7 @@
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-MVAE_EXPORT int mvae_abi_version(void) { return 5; }
+MVAE_EXPORT int mvae_abi_version(void) { return 6; }
 
 #ifdef MVAE_TUNING
 // tuning build only (libmvae_hip_tuning.so): force tile shapes / split counts for tools/gemm_bench.py
@@ -32,6 +33,8 @@ MVAE_EXPORT size_t mvae_gemm_ws_bytes(int rows_out, int cols_out, int reduce_len
     if (MVAE_TUNE(splits) > 0) n = (size_t)MVAE_TUNE(splits) * ((size_t)rows_out * cols_out + rows_out);
     const size_t smallcin = (size_t)512 * rows_out * cols_out;      // per-block partials of wgrad_smallcin_kernel
     if (rows_out <= 64 && cols_out <= 64 && smallcin > n) n = smallcin;
+    const size_t g2n = g2_ws_floats_max(rows_out, cols_out, reduce_len);    // slabs of the version-2 core's cut tiles
+    if (g2n > n) n = g2n;
     return (n > repack ? n : repack) * sizeof(float);
 }
 
@@ -58,6 +61,10 @@ static int linear_fwd_impl(const float *x, int ldx, const float *w, const float 
     e.out_cs = gr.d; e.bias_cs = gr.c;
     auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; p.cls_stride = gr.a; };
     auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; q.cls_stride = gr.b; };
+    if (vec) {
+        G2Plan g2 = g2_plan_for(M, N, K, gr.G, false, ws, ws_bytes, (pre && act) ? G2_FWD_TWO_OUTPUTS : G2_PLAIN);
+        if (g2.ok) return launch_gemm2<G2RowsK, G2RowsK, EpRowMajor, false>(g2, mp, mq, e, st);
+    }
     if (vec)
         return launch_igemm_small<LdRowsK, LdRowsK, LdRowsK64, LdRowsK64, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
     return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
@@ -80,6 +87,41 @@ static int linear_loss_impl(const float *x, int ldx, const float *w, E e, int M,
     return launch_igemm<LdRowsKS, LdRowsKS, E, false>(pl, mp, mq, e, M, N, K, sink, st);
 }
 
+// Data gradient over a SHORT reduction (N <= 16 output features of the forward layer: the 10-class head of
+// mnist/model.py:146, celeba19's one-logit attribute heads, celeba/model.py:170's 18): dx[i][j] = sum_n dy[i][n] * w[n][j] is
+// N multiply-adds per output -- memory-side work.  The MFMA tile kernel ran it as a K = 10 GEMM at 0.8 TFLOP/s (12.8 us on
+// MNIST's critical chain, profiles/r05_mnist_by_shape.txt; 34 us for celeba19's 18 groups with N = 1).  Here a thread owns
+// one column j for ROWS rows: its N weights stay in registers, the dy values of a row are block-uniform (scalar loads),
+// and the epilogue operands of all its rows are fetched before the first is used (EpRowMajor::fetch).
+constexpr int DG_SMALLN_MAX = 16, DG_SMALLN_ROWS = 8;
+__global__ __launch_bounds__(256) void dgrad_smalln_kernel(const float *__restrict__ dy, int lddy, size_t dy_cs,
+                                                           const float *__restrict__ w, size_t w_cs, EpRowMajor e, int M,
+                                                           int N, int K) {
+    const int cls = blockIdx.z;
+    e.set_class(cls);
+    dy += (size_t)cls * dy_cs; w += (size_t)cls * w_cs;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int jc = min(j, K - 1);
+    const int i0 = blockIdx.y * DG_SMALLN_ROWS;
+    float wv[DG_SMALLN_MAX];
+#pragma unroll
+    for (int n = 0; n < DG_SMALLN_MAX; ++n) wv[n] = w[(size_t)min(n, N - 1) * K + jc];
+    EpRowMajor::Pre pre[DG_SMALLN_ROWS];
+#pragma unroll
+    for (int r = 0; r < DG_SMALLN_ROWS; ++r) pre[r] = e.fetch(i0 + r, j);
+#pragma unroll
+    for (int r = 0; r < DG_SMALLN_ROWS; ++r) {
+        const int i = i0 + r;
+        if (i >= M) break;                                   // block-uniform
+        const float *row = dy + (size_t)i * lddy;
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < DG_SMALLN_MAX; ++n)
+            if (n < N) s += row[n] * wv[n];
+        if (j < K) e.put_pre(i, j, s, pre[r]);
+    }
+}
+
 static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *dx, int lddx, const float *pre_in,
                              const float *mask, float mask_scale, int M, int N, int K, int flags, void *ws,
                              size_t ws_bytes, LinGroups gr, hipStream_t st) {
@@ -96,8 +138,17 @@ static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *d
     e.mask = mask; e.ldm = K; e.mask_scale = mask_scale; e.I = M; e.J = K;
     e.accumulate = (flags & MVAE_ACCUMULATE) ? 1 : 0;
     e.out_cs = gr.d; e.dpre_cs = gr.c;
+    if (N <= DG_SMALLN_MAX && !MVAE_TUNE(small_off)) {
+        hipLaunchKernelGGL(dgrad_smalln_kernel, dim3((unsigned)cdiv(K, 256), (unsigned)cdiv(M, DG_SMALLN_ROWS), gr.G), dim3(256), 0,
+                           st, dy, lddy, gr.a, w, gr.b, e, M, N, K);
+        return mvae_launch_status();
+    }
     auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = M; p.Klen = N; p.cls_stride = gr.a; };
     auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = K; q.Klen = N; q.cls_stride = gr.b; };
+    if (vec) {
+        G2Plan g2 = g2_plan_for(M, K, N, gr.G, false, ws, ws_bytes);
+        if (g2.ok) return launch_gemm2<G2RowsK, G2RowsMN, EpRowMajor, false>(g2, mp, mq, e, st);
+    }
     if (vec)
         return launch_igemm_small<LdRowsK, LdRowsMN, LdRowsK64, LdRowsMN64, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
     return launch_igemm<LdRowsKS, LdRowsMNS, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
@@ -122,6 +173,14 @@ static int linear_wgrad_impl(const float *dy, int lddy, const float *x, int ldx,
         return wgrad_direct_launch(dy, lddy, x, ldx, e, N, K, M, db, acc, st);
     auto mp = [&](auto &p) { p.src = dy; p.ld = lddy; p.R = N; p.Klen = M; p.cls_stride = gr.a; };
     auto mq = [&](auto &q) { q.src = x; q.ld = ldx; q.R = K; q.Klen = M; q.cls_stride = gr.b; };
+    if (vec) {
+        G2Plan g2 = g2_plan_for(N, K, M, gr.G, db != nullptr, ws, ws_bytes);
+        if (g2.ok) {
+            g2.a.rowsum = db; g2.a.rowsum_cls_stride = gr.c; g2.a.rowsum_accumulate = acc;
+            return db ? launch_gemm2<G2RowsMN, G2RowsMN, EpRowMajor, true>(g2, mp, mq, e, st)
+                      : launch_gemm2<G2RowsMN, G2RowsMN, EpRowMajor, false>(g2, mp, mq, e, st);
+        }
+    }
     int rc;
     if (db) {
         // row sums of P = dy^T are the bias gradient; partials live right after each dw partial

@@ -499,8 +499,9 @@ inline bool wgrad_batched2_launch(const WgradBatchArgs &a, hipStream_t st, int *
         if (!w.dy) return false;
         t22 += cdiv(w.I, 64) * cdiv(w.J, 64); t21 += cdiv(w.I, 64) * cdiv(w.J, 32); t11 += cdiv(w.I, 32) * cdiv(w.J, 32);
         if (w.M > max_m) max_m = w.M;
-        // byte offsets of (surplus) chunks stay below 2^31 (signed in wb2_rsrc): the prefetch runs up to 8 * 16 * 5 rows past the batch
-        const long over = (long)w.M + 8 * 16 * 5;
+        // byte offsets of (surplus) chunks stay below 2^31 (signed in wb2_rsrc): with KW waves per tile and PD register sets
+        // the prefetch runs up to 8 * KW * (3 * PD + 1) rows past the batch -- KW <= 16, PD <= 2 (8 * 16 * 5 was short)
+        const long over = (long)w.M + 8 * 16 * 8;
         if (over * w.lddy * 4 >= (1L << 31) || over * w.ldx * 4 >= (1L << 31)) return false;
     }
     // Wave tile: every tile of a launch costs the same (M rows x tile area), blocks spread evenly over the 256 CUs, and the

@@ -128,29 +128,61 @@ __global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) ----
 // step t = *step_dev + 1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
-                                                   double lr, double b1d, double b2d, double epsd, float gscale,
-                                                   const int64_t *step_dev, int64_t step_add) {
-    AdamCoef c = adam_coef(b1d, b2d, epsd, gscale);
-    adam_bias_corrections(lr, b1d, b2d, (double)(*step_dev + step_add), &c.step_size, &c.inv_sqrt_bc2);
+// Two float4 groups per thread and array: eight 16-byte loads in flight before the first is used (the arenas are a few
+// tens of MB -- Infinity-Cache resident between steps -- and the launch is the LAST of the step, so its latency is the
+// step's: profiles/r05_mnist_by_shape.txt read 23.5 us = 3.1 TB/s for MNIST's 72 MB with one group per thread).
+__device__ __forceinline__ void adam_body(float *p, const float *g, float *m, float *v, size_t n, const AdamCoef &c) {
     const size_t n4 = n / 4;
     const bool vec = aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v);
     if (vec) {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-            float4 pv = reinterpret_cast<float4 *>(p)[i];
-            const float4 gv = reinterpret_cast<const float4 *>(g)[i];
-            float4 mv = reinterpret_cast<float4 *>(m)[i];
-            float4 vv = reinterpret_cast<float4 *>(v)[i];
-            adam_one(pv.x, mv.x, vv.x, gv.x, c); adam_one(pv.y, mv.y, vv.y, gv.y, c);
-            adam_one(pv.z, mv.z, vv.z, gv.z, c); adam_one(pv.w, mv.w, vv.w, gv.w, c);
-            reinterpret_cast<float4 *>(p)[i] = pv;
-            reinterpret_cast<float4 *>(m)[i] = mv;
-            reinterpret_cast<float4 *>(v)[i] = vv;
+        const size_t stride = (size_t)gridDim.x * 512;
+        for (size_t i0 = (size_t)blockIdx.x * 512 + threadIdx.x; i0 < n4; i0 += stride) {
+            const size_t i1 = i0 + 256;
+            const bool two = i1 < n4;
+            const size_t j1 = two ? i1 : i0;          // a legal address either way: the loads stay unconditional
+            float4 pa = reinterpret_cast<float4 *>(p)[i0], pb = reinterpret_cast<float4 *>(p)[j1];
+            const float4 ga = reinterpret_cast<const float4 *>(g)[i0], gb = reinterpret_cast<const float4 *>(g)[j1];
+            float4 ma = reinterpret_cast<float4 *>(m)[i0], mb = reinterpret_cast<float4 *>(m)[j1];
+            float4 va = reinterpret_cast<float4 *>(v)[i0], vb = reinterpret_cast<float4 *>(v)[j1];
+            adam_one(pa.x, ma.x, va.x, ga.x, c); adam_one(pa.y, ma.y, va.y, ga.y, c);
+            adam_one(pa.z, ma.z, va.z, ga.z, c); adam_one(pa.w, ma.w, va.w, ga.w, c);
+            reinterpret_cast<float4 *>(p)[i0] = pa;
+            reinterpret_cast<float4 *>(m)[i0] = ma;
+            reinterpret_cast<float4 *>(v)[i0] = va;
+            if (two) {
+                adam_one(pb.x, mb.x, vb.x, gb.x, c); adam_one(pb.y, mb.y, vb.y, gb.y, c);
+                adam_one(pb.z, mb.z, vb.z, gb.z, c); adam_one(pb.w, mb.w, vb.w, gb.w, c);
+                reinterpret_cast<float4 *>(p)[i1] = pb;
+                reinterpret_cast<float4 *>(m)[i1] = mb;
+                reinterpret_cast<float4 *>(v)[i1] = vb;
+            }
         }
     }
     const size_t tail0 = vec ? n4 * 4 : 0;
     for (size_t i = tail0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         adam_one(p[i], m[i], v[i], g[i], c);
+}
+
+// The bias corrections need two double-precision pow() (torch computes them in python floats): ~300 fp64 instructions that
+// every WAVE of the launch used to run before touching memory.  Now thread 0 of a block computes them (the other waves
+// skip the branch) and the block reads them from LDS; mvae_adam_apply_coef below takes them ready-made.
+__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
+                                                   double lr, double b1d, double b2d, double epsd, float gscale,
+                                                   const int64_t *step_dev, int64_t step_add) {
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) adam_bias_corrections(lr, b1d, b2d, (double)(*step_dev + step_add), &bc[0], &bc[1]);
+    __syncthreads();
+    AdamCoef c = adam_coef(b1d, b2d, epsd, gscale);
+    c.step_size = bc[0]; c.inv_sqrt_bc2 = bc[1];
+    adam_body(p, g, m, v, n, c);
+}
+
+// ... with the step's two factors already in memory (mvae_adam_prepare, launched early in the step off the critical chain)
+__global__ __launch_bounds__(256) void adam_coef_kernel(float *p, const float *g, float *m, float *v, size_t n,
+                                                        const float *coef2, double b1d, double b2d, double epsd, float gscale) {
+    AdamCoef c = adam_coef(b1d, b2d, epsd, gscale);
+    c.step_size = coef2[0]; c.inv_sqrt_bc2 = coef2[1];
+    adam_body(p, g, m, v, n, c);
 }
 
 // The step counter advanced by `delta` and the two bias-correction factors of step t = the NEW counter value left in
@@ -282,7 +314,7 @@ MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, 
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev, (int64_t)1);
     hipLaunchKernelGGL(bump_i64_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return mvae_launch_status();
@@ -296,7 +328,7 @@ MVAE_EXPORT int mvae_adam_apply(float *param, const float *grad, float *exp_avg,
                                 const int64_t *step_dev, mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, (int64_t)1);
     return mvae_launch_status();
 }
@@ -308,8 +340,19 @@ MVAE_EXPORT int mvae_adam_apply_at(float *param, const float *grad, float *exp_a
                                    const int64_t *step_dev, int64_t step_add, mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, step_add);
+    return mvae_launch_status();
+}
+
+// The same with the two bias-correction factors of the step read from `coef2` (left there by mvae_adam_prepare).
+MVAE_EXPORT int mvae_adam_apply_coef(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                                     const float *coef2, double beta1, double beta2, double eps, float grad_scale,
+                                     mvae_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !coef2) return MVAE_ERR_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(adam_coef_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, coef2, beta1, beta2, eps, grad_scale);
     return mvae_launch_status();
 }
 

@@ -385,6 +385,7 @@ class _StepBase(object):
         early = (os.environ.get('MVAE_EARLY_COUNTER', '1') != '0' and self.side is not None
                  and hasattr(optimizer, 'step_counted'))
         self._adam_counter = optimizer.step_counter() if early else None
+        self._optimizer_early = optimizer if early else None
         fuse = (early and self.fuse_adam and self.batch_wgrad and self.wg_main is None
                 and hasattr(optimizer, 'fusion') and optimizer.grad_scale == 1.0)
         self._fusion = optimizer.fusion() if fuse else None
@@ -478,6 +479,8 @@ class _StepBase(object):
         if getattr(self, '_adam_counter', None) is not None:
             if self._fusion is not None:
                 self._adam_prepare()        # counter + the bias corrections the fused weight-gradient launches read
+            elif hasattr(self._optimizer_early, 'prepare_plain'):
+                self._optimizer_early.prepare_plain()   # counter + the step's bias corrections for the update at the end
             else:
                 K.counter_add(self._adam_counter, 1)
 

@@ -31,12 +31,27 @@ stream; noise comes from the device-side Philox counter (``base.MVAE.device_rand
 ``num_batches_tracked`` is advanced on the host per replay by what one step adds.  The optimizer must be capturable:
 ``optim.FusedAdam`` (device step counter) or ``torch.optim.Adam(..., capturable=True)``.
 Shapes are frozen at capture: a last, shorter batch of an epoch runs the body eagerly (``step.eager(...)``).
+
+What else is frozen: the graph holds ADDRESSES and by-value kernel arguments.  The optimizer's hyper-parameters
+(lr, betas, eps, ...) went into the captured launches as numbers -- a scheduler or a hand edit of ``param_groups`` afterwards
+would be silently ignored by replays -- and the model's device noise counter (``_rng``) is the tensor object that existed at
+capture: ``model.seed_noise()`` replaces it, and replays would keep drawing from the old one while ``step.eager()`` used the
+new.  Both are checked per call: a changed hyper-parameter or a replaced counter raises (capture again, or reseed in place
+with ``step.reseed(seed)``).
 """
 import torch
 
 from . import layers as L
 
 __all__ = ['capture_step', 'CapturedStep']
+
+
+def _hyper_snapshot(optimizer):
+    """The by-value hyper-parameters of every param group (everything that is not the parameter list or a tensor)."""
+    snap = []
+    for g in optimizer.param_groups:
+        snap.append(tuple(sorted((k, repr(v)) for k, v in g.items() if k != 'params' and not torch.is_tensor(v))))
+    return tuple(snap)
 
 
 def _optimizer_tensors(optimizer):
@@ -98,6 +113,8 @@ class CapturedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = fn(*self.static)
+        self._hyper = _hyper_snapshot(optimizer)
+        self._rng_obj = model.__dict__.get('_rng')
         # ---- back to the state before the first warm-up pass (in place: the graph holds these addresses)
         with torch.no_grad():
             for p, s in zip(model.parameters(), params):
@@ -134,10 +151,25 @@ class CapturedStep(object):
                 s.copy_(a, non_blocking=True)
             else:
                 s.fill_(float(a))
+        if _hyper_snapshot(self.optimizer) != self._hyper:
+            raise RuntimeError('the optimizer\'s hyper-parameters changed after capture_step: the graph holds the old values '
+                               '(capture the step again)')
+        if self.model.__dict__.get('_rng') is not self._rng_obj:
+            raise RuntimeError('the model\'s noise counter was replaced after capture_step (seed_noise): the graph draws from '
+                               'the old one -- capture again, or reseed in place with step.reseed(seed)')
         for m, inc in self._bn_inc:
             m._nbt_pending += inc
         self.graph.replay()
         return self.out
+
+    def reseed(self, seed):
+        """Restart the captured step's noise stream IN PLACE (same counter tensor, so the graph sees it): the Philox key of
+        the captured launches is fixed at capture; the counter is set from ``seed`` so that different seeds draw disjoint
+        streams."""
+        rng = self._rng_obj
+        if rng is None:
+            raise RuntimeError('this model draws no device noise')
+        rng[1].fill_((int(seed) & 0x7fffffff) << 32)
 
     def eager(self, *args):
         """The same body without the graph (any batch size)."""

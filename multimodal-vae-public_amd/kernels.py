@@ -806,6 +806,13 @@ def adam_apply_at(param, grad, exp_avg, exp_avg_sq, step_dev, step_add, lr, beta
           'mvae_adam_apply_at')
 
 
+def adam_apply_coef(param, grad, exp_avg, exp_avg_sq, coef2, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """``adam_apply_at(..., step_add=0)`` with the step's bias-correction factors read from ``coef2`` (``adam_prepare``)."""
+    _need_gpu(param, grad, exp_avg, exp_avg_sq, coef2); _f32c(param, grad, exp_avg, exp_avg_sq, coef2)
+    check(_lib.lib().mvae_adam_apply_coef(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                          _ptr(coef2), beta1, beta2, eps, grad_scale, _stream()), 'mvae_adam_apply_coef')
+
+
 def adam_prepare(step_dev, delta, lr, beta1, beta2, coef2):
     """*step_dev += delta; coef2[0:2] = Adam's two bias-correction factors at the new step (mvae_adam_prepare)."""
     _need_gpu(step_dev, coef2); _f32c(coef2)

@@ -133,7 +133,9 @@ def run_attempt(cmd, env, budget_s, poll_s=0.2, peer_failed=None):
             if _exited(proc.pid):
                 _kill_group(proc)      # stragglers of a finished child (none expected); reaps the leader afterwards
                 rc = proc.returncode
-                status = 'ok' if rc == 0 else 'rc=%d' % rc
+                if rc is None:             # _kill_group's bounded wait ran out before the leader was reaped
+                    rc = proc.poll()
+                status = 'ok' if rc == 0 else ('rc=unknown' if rc is None else 'rc=%d' % rc)
             elif time.monotonic() >= deadline:
                 _kill_group(proc)
                 status = 'timeout'

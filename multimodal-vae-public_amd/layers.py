@@ -583,6 +583,12 @@ def _lin_wgrad_targets(op):
     return dw, db, acc
 
 
+def _lin_wgrad_key(op):
+    """Identity of the weight a Linear / paired-heads op writes a gradient for -- WITHOUT touching it (``grad_target`` sets
+    ``p.grad`` and decides the accumulate flag: a side effect that must happen in list order, see WgradBatch.flush)."""
+    return id(op.mod.weight) if op.kind == 'lin' else id(op.mod.heads[0].weight)
+
+
 def _lin_wgrad(op, g, x):
     dw, db, acc = _lin_wgrad_targets(op)
     K.linear_wgrad(g, x, dw, db, accumulate=acc)
@@ -613,17 +619,21 @@ class WgradBatch(list):
     def flush(self):
         items, seen = [], set()
         adam = self.adam
-        targets = [(_lin_wgrad_targets(e[1]) if isinstance(e, tuple) else None) for e in self]
+        # side-effect-free pre-pass: which weights receive exactly ONE contribution in this list.  The
+        # gradient targets themselves -- grad_target() sets p.grad and the accumulate flag -- are taken inside the ordered
+        # loop below, interleaved with the queued closures as they always were.
+        keys = [(_lin_wgrad_key(e[1]) if isinstance(e, tuple) else None) for e in self]
+        key_of = {}                 # gradient address -> weight identity, filled as targets are taken
         if adam is not None:
             # A fused launch applies Adam to the gradient it has just written, so that gradient must be FINAL: exactly
             # one contribution in this list, not accumulated onto an earlier one, and nothing behind it (a
             # layer used twice per step got its update on a partial gradient and rest() then skipped it).  Gradients
             # that do not qualify leave this flush un-fused and stay with the arena-wide launch (rest()).
             count = {}
-            for tg in targets:
-                if tg is not None:
-                    count[tg[0].data_ptr()] = count.get(tg[0].data_ptr(), 0) + 1
-            fusable = {ptr for ptr, n in count.items() if n == 1}
+            for k in keys:
+                if k is not None:
+                    count[k] = count.get(k, 0) + 1
+            fusable = {k for k, n in count.items() if n == 1}
         else:
             fusable = set()
 
@@ -635,7 +645,7 @@ class WgradBatch(list):
 
         def issue():
             fused = (adam is not None and items
-                     and all((it[0] is None) or (not it[4] and it[2].data_ptr() in fusable) for it in items))
+                     and all((it[0] is None) or (not it[4] and key_of.get(it[2].data_ptr()) in fusable) for it in items))
             for it in items:
                 if it[0] is not None:
                     guard(it[2], it[3])
@@ -654,12 +664,13 @@ class WgradBatch(list):
             del items[:]
             seen.clear()
 
-        for e, tg in zip(self, targets):
+        for e, key in zip(self, keys):
             if not isinstance(e, tuple):
                 e()
                 continue
             _, op, g, x = e
-            dw, db, acc = tg
+            dw, db, acc = _lin_wgrad_targets(op)
+            key_of[dw.data_ptr()] = key
             if dw.data_ptr() in seen:
                 issue()                     # a second contribution to the same gradient: keep the order (grad_target made it accumulate)
             if K.wgrad_batchable(g, x):
@@ -669,7 +680,7 @@ class WgradBatch(list):
                 guard(dw, db)
                 K.linear_wgrad(g, x, dw, db, accumulate=acc)
         if adam is not None and self._final:
-            if any(it[4] or it[2].data_ptr() not in fusable for it in items):
+            if any(it[4] or key_of.get(it[2].data_ptr()) not in fusable for it in items):
                 issue()
             for grad in self._final:
                 items.append((None, None, grad.reshape(-1), None, False))

@@ -101,6 +101,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=arena.flat.device)
         self._host_step = 0
         self._fusion = None
+        self._coef = torch.zeros(2, dtype=torch.float32, device=arena.flat.device)
+        self._coef_ready = False
 
     def zero_grad(self, set_to_none=True):
         # None marks "first write of the step overwrites": no memset over the gradient arena
@@ -149,6 +151,23 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         K.adam_prepare(self._step_dev, 1, g['lr'], g['betas'][0], g['betas'][1], fusion.coef)
 
+    def prepare_plain(self):
+        """The counter launch of a fused step WITHOUT fused weight-gradient updates: advance the counter by one and leave
+        the step's two bias-correction factors for ``step_counted()``, whose launch then starts streaming at once
+        (mvae_adam_apply_coef) instead of computing two double-precision powers per wavefront first."""
+        g = self.param_groups[0]
+        K.adam_prepare(self.step_counter(), 1, g['lr'], g['betas'][0], g['betas'][1], self._coef)
+        self._coef_ready = True
+
+    def _apply_counted(self, lo, hi):
+        arena, g = self._arena, self.param_groups[0]
+        if self._coef_ready:
+            K.adam_apply_coef(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._coef,
+                              g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+        else:
+            K.adam_apply_at(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, 0,
+                            g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+
     @torch.no_grad()
     def step_counted(self, fusion=None):
         """``step()`` for a caller that already advanced ``step_counter()`` by one this step: one launch -- or, with
@@ -157,10 +176,9 @@ class FusedAdam(torch.optim.Optimizer):
         for p in arena.params:
             if p.grad is None:
                 raise RuntimeError('a parameter received no gradient this step')
-        g = self.param_groups[0]
         for lo, hi in ([(0, arena.numel)] if fusion is None else fusion.rest()):
-            K.adam_apply_at(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, 0,
-                            g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+            self._apply_counted(lo, hi)
+        self._coef_ready = False
         self._host_step += 1
 
     @torch.no_grad()
@@ -169,13 +187,12 @@ class FusedAdam(torch.optim.Optimizer):
         step updates its decoders' range as soon as their weight gradients are final -- beside the encoders' backward --
         and only the encoders' range at the end of the chain; ``last`` closes the step on the host side."""
         arena = self._arena
-        g = self.param_groups[0]
-        K.adam_apply_at(arena.flat[lo:hi], arena.grad[lo:hi], self._m[lo:hi], self._v[lo:hi], self._step_dev, 0,
-                        g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.grad_scale)
+        self._apply_counted(lo, hi)
         if last:
             for p in arena.params:
                 if p.grad is None:
                     raise RuntimeError('a parameter received no gradient this step')
+            self._coef_ready = False
             self._host_step += 1
 
     @torch.no_grad()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     for name in declared:
         assert hasattr(handle, name), 'header declares %s but the library does not export it' % name
-    assert handle.mvae_abi_version() == 5
+    assert handle.mvae_abi_version() == 6
 
 
 def test_shared_memory_nccl_stand_in_exports_what_the_communicator_binds():
