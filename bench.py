@@ -17,7 +17,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries
                    left them.  ``hot_cache_reissue`` = the same call re-issued back to back in a hipGraph
                    (round 1's figure), ``conv_kernels`` / ``all_gemm_kernels`` = the in-situ aggregates,
                    ``top_hbm_kernel`` = the HBM-bound kernel with the most time, ``traffic`` = HBM-side bytes
-                   per launch from the committed PMC table (profiles/r05_traffic.json) -- like ``rocprof_avg_us`` a
+                   per launch from the committed PMC table (profiles/r06_traffic.json) -- like ``rocprof_avg_us`` a
                    QUOTED figure: ``committed_profiles`` says on which code it was collected, ``profile_stale`` is
                    true when that is not this tree's kernel sources; ``other_workloads`` = the `also` list, compact,
   cpu_baseline  -- the oracle (CPU restatement of the reference step, kind "port") timed on the
@@ -286,8 +286,8 @@ def roofline_from_profile(eng, opt, batches, n_steps=3, kind=None):
 # of the kernel sources + the git head of that session) and `stale` when the hash is not this tree's (the
 # fields were silent look-ups, and fell back to tables of earlier rounds).  No fallback: a call this round's table does
 # not hold reads null.
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
-BY_SHAPE_FILE = os.path.join(ROOT, 'profiles', 'r05_by_shape.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r06_traffic.json')
+BY_SHAPE_FILE = os.path.join(ROOT, 'profiles', 'r06_by_shape.json')
 
 
 def _stamp_verdict(stamp):
@@ -300,7 +300,7 @@ def _stamp_verdict(stamp):
 
 def rocprof_us_for(kind, name, key):
     """(average rocprofv3 duration (us) of the call's kernels in the committed per-(call, shape) table of this workload's
-    step, the table's code stamp) -- profiles/r05_by_shape.json, made by tools/step_by_shape.py on the GPU box; (None, None)
+    step, the table's code stamp) -- profiles/r06_by_shape.json, made by tools/step_by_shape.py on the GPU box; (None, None)
     if not traced."""
     try:
         with open(BY_SHAPE_FILE) as f:
@@ -310,7 +310,7 @@ def rocprof_us_for(kind, name, key):
     ent = table.get(kind, {}).get('%s %s' % (name, key))
     if ent is None:
         return None, None
-    return ent['rocprof_avg_us'], dict(_stamp_verdict(table.get('_meta', {}).get(kind)), file='profiles/r05_by_shape.json')
+    return ent['rocprof_avg_us'], dict(_stamp_verdict(table.get('_meta', {}).get(kind)), file='profiles/r06_by_shape.json')
 
 
 def module_surface(kind, batch, device, steps=20, warmup=5):
@@ -406,7 +406,7 @@ def traffic_for(name, key):
         ent = None
     if ent is None:
         return None, None
-    return ent['hbm_bytes_per_launch'], dict(_stamp_verdict(ent.get('collected_on')), file='profiles/r05_traffic.json')
+    return ent['hbm_bytes_per_launch'], dict(_stamp_verdict(ent.get('collected_on')), file='profiles/r06_traffic.json')
 
 
 def elbo_delta(kind, batch=32):

@@ -41,6 +41,9 @@ struct RcclApi {
     ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;     // optional (mvae_comm_async_error)
+    // optional (MVAE_COMM_ALGO=rs_ag): the all-reduce as a direct reduce-scatter + all-gather
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     char path[512] = {0};
 };
 
@@ -61,6 +64,8 @@ bool bind_all(RcclApi &a, void *h) {
     MVAE_BIND(GetErrorString, "ncclGetErrorString")
 #undef MVAE_BIND
     *(void **)(&a.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");      // absent: async errors are not observable
+    *(void **)(&a.ReduceScatter) = dlsym(h, "ncclReduceScatter");               // absent: MVAE_COMM_ALGO=rs_ag falls back to ncclAllReduce
+    *(void **)(&a.AllGather) = dlsym(h, "ncclAllGather");
     return true;
 }
 
@@ -98,6 +103,7 @@ struct mvae_comm {
     hipStream_t stream;                        // the communication stream
     hipEvent_t ready[COMM_SLOTS], done[COMM_SLOTS];
     long issued;                               // tickets handed out so far
+    int rs_ag;                                 // MVAE_COMM_ALGO=rs_ag at mvae_comm_init (see mvae_comm_allreduce_async)
     char last_error[256];
 };
 
@@ -157,6 +163,10 @@ MVAE_EXPORT int mvae_comm_init(mvae_comm_t **comm_out, const void *id, size_t id
     mvae_comm *c = (mvae_comm *)calloc(1, sizeof(mvae_comm));
     if (!c) return MVAE_ERR_COMM;
     c->rank = rank; c->world = world; c->device = device; c->issued = 0;
+    {
+        const char *algo = getenv("MVAE_COMM_ALGO");
+        c->rs_ag = (algo && strcmp(algo, "rs_ag") == 0 && api->ReduceScatter && api->AllGather) ? 1 : 0;
+    }
     int prev_device = -1;
     (void)hipGetDevice(&prev_device);
     int n_events = 0;               // events created so far (ready / done alternate): what a failure has to give back
@@ -208,8 +218,25 @@ MVAE_EXPORT int mvae_comm_allreduce_async(mvae_comm_t *c, float *buf, size_t cou
         rc = hip_check(c, hipStreamWaitEvent(c->stream, c->ready[slot], 0), "hipStreamWaitEvent(comm)");
         forked = rc == MVAE_OK;
     }
-    if (rc == MVAE_OK)
+    // Algorithm.  Default: ONE ncclAllReduce per bucket -- RCCL picks ring / tree and the channel count from the message size.
+    // MVAE_COMM_ALGO=rs_ag (opt-in, read at mvae_comm_init): the same sum as an in-place ncclReduceScatter + ncclAllGather over
+    // the bucket's whole multiples of the world size (the < world-size remainder goes through ncclAllReduce).  On a full xGMI
+    // mesh a direct reduce-scatter / all-gather moves S / world bytes over EVERY link at once, where one ring pushes
+    // 2 (N - 1) / N x S through a single link per rank ("prefer direct over ring"; DESIGN section 6's
+    // table prices both).  It is a switch, not a default: no multi-GPU node was available to measure it on.
+    const size_t per = c->rs_ag ? count / (size_t)c->world : 0;
+    if (rc == MVAE_OK && per > 0) {
+        float *mine = buf + (size_t)c->rank * per;
+        rc = nccl_check(c, api, api->ReduceScatter(buf, mine, per, ncclFloat32, ncclSum, c->nccl, c->stream), "ncclReduceScatter");
+        if (rc == MVAE_OK)
+            rc = nccl_check(c, api, api->AllGather(mine, buf, per, ncclFloat32, c->nccl, c->stream), "ncclAllGather");
+        const size_t done_n = per * (size_t)c->world;
+        if (rc == MVAE_OK && done_n < count)
+            rc = nccl_check(c, api, api->AllReduce(buf + done_n, buf + done_n, count - done_n, ncclFloat32, ncclSum, c->nccl, c->stream),
+                            "ncclAllReduce(tail)");
+    } else if (rc == MVAE_OK) {
         rc = nccl_check(c, api, api->AllReduce(buf, buf, count, ncclFloat32, ncclSum, c->nccl, c->stream), "ncclAllReduce");
+    }
     if (rc == MVAE_OK) rc = hip_check(c, hipEventRecord(c->done[slot], c->stream), "hipEventRecord(done)");
     if (rc != MVAE_OK) {
         // a partial enqueue must not leave the communication stream forked into a capture with no way back: join it

@@ -1,6 +1,7 @@
 // conv.hip -- Conv2d / ConvTranspose2d 4x4 (forward, data gradient, weight gradient) on the implicit-GEMM
 // kernel of gemm_core.h: the gather loaders, the three special-shape kernels and the C ABI.
 #include "gemm_core.h"
+#include "gemm2.h"
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
@@ -207,6 +208,45 @@ struct LdIm2colT {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
             if (MVAE_IN_PART(v, NV, part, nparts)) L[kb + v * KSTEP][m] = rg.v[v];
+    }
+};
+
+// The same gather for the version-2 core (gemm2.h): LDS-DMA, one dword per lane.  A k-tile is 16 deep = the 16 taps of ONE
+// input channel; a DMA instruction fills the 64 consecutive columns (output positions) of one tap's row of the k-major image
+// [16][TILE].  A lane keeps ONE byte offset per tap it issues (its column's window corner + the tap, out of range when the
+// tap falls outside the image or the column does not exist); the channel rides the instruction's SCALAR offset.  Wave w
+// issues taps 4w .. 4w + 3 (TILE 64) or half (w & 1), taps 8 (w >> 1) .. + 7 (TILE 128).
+template <int TILE_>
+struct G2Im2col {
+    static constexpr int TILE = TILE_;
+    static constexpr bool RK = false;
+    static constexpr int NPW = TILE / 16;                   // 16 taps x TILE / 64 pieces over 4 waves
+    const float *x; ConvGeom g; int Mtot;
+    BufBase blk; int voff[NPW];
+    __device__ void init(int tile0, int, int lane, int wave) {
+        const int half = TILE == 128 ? (wave & 1) : 0, tap0 = TILE == 128 ? (wave >> 1) * 8 : wave * 4;
+        const int m = tile0 + half * 64 + lane;
+        const int ohw = g.OH * g.OW;
+        const int n0 = g2_uni(g.lg_ohw >= 0 ? tile0 >> g.lg_ohw : tile0 / ohw);
+        blk = buf_base(x + (size_t)n0 * g.Cin * g.H * g.W);
+        int b, rem, oh, ow;
+        divmod_fast(min(m, Mtot - 1), ohw, g.lg_ohw, b, rem);
+        divmod_fast(rem, g.OW, g.lg_ow, oh, ow);
+        const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+        const int rel = ((b - n0) * g.Cin * g.H + ih0) * g.W + iw0;
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int kh = (tap0 + u) >> 2, kw = (tap0 + u) & 3;
+            const bool ok = m < Mtot && ih0 + kh >= 0 && ih0 + kh < g.H && iw0 + kw >= 0 && iw0 + kw < g.W;
+            voff[u] = ok ? (rel + kh * g.W + kw) * 4 : BUF_OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned dst, int k0, int, int wave) const {
+        const i32x4_t rs = g2_rsrc(blk, 0, 0x7fffffff);
+        const int soff = g2_uni((k0 >> 4) * g.H * g.W * 4);
+        const int half = TILE == 128 ? (wave & 1) : 0, tap0 = TILE == 128 ? (wave >> 1) * 8 : wave * 4;
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) g2_dma4(rs, voff[u], soff, g2_uni(dst + ((tap0 + u) * TILE + half * 64) * 4));
     }
 };
 
@@ -942,6 +982,18 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     e.lg_hw2 = g.lg_ohw; e.lg_w2 = g.lg_ow;
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
+    if (aligned16(w) && (size_t)g.Cin * g.H * g.W * 4 * (256 / (g.OH * g.OW) + 2) < ((size_t)1 << 31)) {
+        void *g2ws = nullptr; size_t g2ws_bytes = 0;
+#ifdef MVAE_TUNING
+        {   // experiments only: the forward entry points carry no scratch argument (the persistent modes' slabs need one)
+            static void *tune_ws = nullptr;
+            if (!tune_ws && getenv("MVAE_G2_FORCE")) (void)hipMalloc(&tune_ws, (size_t)256 << 20);
+            g2ws = tune_ws; g2ws_bytes = tune_ws ? (size_t)256 << 20 : 0;
+        }
+#endif
+        G2Plan g2 = g2_plan_for(I, J, K, 1, false, g2ws, g2ws_bytes, G2_CONV_FWD);
+        if (g2.ok) return launch_gemm2<G2RowsK, G2Im2col, EpNCHW, false>(g2, mp, mq, e, st);
+    }
     if (aligned16(w))
         return launch_igemm<LdRowsKC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);
     return launch_igemm<LdRowsKSC, LdIm2col, EpNCHW, false>(pl, mp, mq, e, I, J, K, make_sink(nullptr, I, J, false), st);

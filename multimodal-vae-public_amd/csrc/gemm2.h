@@ -479,7 +479,7 @@ inline G2Plan g2_plan(int I, int J, int K, int ncls, bool rowsum, int force_wm =
 //     the long-reduction weight gradients and loses as much on the short ones: the slabs of the cut tiles and the blocks
 //     running in lock-step through their epilogues cost what the balance gains) and stays where it was; the persistent
 //     modes remain reachable through MVAE_G2_FORCE in the tuning build.
-enum G2Hint { G2_PLAIN = 0, G2_FWD_TWO_OUTPUTS = 1 };
+enum G2Hint { G2_PLAIN = 0, G2_FWD_TWO_OUTPUTS = 1, G2_CONV_FWD = 2 };
 inline G2Plan g2_plan_for(int I, int J, int K, int ncls, bool rowsum, void *ws, size_t ws_bytes, G2Hint hint = G2_PLAIN) {
     G2Plan none; none.ok = false;
     if (!MVAE_G2) return none;

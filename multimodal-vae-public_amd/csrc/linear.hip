@@ -97,28 +97,34 @@ constexpr int DG_SMALLN_MAX = 16, DG_SMALLN_ROWS = 8;
 __global__ __launch_bounds__(256) void dgrad_smalln_kernel(const float *__restrict__ dy, int lddy, size_t dy_cs,
                                                            const float *__restrict__ w, size_t w_cs, EpRowMajor e, int M,
                                                            int N, int K) {
+    __shared__ float sdy[DG_SMALLN_ROWS][DG_SMALLN_MAX];
     const int cls = blockIdx.z;
     e.set_class(cls);
     dy += (size_t)cls * dy_cs; w += (size_t)cls * w_cs;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int t = threadIdx.x;
+    const int j = blockIdx.x * 256 + t;
     const int jc = min(j, K - 1);
     const int i0 = blockIdx.y * DG_SMALLN_ROWS;
+    // everything the block needs is requested at once: its dy rows (one value per thread, through LDS), the thread's N
+    // weights, the epilogue operands of its ROWS outputs -- ONE memory round trip, then arithmetic and stores
+    const int dr = t / DG_SMALLN_MAX, dn = t % DG_SMALLN_MAX;
+    float dval = 0.f;
+    if (t < DG_SMALLN_ROWS * DG_SMALLN_MAX) dval = dy[(size_t)min(i0 + dr, M - 1) * lddy + min(dn, N - 1)];
     float wv[DG_SMALLN_MAX];
 #pragma unroll
     for (int n = 0; n < DG_SMALLN_MAX; ++n) wv[n] = w[(size_t)min(n, N - 1) * K + jc];
     EpRowMajor::Pre pre[DG_SMALLN_ROWS];
 #pragma unroll
     for (int r = 0; r < DG_SMALLN_ROWS; ++r) pre[r] = e.fetch(i0 + r, j);
+    if (t < DG_SMALLN_ROWS * DG_SMALLN_MAX) sdy[dr][dn] = dn < N ? dval : 0.f;      // columns beyond N multiply by zero
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < DG_SMALLN_ROWS; ++r) {
         const int i = i0 + r;
-        if (i >= M) break;                                   // block-uniform
-        const float *row = dy + (size_t)i * lddy;
         float s = 0.f;
 #pragma unroll
-        for (int n = 0; n < DG_SMALLN_MAX; ++n)
-            if (n < N) s += row[n] * wv[n];
-        if (j < K) e.put_pre(i, j, s, pre[r]);
+        for (int n = 0; n < DG_SMALLN_MAX; ++n) s += sdy[r][n] * wv[n];
+        if (i < M && j < K) e.put_pre(i, j, s, pre[r]);
     }
 }
 

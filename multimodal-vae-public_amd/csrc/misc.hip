@@ -128,33 +128,33 @@ __global__ void bump_u64_kernel(uint64_t *counter) { *counter += 1; }
 // ---- Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) ----
 // step t = *step_dev + 1; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-// Two float4 groups per thread and array: eight 16-byte loads in flight before the first is used (the arenas are a few
+// ADAM_GROUPS float4 groups per thread and array: all their 16-byte loads in flight before the first is used (the arenas are a few
 // tens of MB -- Infinity-Cache resident between steps -- and the launch is the LAST of the step, so its latency is the
 // step's: profiles/r05_mnist_by_shape.txt read 23.5 us = 3.1 TB/s for MNIST's 72 MB with one group per thread).
+constexpr int ADAM_GROUPS = 2;      // float4 groups per thread and array: 8 x 16-byte loads in flight per thread (4 groups measured equal)
 __device__ __forceinline__ void adam_body(float *p, const float *g, float *m, float *v, size_t n, const AdamCoef &c) {
     const size_t n4 = n / 4;
     const bool vec = aligned16_dev(p) && aligned16_dev(g) && aligned16_dev(m) && aligned16_dev(v);
     if (vec) {
-        const size_t stride = (size_t)gridDim.x * 512;
-        for (size_t i0 = (size_t)blockIdx.x * 512 + threadIdx.x; i0 < n4; i0 += stride) {
-            const size_t i1 = i0 + 256;
-            const bool two = i1 < n4;
-            const size_t j1 = two ? i1 : i0;          // a legal address either way: the loads stay unconditional
-            float4 pa = reinterpret_cast<float4 *>(p)[i0], pb = reinterpret_cast<float4 *>(p)[j1];
-            const float4 ga = reinterpret_cast<const float4 *>(g)[i0], gb = reinterpret_cast<const float4 *>(g)[j1];
-            float4 ma = reinterpret_cast<float4 *>(m)[i0], mb = reinterpret_cast<float4 *>(m)[j1];
-            float4 va = reinterpret_cast<float4 *>(v)[i0], vb = reinterpret_cast<float4 *>(v)[j1];
-            adam_one(pa.x, ma.x, va.x, ga.x, c); adam_one(pa.y, ma.y, va.y, ga.y, c);
-            adam_one(pa.z, ma.z, va.z, ga.z, c); adam_one(pa.w, ma.w, va.w, ga.w, c);
-            reinterpret_cast<float4 *>(p)[i0] = pa;
-            reinterpret_cast<float4 *>(m)[i0] = ma;
-            reinterpret_cast<float4 *>(v)[i0] = va;
-            if (two) {
-                adam_one(pb.x, mb.x, vb.x, gb.x, c); adam_one(pb.y, mb.y, vb.y, gb.y, c);
-                adam_one(pb.z, mb.z, vb.z, gb.z, c); adam_one(pb.w, mb.w, vb.w, gb.w, c);
-                reinterpret_cast<float4 *>(p)[i1] = pb;
-                reinterpret_cast<float4 *>(m)[i1] = mb;
-                reinterpret_cast<float4 *>(v)[i1] = vb;
+        const size_t stride = (size_t)gridDim.x * 256 * ADAM_GROUPS;
+        for (size_t i0 = (size_t)blockIdx.x * 256 * ADAM_GROUPS + threadIdx.x; i0 < n4; i0 += stride) {
+            float4 pv[ADAM_GROUPS], gv[ADAM_GROUPS], mv[ADAM_GROUPS], vv[ADAM_GROUPS];
+            // (a group beyond the end re-reads the thread's first one -- a legal address: the loads stay unconditional)
+#pragma unroll
+            for (int u = 0; u < ADAM_GROUPS; ++u) {
+                const size_t i = i0 + 256 * u, j = i < n4 ? i : i0;
+                pv[u] = reinterpret_cast<float4 *>(p)[j]; gv[u] = reinterpret_cast<const float4 *>(g)[j];
+                mv[u] = reinterpret_cast<float4 *>(m)[j]; vv[u] = reinterpret_cast<float4 *>(v)[j];
+            }
+#pragma unroll
+            for (int u = 0; u < ADAM_GROUPS; ++u) {
+                const size_t i = i0 + 256 * u;
+                if (i >= n4) break;
+                adam_one(pv[u].x, mv[u].x, vv[u].x, gv[u].x, c); adam_one(pv[u].y, mv[u].y, vv[u].y, gv[u].y, c);
+                adam_one(pv[u].z, mv[u].z, vv[u].z, gv[u].z, c); adam_one(pv[u].w, mv[u].w, vv[u].w, gv[u].w, c);
+                reinterpret_cast<float4 *>(p)[i] = pv[u];
+                reinterpret_cast<float4 *>(m)[i] = mv[u];
+                reinterpret_cast<float4 *>(v)[i] = vv[u];
             }
         }
     }
@@ -314,7 +314,7 @@ MVAE_EXPORT int mvae_adam_step(float *param, const float *grad, float *exp_avg, 
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / (4 * ADAM_GROUPS) + 1, 256)), dim3(256), 0, st, param, grad, exp_avg,
                        exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, (const int64_t *)step_dev, (int64_t)1);
     hipLaunchKernelGGL(bump_i64_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return mvae_launch_status();
@@ -328,7 +328,7 @@ MVAE_EXPORT int mvae_adam_apply(float *param, const float *grad, float *exp_avg,
                                 const int64_t *step_dev, mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / (4 * ADAM_GROUPS) + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, (int64_t)1);
     return mvae_launch_status();
 }
@@ -340,7 +340,7 @@ MVAE_EXPORT int mvae_adam_apply_at(float *param, const float *grad, float *exp_a
                                    const int64_t *step_dev, int64_t step_add, mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / (4 * ADAM_GROUPS) + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_dev, step_add);
     return mvae_launch_status();
 }
@@ -351,7 +351,7 @@ MVAE_EXPORT int mvae_adam_apply_coef(float *param, const float *grad, float *exp
                                      mvae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !coef2) return MVAE_ERR_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(adam_coef_kernel, dim3(ew_blocks(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+    hipLaunchKernelGGL(adam_coef_kernel, dim3(ew_blocks(n / (4 * ADAM_GROUPS) + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, n, coef2, beta1, beta2, eps, grad_scale);
     return mvae_launch_status();
 }

@@ -1,6 +1,6 @@
 // shm_nccl.cpp -- TEST INFRASTRUCTURE: the subset of the NCCL/RCCL ABI that csrc/comm.hip binds
 // (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclBroadcast, ncclCommDestroy, ncclGetVersion,
-// ncclGetErrorString, ncclCommGetAsyncError), implemented over POSIX shared memory + host staging, so that
+// ncclGetErrorString, ncclCommGetAsyncError, and for MVAE_COMM_ALGO=rs_ag ncclReduceScatter / ncclAllGather), implemented over POSIX shared memory + host staging, so that
 // N ranks can share ONE GPU.
 //
 // Why: RCCL refuses two ranks on one device, the build pool has one-GPU boxes, and the default data-parallel
@@ -78,7 +78,7 @@ struct Comm {
     char *slot(int r) const { return slots + (size_t)r * CHUNK; }
 };
 
-struct Op { Comm *c; int kind; size_t bytes; int root; };     // kind 0: fp32 sum, 1: broadcast
+struct Op { Comm *c; int kind; size_t bytes; int root; };     // kind 0: fp32 sum, 1: broadcast, 2: fp32 sum kept by `root` only
 
 void fail(Comm *c, const char *why) {
     if (!c->failed.exchange(1)) fprintf(stderr, "[shm_nccl rank %d/%d] communicator failed: %s\n", c->rank, c->world, why);
@@ -108,7 +108,7 @@ void host_step(void *arg) {
     Op *op = (Op *)arg;
     Comm *c = op->c;
     if (c->failed.load()) return;
-    if (op->kind == 0) {
+    if (op->kind == 0 || op->kind == 2) {
         memcpy(c->slot(c->rank), c->bounce, op->bytes);
         if (!barrier(c)) return;
         const size_t n = op->bytes / sizeof(float);
@@ -137,6 +137,7 @@ ncclResult_t enqueue(Comm *c, int kind, const void *send, void *recv, size_t byt
         { std::lock_guard<std::mutex> lock(c->ops_mutex); c->ops.push_back(op); }
         if (hipMemcpyAsync(c->bounce, (const char *)send + off, nb, hipMemcpyDeviceToHost, st) != hipSuccess) return ncclUnhandledCudaError;
         if (hipLaunchHostFunc(st, host_step, op) != hipSuccess) return ncclUnhandledCudaError;
+        if (kind == 2 && c->rank != root) continue;                 // a reduce-scatter piece: only its owner keeps the sum
         if (hipMemcpyAsync((char *)recv + off, c->bounce, nb, hipMemcpyHostToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
     }
     return ncclSuccess;
@@ -241,6 +242,31 @@ __attribute__((visibility("default"))) ncclResult_t ncclBroadcast(const void *se
     Comm *c = (Comm *)comm;
     if (dt != ncclUint8 || !c || root < 0 || root >= c->world) return ncclInvalidArgument;
     return enqueue(c, 1, send, recv, count, root, st);
+}
+
+// piece p of the send buffer (recvcount floats) summed over the ranks in rank order, delivered to rank p
+__attribute__((visibility("default"))) ncclResult_t ncclReduceScatter(const void *send, void *recv, size_t recvcount, ncclDataType_t dt,
+                                                                       ncclRedOp_t op, ncclComm_t comm, hipStream_t st) {
+    Comm *c = (Comm *)comm;
+    if (dt != ncclFloat32 || op != ncclSum || !c) return ncclInvalidArgument;
+    for (int p = 0; p < c->world; ++p) {
+        const ncclResult_t r = enqueue(c, 2, (const float *)send + (size_t)p * recvcount, recv, recvcount * sizeof(float), p, st);
+        if (r != ncclSuccess) return r;
+    }
+    return ncclSuccess;
+}
+
+// rank p's sendcount floats land at recv + p * sendcount on every rank (a broadcast per rank)
+__attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *send, void *recv, size_t sendcount, ncclDataType_t dt,
+                                                                   ncclComm_t comm, hipStream_t st) {
+    Comm *c = (Comm *)comm;
+    if (dt != ncclFloat32 || !c) return ncclInvalidArgument;
+    for (int p = 0; p < c->world; ++p) {
+        float *dst = (float *)recv + (size_t)p * sendcount;
+        const ncclResult_t r = enqueue(c, 1, c->rank == p ? send : (const void *)dst, dst, sendcount * sizeof(float), p, st);
+        if (r != ncclSuccess) return r;
+    }
+    return ncclSuccess;
 }
 
 }  // extern "C"

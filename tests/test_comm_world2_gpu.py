@@ -166,7 +166,9 @@ def _oracle_shard_sums(kind, batch, input_seed, shards):
     return model, sums, zero_logit
 
 
-@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 12), ('celeba', 6), ('celeba19', 4), ('mnist', 512)])
+# (the last three: BASELINE.json configs[1..3]'s per-GPU batches on the default one-graph transport -- VERDICT r5 item 8b)
+@pytest.mark.parametrize('kind,batch', [('mnist', 16), ('fashionmnist', 12), ('celeba', 6), ('celeba19', 4), ('mnist', 512),
+                                        ('fashionmnist', 1024), ('celeba', 256)])
 def test_one_graph_step_at_world_size_two(kind, batch, tmp_path):
     redraws = 0
     for attempt in range(3):
@@ -226,6 +228,30 @@ def test_one_graph_step_at_world_size_two(kind, batch, tmp_path):
     assert not np.array_equal(p0, a['w1'].numpy())
     print('%s B=%d world 2, ONE graph with the collectives inside: worst reduced-gradient rel err %.2e, %d re-draw(s)'
           % (kind, batch, worst, redraws))
+
+
+def test_reduce_scatter_all_gather_algorithm_gives_the_same_bits(tmp_path, monkeypatch):
+    """MVAE_COMM_ALGO=rs_ag (csrc/comm.hip: the bucket all-reduce as an in-place ncclReduceScatter + ncclAllGather, the
+    remainder through ncclAllReduce) -- the switch SURVEY 8e's "direct over ring" can be A/B-ed with the day a multi-GPU
+    node exists.  Over the stand-in both algorithms add in rank order, so the reduced gradient, the first update and the
+    weights after three replays must be the SAME BITS as the default's (FashionMNIST: three buckets, one of them with a
+    length that is not a multiple of the world size)."""
+    kind, batch, seed = 'fashionmnist', 12, 733
+    outs = {}
+    for algo in ('default', 'rs_ag'):
+        out = tmp_path / algo
+        out.mkdir()
+        if algo == 'rs_ag':
+            monkeypatch.setenv('MVAE_COMM_ALGO', 'rs_ag')
+        else:
+            monkeypatch.delenv('MVAE_COMM_ALGO', raising=False)
+        _spawn(kind, batch, seed, out)
+        outs[algo] = ([torch.load(str(out / ('step0_rank%d.pt' % r)), weights_only=False) for r in range(2)],
+                      np.load(str(out / 'after_rank0.npy')))
+    (d_sh, d_after), (r_sh, r_after) = outs['default'], outs['rs_ag']
+    assert torch.equal(r_sh[0]['grad'], r_sh[1]['grad']) and torch.equal(r_sh[0]['w1'], r_sh[1]['w1'])
+    assert torch.equal(d_sh[0]['grad'], r_sh[0]['grad']), 'rs_ag reduced a different gradient'
+    assert torch.equal(d_sh[0]['w1'], r_sh[0]['w1']) and np.array_equal(d_after, r_after)
 
 
 def test_peer_killed_between_steps_raises_within_the_watchdog_budget(tmp_path):

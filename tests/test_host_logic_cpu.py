@@ -311,15 +311,15 @@ def test_committed_profile_tables_carry_this_trees_code_stamp(tmp_path, monkeypa
     with open(bench.BY_SHAPE_FILE) as f:
         by_shape = json.load(f)
     for kind in ('mnist', 'fashionmnist', 'celeba', 'celeba19'):
-        assert by_shape['_meta'][kind]['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r05_by_shape.json [%s] was collected on other kernel sources' % kind
+        assert by_shape['_meta'][kind]['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r06_by_shape.json [%s] was collected on other kernel sources' % kind
     with open(bench.TRAFFIC_FILE) as f:
         traffic = json.load(f)
     assert len(traffic) >= 8
     for call, ent in traffic.items():
-        assert ent['collected_on']['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r05_traffic.json [%s] was collected on other kernel sources' % call
+        assert ent['collected_on']['csrc_sha16'] == mine['csrc_sha16'], 'profiles/r06_traffic.json [%s] was collected on other kernel sources' % call
         assert ent['hbm_bytes_per_launch'] >= 0.9 * ent['algorithmic_bytes_per_launch'], call     # a launch cannot move less than it must
     us, st = bench.rocprof_us_for('mnist', 'linear_fwd', 'M1024 N512 K512')
-    assert 5.0 < us < 50.0 and st['stale'] is False and st['file'] == 'profiles/r05_by_shape.json'
+    assert 5.0 < us < 50.0 and st['stale'] is False and st['file'] == 'profiles/r06_by_shape.json'
     # a stamp from other sources is reported stale
     other = dict(traffic)
     k0 = sorted(other)[0]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: per-(launcher call, shape) rocprofv3 tables of one step of each workload
 #   -> gpurun_out/by_shape/${PFX}_<workload>_by_shape.txt + gpurun_out/by_shape/${PFX}_by_shape.json (copy into profiles/)
-PFX=${PFX:-r05}
+PFX=${PFX:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/by_shape; rm -rf $out; mkdir -p $out

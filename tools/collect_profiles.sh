@@ -2,7 +2,7 @@
 # GPU box: rocprofv3 kernel-trace summaries of the bench command for each workload -> gpurun_out/profiles_new/
 # (copy the ${PFX}_* files into profiles/)
 set -e
-PFX=${PFX:-r05}
+PFX=${PFX:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_new

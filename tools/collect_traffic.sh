@@ -3,7 +3,7 @@
 # usage: TRAFFIC_TABLE=r04_traffic.json tools/collect_traffic.sh "<name>|<key>" ...
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-table=${TRAFFIC_TABLE:-r05_traffic.json}
+table=${TRAFFIC_TABLE:-r06_traffic.json}
 out=gpurun_out/traffic
 rm -rf $out; mkdir -p $out
 for spec in "$@"; do
