@@ -1852,6 +1852,183 @@ __global__ __launch_bounds__(64 * SC_WAVES) void wgrad_smallcin_kernel(const flo
             }
 }
 
+// ---- the same through LDS-DMA (round 6).  What the register-staged kernel above paid per unit: 12 vector loads of 8 / 16
+//      bytes per lane (the 8-byte ones at a quarter of the addresser's rate), ~20 ds_write, ONE unit of prefetch (a second
+//      register set does not fit beside 32-64 accumulators) -- and, per launch, a tail that does not shrink with the batch:
+//      B = 256 -> 512 rows cost 11.6 us for 46 MB more (4 TB/s), the first 256 rows 23 us (profiles/r06_small_conv.txt).
+//      Here a wave's units arrive by `buffer_load_dword ... lds` into a wave-private ring of S stages: no staging registers,
+//      no ds_write, S - 1 units in flight, a counted vmcnt and NO barrier (the ring is the wave's own).  The dy slab lands
+//      as [CO][P] (P = 16 or 32 columns) with the column index XOR-swizzled on the SOURCE side -- element (co, ow) sits at
+//      column ow ^ s(co), s(co) = (co / (32 / P)) % P -- so that the A fragments (32 lanes = 32 channels, one column) read 32
+//      different banks; the input rows land in zero-haloed rows of pitch XW = 4 x odd, as before.  A row outside the image is
+//      fetched through an EMPTY descriptor (zeros), a dy column beyond OW through an out-of-range offset.
+constexpr int SC2_WAVES = 8;
+template <int MT, int NT, int CIN, int P, int S>
+__global__ __launch_bounds__(64 * SC2_WAVES) void wgrad_smallcin2_kernel(const float *dy, const float *x, float *ws, ConvGeom g,
+                                                                          int units, int XW) {
+    extern __shared__ __attribute__((aligned(16))) float sc_lds[];
+    constexpr int CO = 32 * MT;
+    constexpr int NDY = CO * P / 64;               // DMA instructions of a dy slab
+    constexpr int NXR = CIN * 4;                   // input rows of a unit: one DMA instruction each (W <= 64)
+    constexpr int NPU = NDY + NXR;
+    static_assert((S - 1) * NPU <= 63, "vmcnt is a 6-bit counter");
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int stage_floats = CO * P + NXR * XW;
+    float *ring = sc_lds + wave * S * stage_floats;
+    const unsigned ring_b = (unsigned)(unsigned long)(g2_lds_void *)ring;
+    const int J = CIN * 16, OW = g.OW, W = g.W, OH = g.OH;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // the halos of every stage's input rows: zero once, never rewritten (the DMA touches columns 4 .. 4 + W - 1 only)
+    for (int i = lane; i < S * NXR * 8; i += 64) {
+        const int st = i / (NXR * 8), rem = i - st * (NXR * 8), row = rem >> 3, c = rem & 7;
+        ring[st * stage_floats + CO * P + row * XW + (c < 4 ? c : W + c)] = 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int lr = lane & 31, lk = lane >> 5;
+    // dy: LDS dword `pos` of instruction i holds element (co, ow) = (pos / P, (pos % P) ^ s(co)), or zero
+    int dvoff[NDY];
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+        const int pos = i * 64 + lane, co = pos / P, ow = (pos % P) ^ ((co / (32 / P)) % P);
+        dvoff[i] = ow < OW ? (co * OH * OW + ow) * 4 : BUF_OOB;
+    }
+    // fragment addresses: A = dy[co = 32 a + lr][ow = 2 q + lk], B = x tap column j = 32 b + lr at input column 2 ow - 1 + kw
+    int aoff[MT], asw[MT], xoff[NT]; float xmask[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) { const int co = a * 32 + lr; aoff[a] = co * P; asw[a] = (co / (32 / P)) % P; }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int j = b * 32 + lr;
+        const bool ok = j < J;
+        const int jj = ok ? j : 0;
+        xoff[b] = CO * P + ((jj >> 4) * 4 + ((jj >> 2) & 3)) * XW + 4 - 1 + (jj & 3);      // + 2 * ow at use
+        xmask[b] = ok ? 1.f : 0.f;
+    }
+    const BufBase bdy = buf_base(dy), bx = buf_base(x);
+    const int nwaves = gridDim.x * SC2_WAVES;
+    const int u0 = blockIdx.x * SC2_WAVES + wave;
+    auto issue = [&](int u, int stage) {
+        const int b = u / OH, oh = u - b * OH;
+        const unsigned dst = ring_b + (unsigned)(stage * stage_floats) * 4u;
+        const i32x4_t rdy = g2_rsrc(bdy, ((long)b * CO * OH + oh) * OW, 0x7fffffff);
+        asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) g2_dma4(rdy, dvoff[i], 0, g2_uni(dst + i * 256));
+        const long img = (long)b * CIN * g.H * W;
+#pragma unroll
+        for (int r = 0; r < NXR; ++r) {
+            const int ci = r >> 2, ih = 2 * oh - 1 + (r & 3);
+            const bool in = ih >= 0 && ih < g.H;                     // wave-uniform
+            const i32x4_t rx = g2_rsrc(bx, img + ((long)ci * g.H + (in ? ih : 0)) * W, in ? 0x7fffffff : 0);
+            asm volatile("s_nop 4" ::: "memory");
+            // only the lanes of the row's W columns take part (EXEC): the piece must not run on into the halo and the next row
+            if (lane < W) g2_dma4(rx, lane * 4, 0, g2_uni(dst + (CO * P + r * XW + 4) * 4));
+        }
+    };
+    int nmine = 0;
+    for (int u = u0; u < units; u += nwaves) ++nmine;
+    int ui = u0;                                   // next unit to issue
+#pragma unroll
+    for (int s2 = 0; s2 < S - 1; ++s2) {
+        if (s2 < nmine) { issue(ui, s2); ui += nwaves; }
+    }
+    int st_c = 0, st_i = (S - 1) % S;
+    for (int n = 0; n < nmine; ++n) {
+        if (n + S - 1 < nmine) {
+            issue(ui, st_i); ui += nwaves;
+            st_i = st_i + 1 == S ? 0 : st_i + 1;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 1) * NPU) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const float *stg = ring + st_c * stage_floats;
+#pragma unroll 4
+        for (int q = 0; q < (OW >> 1); ++q) {
+            const int k = 2 * q + lk;
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = stg[aoff[a] + (k ^ asw[a])];
+#pragma unroll
+            for (int b2 = 0; b2 < NT; ++b2) bf[b2] = stg[xoff[b2] + 2 * k] * xmask[b2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < NT; ++b2)
+                    acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b2], acc[a][b2], 0, 0, 0);
+        }
+        st_c = st_c + 1 == S ? 0 : st_c + 1;
+    }
+    // ---- sum the waves' partials in a fixed order, write this block's [CO][J] partial (as the kernel above)
+    __syncthreads();
+    float *red = sc_lds;
+    if (wave > 0) {
+        float *dst = red + (wave - 1) * MT * NT * 1024 + lane;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * NT + b) * 16 + r) * 64] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float *out = ws + (size_t)blockIdx.x * CO * J;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][b][r];
+#pragma unroll
+                for (int w2 = 0; w2 < SC2_WAVES - 1; ++w2) v += red[w2 * MT * NT * 1024 + ((a * NT + b) * 16 + r) * 64 + lane];
+                const int co = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, j = b * 32 + lr;
+                if (j < J) out[(size_t)co * J + j] = v;
+            }
+}
+
+// the partials of up to 1024 blocks summed with ONE memory round trip: 32 outputs x 32 groups per block, group q adds
+// partials q, q + 32, ... (all its loads in flight), the 32 group sums combined through LDS in a fixed order
+template <class E>
+__global__ __launch_bounds__(1024) void finish_wide_kernel(SplitSink sink, int splits, E e) {
+    __shared__ float part[32][33];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + o, i = blockIdx.y;
+    float v[32];
+    const int jc = min(j, sink.J - 1);
+    const float *src = sink.ws + (size_t)i * sink.J + jc;
+#pragma unroll
+    for (int z = 0; z < 32; ++z) {
+        const int zz = grp + 32 * z;
+        v[z] = src[(size_t)min(zz, splits - 1) * sink.stride] * (zz < splits ? 1.f : 0.f);
+    }
+    float s0 = 0.f;
+#pragma unroll
+    for (int z = 0; z < 32; ++z) s0 += v[z];
+    part[grp][o] = s0;
+    __syncthreads();
+    if (grp == 0 && j < sink.J && e.col(j)) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tot += part[q][o];
+        e.put(i, j, tot);
+    }
+}
+
+#ifndef MVAE_SC2
+#define MVAE_SC2 1                // weight gradient of the <= 4-input-channel convs: the LDS-DMA kernel (0: the register-staged one)
+#endif
+#ifndef MVAE_SC2_STAGES
+#define MVAE_SC2_STAGES 2
+#endif
+
 inline bool wgrad_smallcin_ok(const ConvGeom &g) {
     return g.stride == 2 && g.pad == 1 && g.Cin <= 4 && (g.Cout == 32 || g.Cout == 64) && g.OW <= 32 &&
            (g.OW & 1) == 0 && g.W <= SC_MAXW && (g.W & 3) == 0;
@@ -1874,6 +2051,38 @@ int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int 
         const int blocks = wgrad_smallcin_blocks(g);
         if (ws_bytes >= (size_t)blocks * I * J * sizeof(float)) {
             const int mt = I / 32, nt = (J + 31) / 32;
+            bool launched = false;
+            if (MVAE_SC2) {
+                int xw = g.W + 8;
+                if (((xw / 4) & 1) == 0) xw += 4;                       // pitch = 4 x odd: the tap columns of a tile hit 32 banks
+                const int p = g.OW <= 16 ? 16 : 32;
+                const size_t stage_f = (size_t)I * p + (size_t)g.Cin * 4 * xw;
+                const size_t red_f = (size_t)(SC2_WAVES - 1) * mt * nt * 1024;
+                size_t lds2 = (size_t)SC2_WAVES * MVAE_SC2_STAGES * stage_f;
+                if (red_f > lds2) lds2 = red_f;
+                lds2 *= sizeof(float);
+#define MVAE_SC2L(MT_, NT_, CI_, P_)                                                                        \
+    {                                                                                                       \
+        auto kern = wgrad_smallcin2_kernel<MT_, NT_, CI_, P_, MVAE_SC2_STAGES>;                             \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SC2_WAVES), lds2, st, dy, x, (float *)ws, g, g.B * g.OH, xw); \
+        launched = true;                                                                                    \
+    }
+                if (lds2 <= 160 * 1024 && (size_t)g.B * I * g.OH * g.OW * 4 < ((size_t)1 << 31) &&
+                    (size_t)g.B * g.Cin * g.H * g.W * 4 < ((size_t)1 << 31)) {
+                    if (I == 32 && g.Cin == 3 && p == 32) MVAE_SC2L(1, 2, 3, 32)
+                    else if (I == 64 && g.Cin == 1 && p == 16) MVAE_SC2L(2, 1, 1, 16)
+                    else if (I == 32 && g.Cin == 1 && p == 32) MVAE_SC2L(1, 1, 1, 32)
+                    else if (I == 32 && g.Cin == 1 && p == 16) MVAE_SC2L(1, 1, 1, 16)
+                }
+#undef MVAE_SC2L
+            }
+            if (!launched) {
             const size_t wave_b = ((size_t)I * SC_DW + 16 * SC_XW) * sizeof(float);
             const size_t red_b = (size_t)(SC_WAVES - 1) * mt * nt * 1024 * sizeof(float);
             const size_t lds = SC_WAVES * wave_b > red_b ? SC_WAVES * wave_b : red_b;
@@ -1893,8 +2102,11 @@ int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int 
             else if (nt == 1) MVAE_SC(2, 1)
             else MVAE_SC(2, 2)
 #undef MVAE_SC
+            }
             SplitSink fs = make_sink(ws, I, J, false);
-            if (blocks > 16) {
+            if (blocks > 16 && blocks <= 1024 && MVAE_SC2) {
+                hipLaunchKernelGGL((finish_wide_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(1024), 0, st, fs, blocks, e);
+            } else if (blocks > 16) {
                 hipLaunchKernelGGL((finish_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(256), 0, st, fs, blocks, e);
             } else {
                 hipLaunchKernelGGL((finish_few_kernel<EpRowMajor>), dim3((J + 255) / 256, I), dim3(256), 0, st, fs,
