@@ -546,4 +546,211 @@ int launch_gemm2(const G2Plan &pl, PF make_p, QF make_q, E e, hipStream_t st) {
     return mvae_launch_status();
 }
 
+
+// ==========================================================================================
+// The latency layouts ("gemm2s"): the 512-wide MLP layers at batch 512-1024 -- 3.4 us of matrix time inside a 12-14 us
+// launch (profiles/r05_mnist_by_shape.txt), a step that is a chain of ~26 of them.  Same k-grouped block shape as
+// gemm_core.h's small layouts (tile 32 x 64 / 64 x 32 / 32 x 32, KW k-groups of waves that split every k-step, one block
+// per CU or two, the k-groups' tiles summed through LDS in a cooperative epilogue), on the LDS-DMA machinery above:
+//   * the operands of a k-step arrive by `buffer_load_dwordx4 ... lds` issued by the block's first four waves: nothing is
+//     staged through registers, so the ring is FOUR steps deep at 116-122 -> ~60 registers (round 5 measured four tiles in
+//     flight in REGISTERS: the launch 13.2 -> 12.4 us, the step +9 % -- two chain kernels no longer shared a CU);
+//   * the fragments of step k + 1 are read from LDS BEFORE the matrix instructions of step k issue: with two waves per SIMD
+//     that leave every barrier together, nothing else covers the LDS latency (~250 of a step's ~1300 cycles);
+//   * tools/gemm2s_probe.hip, hot inside a hipGraph: 1024 x 512 x 512 with bias + Swish, two outputs: 9.2-9.7 us against
+//     10.4 for the round-5 kernel.
+// K % 4 == 0 (whole float4s; a partial last k-step reads as zero), ragged rows / columns through out-of-range offsets.
+template <class E, int TMW, int TNW, int KW, int CH, int S, bool Q_RK>
+__global__ __launch_bounds__(64 * TMW * TNW * KW)
+void gemm2s_kernel(const float *__restrict__ P, int ldp, size_t p_cs, const float *__restrict__ Q, int ldq, size_t q_cs, E e,
+                   int I, int J, int K) {
+    constexpr int NIW = 4;                                         // issuing waves
+    constexpr int BM = 32 * TMW, BN = 32 * TNW, BK = 8 * KW * CH, NT = 64 * TMW * TNW * KW;
+    constexpr int F = BK / 4;
+    constexpr int P_FLOATS = BM * BK, Q_FLOATS = BN * BK, STAGE_FLOATS = P_FLOATS + Q_FLOATS;
+    constexpr int NA = P_FLOATS / 256, NB = Q_FLOATS / 256;
+    static_assert(NA % NIW == 0 && NB % NIW == 0, "pieces must divide over the issuing waves");
+    constexpr int NPW = (NA + NB) / NIW;
+    static_assert(NPW * (S - 2) <= 63 && S >= 3, "ring depth");
+    static_assert(F == 4 || F == 8 || F == 16, "k-step depth");
+    static_assert((BM * BN) % NT == 0, "cooperative epilogue: every thread takes part in every round");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = g2_uni(t >> 6);
+    const int kg = wave / (TMW * TNW), wq = wave % (TMW * TNW), wi = wq / TNW, wj = wq % TNW;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int cls = blockIdx.y;
+    const int tiles_j = (J + BN - 1) / BN, tiles_i = (I + BM - 1) / BM;
+    int b = blockIdx.x;
+    if (tiles_i % 8 == 0) b = (b & 7) * (tiles_i * tiles_j / 8) + (b >> 3);      // XCD x owns tiles_i / 8 row bands x all column tiles
+    const int ti = b / tiles_j, tj = b - ti * tiles_j;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const unsigned lds0 = (unsigned)(unsigned long)(g2_lds_void *)lds;
+    auto swz = [](int r) { return F == 4 ? (r >> 2) & 3 : F == 8 ? (r >> 1) & 7 : r & 15; };
+    E et = e;
+    et.set_class(cls);
+    // what this thread's outputs will need (bias, the producer's pre-activation, the dropout mask): requested first
+    constexpr int CNE = (BM * BN) / NT;
+    typename E::Pre cpre[CNE];
+#pragma unroll
+    for (int k = 0; k < CNE; ++k) {
+        const int el = t + k * NT;
+        cpre[k] = et.fetch(i0 + el / BN, j0 + el % BN);
+    }
+    // ---- DMA pieces of the issuing waves: piece q = wave + NIW * u (u < NPW); q < NA: a P piece, else Q piece q - NA
+    int voff[NPW], kpos[NPW];
+    if (wave < NIW) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int q = wave + NIW * u;
+            if (NIW * u < NA) {
+                const int slot = q * 64 + lane, r = slot / F, f = (slot % F) ^ swz(r);
+                voff[u] = (i0 + r < I) ? (r * ldp + f * 4) * 4 : BUF_OOB;
+                kpos[u] = f * 4;
+            } else if (Q_RK) {
+                const int slot = (q - NA) * 64 + lane, r = slot / F, f = (slot % F) ^ swz(r);
+                voff[u] = (j0 + r < J) ? (r * ldq + f * 4) * 4 : BUF_OOB;
+                kpos[u] = f * 4;
+            } else {
+                const int slot = (q - NA) * 64 + lane, k = slot / (BN / 4), n = (slot % (BN / 4)) * 4;
+                voff[u] = (j0 + n < J) ? (k * ldq + n) * 4 : BUF_OOB;
+                kpos[u] = 0;
+            }
+        }
+    }
+    const BufBase pb = buf_base(P + (size_t)cls * p_cs + (size_t)i0 * ldp);
+    const BufBase qb0 = buf_base(Q_RK ? Q + (size_t)cls * q_cs + (size_t)j0 * ldq : Q + (size_t)cls * q_cs + j0);
+    auto issue = [&](int kt, int stage) {
+        if (wave >= NIW) return;
+        const int k0 = kt * BK;
+        const bool tail = k0 + BK > K;                             // block-uniform: the last, partial k-step
+        const i32x4_t rp = g2_rsrc(pb, k0, 0x7fffffff);
+        const long left = (long)(K - k0) * ldq * 4;
+        const i32x4_t rq = Q_RK ? g2_rsrc(qb0, k0, 0x7fffffff)
+                                : g2_rsrc(qb0, (long)k0 * ldq, (int)(left < 0x7fffffffl ? left : 0x7fffffffl));
+        asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int q = wave + NIW * u;
+            const bool isp = NIW * u < NA;
+            const bool rk = isp || Q_RK;
+            const int vo = (rk && tail && k0 + kpos[u] >= K) ? BUF_OOB : voff[u];
+            g2_dma16(isp ? rp : rq, vo, g2_uni(lds0 + (stage * STAGE_FLOATS + (isp ? q * 256 : P_FLOATS + (q - NA) * 256)) * 4));
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int pbase = (wi * 32 + lcol) * BK;
+    const int qbase = Q_RK ? (wj * 32 + lcol) * BK : 4 * lrow * BN + wj * 32 + lcol;
+    const int fsw = swz(lcol);
+    const int nk = (K + BK - 1) / BK;
+    // fragments of one k-step: CH chunks of 8 k's (this k-group's), 4 k-pairs each
+    auto frags = [&](int stage, float4 (&pa)[CH], float4 (&qv)[CH]) {
+        const float *Ps = lds + stage * STAGE_FLOATS;
+        const float *Qs = Ps + P_FLOATS;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = kg * CH + c;
+            pa[c] = *reinterpret_cast<const float4 *>(Ps + pbase + 4 * ((2 * ch + lrow) ^ fsw));
+            if (Q_RK) qv[c] = *reinterpret_cast<const float4 *>(Qs + qbase + 4 * ((2 * ch + lrow) ^ fsw));
+            else qv[c] = make_float4(Qs[qbase + (8 * ch + 0) * BN], Qs[qbase + (8 * ch + 1) * BN], Qs[qbase + (8 * ch + 2) * BN],
+                                     Qs[qbase + (8 * ch + 3) * BN]);
+        }
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < S - 1; ++s2)
+        if (s2 < nk) issue(s2, s2);
+    // step 0 has landed when at most the younger S - 2 steps are outstanding
+    if (nk >= S - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPW * (S - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    float4 pa[CH], qv[CH], pa_n[CH], qv_n[CH];
+    frags(0, pa, qv);
+    int st_n = 1, st_i = S - 1;                                     // stage of step kt + 1, stage the next issue fills
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            // step kt + 1 must have landed: issued so far min(nk, kt + S - 1) steps, the ones after kt + 1 may stay in flight
+            if (kt + S - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPW * (S - 3 > 0 ? S - 3 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // behind the barrier every wave holds step kt's fragments in registers: stage kt % S is free
+            if (kt + S - 1 < nk) { issue(kt + S - 1, st_i); }
+            st_i = st_i + 1 == S ? 0 : st_i + 1;
+            frags(st_n, pa_n, qv_n);
+            st_n = st_n + 1 == S ? 0 : st_n + 1;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c].x, qv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c].y, qv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c].z, qv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c].w, qv[c].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { pa[c] = pa_n[c]; qv[c] = qv_n[c]; }
+    }
+    // ---- cooperative epilogue: park the k-groups' tiles, sum them in group order, run the epilogue functor
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    constexpr int TP = BN + 1;
+    float *tile = lds + kg * (BM * TP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = wi * 32 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+        tile[il * TP + wj * 32 + lcol] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CNE; ++k) {
+        const int el = t + k * NT;
+        const int il = el / BN, jl = el % BN;
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < KW; ++g2) v += lds[g2 * (BM * TP) + il * TP + jl];
+        const int i = i0 + il, j = j0 + jl;
+        if (et.col(j)) et.put_pre(i, j, v, cpre[k]);
+    }
+}
+
+#ifndef MVAE_G2S
+#define MVAE_G2S 1                // 0: the k-grouped small layouts of gemm_core.h everywhere (A/B builds)
+#endif
+#ifndef MVAE_G2S_STAGES
+#define MVAE_G2S_STAGES 4
+#endif
+
+// Launch for a plan of gemm_core.h's small layouts (pl.bk == 64): false when the shape has no instantiation here.
+template <class E, bool Q_RK>
+bool launch_gemm2s(const Plan &pl, const float *P, int ldp, size_t p_cs, const float *Q, int ldq, size_t q_cs, E e, int I,
+                   int J, int K, int ncls, hipStream_t st, int *status) {
+    if (!MVAE_G2S || pl.bk != 64 || pl.splits != 1 || (K & 3)) return false;
+#ifdef MVAE_TUNING
+    if (getenv("MVAE_G2S_OFF")) return false;
+#endif
+#define MVAE_G2S_LAUNCH(TMW, TNW, KW, CH)                                                                         \
+    {                                                                                                             \
+        constexpr int BM = 32 * TMW, BN = 32 * TNW, BK = 8 * KW * CH, NT = 64 * TMW * TNW * KW, STG = MVAE_G2S_STAGES; \
+        constexpr size_t ring = (size_t)STG * (BM + BN) * BK * sizeof(float);                                     \
+        constexpr size_t red = (size_t)KW * BM * (BN + 1) * sizeof(float);                                        \
+        constexpr size_t ldsb = ring > red ? ring : red;                                                          \
+        auto kern = gemm2s_kernel<E, TMW, TNW, KW, CH, STG, Q_RK>;                                                \
+        static bool attr_done = false;                                                                            \
+        if (!attr_done) {                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+            attr_done = true;                                                                                     \
+        }                                                                                                         \
+        const dim3 grid((unsigned)(cdiv(I, BM) * cdiv(J, BN)), (unsigned)ncls);                                   \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), ldsb, st, P, ldp, p_cs, Q, ldq, q_cs, e, I, J, K);               \
+        *status = mvae_launch_status();                                                                           \
+        return true;                                                                                              \
+    }
+    if (pl.wgm == 1 && pl.wgn == 2 && pl.kw == 4) MVAE_G2S_LAUNCH(1, 2, 4, 1)
+    if (pl.wgm == 2 && pl.wgn == 1 && pl.kw == 4) MVAE_G2S_LAUNCH(2, 1, 4, 1)
+    if (pl.wgm == 1 && pl.wgn == 2 && pl.kw == 2) MVAE_G2S_LAUNCH(1, 2, 2, 2)
+    if (pl.wgm == 2 && pl.wgn == 1 && pl.kw == 2) MVAE_G2S_LAUNCH(2, 1, 2, 2)
+    if (pl.wgm == 1 && pl.wgn == 1 && pl.kw == 8) MVAE_G2S_LAUNCH(1, 1, 8, 1)
+    if (pl.wgm == 1 && pl.wgn == 1 && pl.kw == 4) MVAE_G2S_LAUNCH(1, 1, 4, 2)
+#undef MVAE_G2S_LAUNCH
+    return false;
+}
+
 }  // namespace

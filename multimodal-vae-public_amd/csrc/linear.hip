@@ -65,6 +65,10 @@ static int linear_fwd_impl(const float *x, int ldx, const float *w, const float 
         G2Plan g2 = g2_plan_for(M, N, K, gr.G, false, ws, ws_bytes, (pre && act) ? G2_FWD_TWO_OUTPUTS : G2_PLAIN);
         if (g2.ok) return launch_gemm2<G2RowsK, G2RowsK, EpRowMajor, false>(g2, mp, mq, e, st);
     }
+    if (vec) {
+        int rc2 = MVAE_OK;
+        if (launch_gemm2s<EpRowMajor, true>(pl, x, ldx, gr.a, w, K, gr.b, e, M, N, K, gr.G, st, &rc2)) return rc2;
+    }
     if (vec)
         return launch_igemm_small<LdRowsK, LdRowsK, LdRowsK64, LdRowsK64, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
     return launch_igemm<LdRowsKS, LdRowsKS, EpRowMajor, false>(pl, mp, mq, e, M, N, K, sink, st);
@@ -154,6 +158,10 @@ static int linear_dgrad_impl(const float *dy, int lddy, const float *w, float *d
     if (vec) {
         G2Plan g2 = g2_plan_for(M, K, N, gr.G, false, ws, ws_bytes);
         if (g2.ok) return launch_gemm2<G2RowsK, G2RowsMN, EpRowMajor, false>(g2, mp, mq, e, st);
+    }
+    if (vec) {
+        int rc2 = MVAE_OK;
+        if (launch_gemm2s<EpRowMajor, false>(pl, dy, lddy, gr.a, w, K, gr.b, e, M, K, N, gr.G, st, &rc2)) return rc2;
     }
     if (vec)
         return launch_igemm_small<LdRowsK, LdRowsMN, LdRowsK64, LdRowsMN64, EpRowMajor, false>(pl, mp, mq, e, M, K, N, sink, st);
