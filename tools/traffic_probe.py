@@ -123,7 +123,7 @@ def algorithmic_bytes(name, key):
 def _per_call_kib(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)).fetchall()
-    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_batched|wgrad_smallcin|repack_dgrad', n)]
+    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|wgrad_direct|wgrad_batched|wgrad_smallcin|repack_dgrad', n)]
     per_kernel = {}
     for n, v in ours:
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:90]
@@ -165,7 +165,7 @@ def counters(db):
     rows = c.execute('select kernel_name, counter_name, value from counters_collection').fetchall()
     acc = {}
     for n, cn, v in rows:
-        if re.search(r'igemm_kernel|finish|convT_s1|convT_small|wgrad_direct|wgrad_batched|wgrad_smallcin', n):
+        if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|wgrad_direct|wgrad_batched|wgrad_smallcin', n):
             short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:100]
             acc.setdefault(short, {}).setdefault(cn, 0.0)
             acc[short][cn] += v / N_CALLS
