@@ -96,20 +96,48 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_stats_kernel(const floa
     }
 }
 
-// Chan merge of the S slice statistics of (g, c): returns mean and biased variance.
-__device__ inline void bn_merge(const float *ws, const BnShape &sh, int g, int c, float *mean, float *var) {
+// Chan merge of the S slice statistics of (g, c) by the WHOLE block: returns mean and biased variance to every thread.
+// Thread t folds slices t, t + 256, ... (one for every batch the step runs), the wave merges its 64 partials in a
+// butterfly, and every thread folds the four wave results (lane 0's) in wave order from LDS: a fixed tree --
+// deterministic, the same bits in every block of the (group, channel).  (Round 5's form was one thread walking the
+// S records in order, every thread of every block redundantly: a chain of S dependent loads -- the `continue` on an empty
+// record keeps hipcc from hoisting them -- and 2 S divisions in front of the first byte a block streams: 8 us of the
+// 38-us apply launch of CelebA's 32 x 32 maps at S = 32, which ran at 3.5 TB/s where its backward sibling does 5.9.)
+struct BnMoments { float n, m, m2; };
+__device__ __forceinline__ BnMoments bn_chan(BnMoments a, BnMoments b) {
+    const float nt = a.n + b.n;
+    if (nt <= 0.f) return a;
+    const float d = b.m - a.m, r = b.n / nt;
+    BnMoments o;
+    o.n = nt; o.m = a.m + d * r; o.m2 = a.m2 + b.m2 + d * d * (a.n * r);
+    return o;
+}
+__device__ __forceinline__ void bn_merge_block(const float *ws, const BnShape &sh, int g, int c, float *mean, float *var,
+                                               float (*red)[3]) {
     const float *p = ws + (size_t)(g * sh.C + c) * sh.S * 3;
-    float n = 0.f, m = 0.f, m2 = 0.f;
-    for (int s = 0; s < sh.S; ++s) {
-        const float nb = p[s * 3], mb = p[s * 3 + 1], m2b = p[s * 3 + 2];
-        if (nb <= 0.f) continue;
-        const float nt = n + nb, d = mb - m;
-        m += d * (nb / nt);
-        m2 += m2b + d * d * (n * nb / nt);
-        n = nt;
+    BnMoments a = {0.f, 0.f, 0.f};
+    for (int s = threadIdx.x; s < sh.S; s += BN_THREADS) {
+        const BnMoments b = {p[s * 3], p[s * 3 + 1], p[s * 3 + 2]};
+        a = bn_chan(a, b);
     }
-    *mean = m;
-    *var = n > 0.f ? m2 / n : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        BnMoments b;
+        b.n = __shfl_xor(a.n, off, 64); b.m = __shfl_xor(a.m, off, 64); b.m2 = __shfl_xor(a.m2, off, 64);
+        a = bn_chan(a, b);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                   // the previous call's readers are done with `red`
+    if (lane == 0) { red[wave][0] = a.n; red[wave][1] = a.m; red[wave][2] = a.m2; }
+    __syncthreads();
+    BnMoments t = {red[0][0], red[0][1], red[0][2]};
+#pragma unroll
+    for (int w = 1; w < BN_THREADS / 64; ++w) {
+        const BnMoments b = {red[w][0], red[w][1], red[w][2]};
+        t = bn_chan(t, b);
+    }
+    *mean = t.m;
+    *var = t.n > 0.f ? t.m2 / t.n : 0.f;
 }
 
 // y = swish?(gamma * ((x - mean) * invstd) + beta); also saves mean/invstd and advances the
@@ -121,25 +149,28 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float *_
                                                                   BnShape sh, float eps, float momentum,
                                                                   int n_updates, const int *n_updates_dev,
                                                                   int swish) {
+    __shared__ float red[BN_THREADS / 64][3];
     const int s = blockIdx.x, c = blockIdx.y, g = blockIdx.z;
     if (n_updates_dev) n_updates = *n_updates_dev;   // device-side count: graph replays may vary it
     float mean, var;
-    bn_merge(ws, sh, g, c, &mean, &var);
+    bn_merge_block(ws, sh, g, c, &mean, &var, red);
     const float invstd = rsqrtf(var + eps);
     if (s == 0 && threadIdx.x == 0) {
         save_mean[g * sh.C + c] = mean;
         save_invstd[g * sh.C + c] = invstd;
-        if (g == 0 && running_mean) {
-            float rm = running_mean[c], rv = running_var[c];
-            const float unb = sh.n > 1 ? (float)sh.n / (float)(sh.n - 1) : 1.f;
-            for (int gg = 0; gg < sh.G; ++gg) {
-                float m, v;
-                bn_merge(ws, sh, gg, c, &m, &v);
-                for (int u = 0; u < n_updates; ++u) {
-                    rm = (1.f - momentum) * rm + momentum * m;
-                    rv = (1.f - momentum) * rv + momentum * (v * unb);
-                }
+    }
+    if (s == 0 && g == 0 && running_mean) {            // block-uniform: the whole block merges every group, in order
+        float rm = running_mean[c], rv = running_var[c];
+        const float unb = sh.n > 1 ? (float)sh.n / (float)(sh.n - 1) : 1.f;
+        for (int gg = 0; gg < sh.G; ++gg) {
+            float m, v;
+            bn_merge_block(ws, sh, gg, c, &m, &v, red);
+            for (int u = 0; u < n_updates; ++u) {
+                rm = (1.f - momentum) * rm + momentum * m;
+                rv = (1.f - momentum) * rv + momentum * (v * unb);
             }
+        }
+        if (threadIdx.x == 0) {
             running_mean[c] = rm;
             running_var[c] = rv;
         }
