@@ -2,6 +2,7 @@
 // kernel of gemm_core.h: the gather loaders, the three special-shape kernels and the C ABI.
 #include "gemm_core.h"
 #include "gemm2.h"
+#include "convt_patch.h"
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
@@ -1646,6 +1647,17 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
     SplitSink sink = make_sink(nullptr, I, J, false);
     sink.ncls = s * s;      // all parity classes in ONE launch: s*s times the blocks
     sink.cls_minor = MVAE_CLS_MINOR;
+    if (vec && s == 2 && e.pair && MVAE_EP_BUFFER && !MVAE_TUNE(wm) && aligned16(dy)) {
+        // one LDS input patch for the four parity classes (convt_patch.h): the 64- and 32-row layers on 7 x 7 / 8 x 8 / 16 x 16 maps
+        const PatchPlan pp = convt_patch_plan(g.B, g.Cout, g.Cin, g.OH, g.OW, false);
+        if (pp.kind) {
+            EpNCHWPair ep;
+            static_cast<EpNCHW &>(ep) = e;
+            if (pp.kind == 1) return launch_convt_patch2<68, true>(pp, dy, wr, ep, st);
+            if (pp.kind == 2) return launch_convt_patch2<148, false>(pp, dy, wr, ep, st);
+            if (pp.kind == 3) return launch_convt_patch2<100, true>(pp, dy, wr, ep, st);
+        }
+    }
     if (vec) {
         // pair stores want the two px classes of a tile in ONE block.  Short reductions (K <= 256) run multi-item
         // blocks anyway; for K = 512 (the 64-channel layers) two items per block pay only when the launch still
@@ -1695,6 +1707,14 @@ int conv_dgrad_stats_impl(const float *dy, const float *w, float *part, ConvGeom
         int blocks = (total + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(repack_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wr, g.Cout, g.Cin, s, g.pad);
+    }
+    if (!MVAE_TUNE(wm) && aligned16(dy)) {
+        const PatchPlan pp = convt_patch_plan(g.B, g.Cout, g.Cin, g.OH, g.OW, true);
+        if (pp.kind == 4) {                                 // one record per 128-column tile, as below
+            EpStats es;
+            es.part = part; es.C = g.Cin; es.J = J;
+            return launch_convt_patch<EpStats, 32, 128, 164, true, MVAE_PATCH_KPH32>(pp, dy, wr, es, st);
+        }
     }
     Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);
     if (!(pl.wgn == 4 && pl.wm == 1 && pl.wn == 1 && pl.kw == 1 && pl.splits == 1)) return MVAE_ERR_ARG;   // the 32-row layout

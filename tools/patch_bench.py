@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""The LDS-patch transposed-conv kernels (csrc/convt_patch.h) against the class-by-class gather launches of gemm_core.h at
+the shapes of the bench workloads: outputs compared element by element, launches timed hot inside a hipGraph
+(tools/gemm_bench.timeit).  Uses the tuning library (MVAE_PATCH_OFF picks the kernel per call).
+
+    python tools/patch_bench.py [lib-variant ...]     (extra columns: MVAE_HIP_LIB variants cannot switch in-process -- one process per library)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+import torch  # noqa: E402
+
+import gemm_bench as gb  # noqa: E402  (sets MVAE_HIP_LIB to the tuning build unless it is set)
+from mvae_amd import kernels as K  # noqa: E402
+
+
+def convT_fwd(B, Cin, H, Cout, tag, stats=False):
+    r = gb.r
+    OH = 2 * H
+    x, w = r(B, Cin, H, H), r(Cin, Cout, 4, 4)
+    y, a = torch.empty(B, Cout, OH, OH, device='cuda'), torch.empty(B, Cout, OH, OH, device='cuda')
+    fl = 2.0 * B * Cin * H * H * Cout * 16
+    return ('%s convT fwd' % tag, fl, lambda: K.convT2d_fwd(x, w, y, a, 2, 1), lambda: (y, a))
+
+
+def conv_dgrad(B, Cin, H, Cout, tag):
+    r = gb.r
+    OH = H // 2
+    x, w, dy = r(B, Cin, H, H), r(Cout, Cin, 4, 4), r(B, Cout, OH, OH)
+    dx = torch.empty_like(x)
+    fl = 2.0 * B * Cout * OH * OH * Cin * 16
+    return ('%s conv dgrad' % tag, fl, lambda: K.conv2d_dgrad(dy, w, dx, x, 2, 1), lambda: (dx,))
+
+
+def main():
+    cases = [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
+             conv_dgrad(1024, 64, 14, 128, 'fm enc2 64->128 14x14 B1024'),
+             convT_fwd(512, 128, 8, 64, 'dec2 128->64 8x8 B512'),
+             convT_fwd(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608'),
+             conv_dgrad(256, 64, 16, 128, 'enc3 64->128 16x16 B256'),
+             convT_fwd(512, 64, 16, 32, 'dec3 64->32 16x16 B512'),
+             convT_fwd(256, 64, 16, 32, 'dec3 64->32 16x16 B256'),
+             conv_dgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256')]
+    print('%-40s %7s | %9s %9s  (TFLOP/s, us)  | max rel diff' % ('op', 'GFLOP', 'gather', 'patch'))
+    for name, fl, fn, outs in cases:
+        row, ref, worst = [], None, 0.0
+        for off in (True, False):
+            if off:
+                os.environ['MVAE_PATCH_OFF'] = '1'
+            else:
+                os.environ.pop('MVAE_PATCH_OFF', None)
+            for o in outs():
+                o.fill_(float('nan'))
+            fn()
+            torch.cuda.synchronize()
+            got = [o.clone() for o in outs()]
+            if off:
+                ref = got
+            else:
+                for g, rf in zip(got, ref):
+                    d = ((g - rf).abs().max() / rf.abs().max().clamp_min(1e-30)).item()
+                    worst = max(worst, d if d == d else float('inf'))
+            row.append(gb.timeit(fn, launches=10, replays=3))
+        os.environ.pop('MVAE_PATCH_OFF', None)
+        print('%-40s %7.2f | ' % (name, fl / 1e9) + ' '.join('%6.1f %6.1f' % (fl / (ms * 1e-3) / 1e12, ms * 1e3) for ms in row) + '   | %.2e' % worst)
+
+
+if __name__ == '__main__':
+    main()
