@@ -1653,9 +1653,9 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
         if (pp.kind) {
             EpNCHWPair ep;
             static_cast<EpNCHW &>(ep) = e;
-            if (pp.kind == 1) return launch_convt_patch2<68, true>(pp, dy, wr, ep, st);
-            if (pp.kind == 2) return launch_convt_patch2<148, false>(pp, dy, wr, ep, st);
-            if (pp.kind == 3) return launch_convt_patch2<100, true>(pp, dy, wr, ep, st);
+            if (pp.kind == 1) return launch_convt_patch2<EpNCHWPair, 1, 68, true>(pp, dy, wr, ep, st);
+            if (pp.kind == 2) return launch_convt_patch2<EpNCHWPair, 1, 148, false>(pp, dy, wr, ep, st);
+            if (pp.kind == 3) return launch_convt_patch2<EpNCHWPair, 1, 100, true>(pp, dy, wr, ep, st);
         }
     }
     if (vec) {
@@ -1713,7 +1713,7 @@ int conv_dgrad_stats_impl(const float *dy, const float *w, float *part, ConvGeom
         if (pp.kind == 4) {                                 // one record per 128-column tile, as below
             EpStats es;
             es.part = part; es.C = g.Cin; es.J = J;
-            return launch_convt_patch<EpStats, 32, 128, 164, true, MVAE_PATCH_KPH32>(pp, dy, wr, es, st);
+            return launch_convt_patch2<EpStats, 2, 100, true>(pp, dy, wr, es, st);
         }
     }
     Plan pl = make_plan(I, J, K, false, PLAN_FWD, s * s);

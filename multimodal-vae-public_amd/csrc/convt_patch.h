@@ -270,10 +270,13 @@ __global__ __launch_bounds__(256) void convT_patch_kernel(const float *__restric
 // profiles/r06_patch_bench.txt).  Rows: i0 = 32 * blockIdx.y (Cin = 64: two row halves re-read the patch).
 constexpr int CP2_KPH = 16, CP2_SPP = CP2_KPH / 4;
 
-template <int PS, bool X4, int NUI>
+// E = EpNCHWPair: one tile per block, pair stores.  E = EpStats: TILES = 2 consecutive tiles per block and one (mean, M2)
+// record over their 4 x 128 values per row -- the record mvae_bn_stats_merge expects (gemm_core.h STATK).
+template <class E, int TILES, int PS, bool X4, int NUI>
 __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__restrict__ dy, const float *__restrict__ wr,
-                                                              EpNCHWPair e, PatchGeo g) {
+                                                              E e, PatchGeo g) {
     static_assert(!X4 || PS % 4 == 0, "16-byte pieces");
+    constexpr bool STATS = ep_stats<E>::value;
     constexpr int PSV = X4 ? PS / 4 : PS;
     constexpr int PATCH_FLOATS = NUI * 256 * (X4 ? 4 : 1);  // one buffer
     constexpr int WT = 4 * CP_BK * 32;                      // floats per ring stage: [ph][pw][16][32]
@@ -284,60 +287,14 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
     const int wave = g2_uni(t >> 6);
     const int wj = wave & 1, ph = wave >> 1;
     const int lrow = lane >> 5, lcol = lane & 31;
-    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
+    const int i0 = blockIdx.y * 32;
     const unsigned lds0 = (unsigned)(unsigned long)(g2_lds_void *)lds;
     const unsigned ring0 = lds0 + 2 * PATCH_FLOATS * 4;
-
-    const int j = j0 + wj * 32 + lcol;
-    const bool jok = j < g.J;
-    const int jj = jok ? j : 0;
-    const int n = jj / g.OHW, rem = jj - n * g.OHW;
-    const int ih2 = rem / g.W2, iw2 = rem - ih2 * g.W2;
-    const int n0 = g2_uni(j0 / g.OHW);
-    const int r0 = g2_uni((j0 - n0 * g.OHW) / g.W2);
-    const int pidx = g.mode_a ? (n - n0) * g.OHW + rem : (ih2 - r0 + 1) * g.W2 + iw2;
-    // the wave's ph picks two of the three neighbour rows: tap a = 0 -> row ih' + ph, a = 1 -> row ih' + ph - 1
-    int pb[2][3];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-            const int dr = ph - a;
-            const bool ok = jok && ih2 + dr >= 0 && ih2 + dr < g.H2 && iw2 + dc >= 0 && iw2 + dc < g.W2;
-            pb[a][dc + 1] = ((ok ? pidx + dr * g.W2 + dc : PS - 1) + lrow * PS) * 4;
-        }
-    int pvoff[NUI];
-#pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-        const int u = i * 256 + t, c = u / PSV, q = (u - c * PSV) * (X4 ? 4 : 1);
-        int off = BUF_OOB;
-        if (c < CP2_KPH && q < g.ps_raw) {
-            if (g.mode_a) {
-                const int img = q / g.OHW, pos = q - img * g.OHW;
-                if (n0 + img < g.B) off = ((img * g.Cout + c) * g.OHW + pos) * 4;
-            } else {
-                const int row = q / g.W2, ih = r0 - 1 + row;
-                if (ih >= 0 && ih < g.H2) off = (c * g.OHW + ih * g.W2 + (q - row * g.W2)) * 4;
-            }
-        }
-        pvoff[i] = off;
-    }
-    const BufBase dyb = buf_base(dy + (size_t)n0 * g.Cout * g.OHW);
-    auto issue_patch = [&](int phase) {
-        const i32x4_t rs = g2_rsrc(dyb, (long)phase * CP2_KPH * g.OHW, 0x7fffffff);
-        const unsigned base = lds0 + (phase & 1) * PATCH_FLOATS * 4;
-        asm volatile("s_nop 4" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NUI; ++i) {
-            const unsigned dst = g2_uni(base + (i * 256 + wave * 64) * (X4 ? 16 : 4));
-            if (X4) g2_dma16(rs, pvoff[i], dst);
-            else g2_dma4(rs, pvoff[i], 0, dst);
-        }
-    };
     // weights: wave w moves the 16 x 32 tile of class w (= ph * 2 + pw) in two 1-KiB pieces (rows 0-7, 8-15)
     const BufBase wb = buf_base(wr + i0);
     const int wvoff = ((lane >> 3) * g.Cin + (lane & 7) * 4) * 4;
     const int steps_total = (g.Cout / CP2_KPH) * CP2_SPP;
+    const int nphase = g.Cout / CP2_KPH;
     auto issue_w = [&](int u) {
         const unsigned dst = ring0 + ((u % CP_STAGES) * WT + wave * 512) * 4;
         const i32x4_t rs = g2_rsrc(wb, ((long)wave * g.K + (long)u * CP_BK) * g.Cin, 0x7fffffff);
@@ -346,62 +303,172 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
         g2_dma16(rs, wvoff, g2_uni(dst));
         g2_dma16(rs2, wvoff, g2_uni(dst + 1024));
     };
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
     const int abase = (ph * 2 * CP_BK * 32 + 4 * lrow * 32 + lcol) * 4;
-    issue_w(0);
-    if (steps_total > 1) issue_w(1);
-    issue_patch(0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    const int nphase = g.Cout / CP2_KPH;
-    int u = 0;
-    for (int phase = 0; phase < nphase; ++phase) {
-        const bool more = phase + 1 < nphase;               // block-uniform
-        const char *Pp = reinterpret_cast<const char *>(lds) + (phase & 1) * PATCH_FLOATS * 4;
+    std::conditional_t<STATS, f32x16, char> st1, st2, shf;
+
+    for (int tile = 0; tile < TILES; ++tile) {
+        const int j0 = (blockIdx.x * TILES + tile) * 64;
+        const int j = j0 + wj * 32 + lcol;
+        const bool jok = j < g.J;
+        const int jj = jok ? j : 0;
+        const int n = jj / g.OHW, rem = jj - n * g.OHW;
+        const int ih2 = rem / g.W2, iw2 = rem - ih2 * g.W2;
+        const int n0 = g2_uni(j0 / g.OHW);
+        const int n1 = g2_uni((min(j0 + 63, g.J - 1)) / g.OHW);      // last image of the tile
+        const int r0 = g2_uni((j0 - n0 * g.OHW) / g.W2);
+        const int pidx = g.mode_a ? (n - n0) * g.OHW + rem : (ih2 - r0 + 1) * g.W2 + iw2;
+        // the wave's ph picks two of the three neighbour rows: tap a = 0 -> row ih' + ph, a = 1 -> row ih' + ph - 1
+        int pb[2][3];
 #pragma unroll
-        for (int ks = 0; ks < CP2_SPP; ++ks, ++u) {
-            if (u > 0) {
-                // what may stay in flight behind step u's weights: step u + 1's, and (steps 1, 2 of a phase) the next patch
-                if (u + 1 >= steps_total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else if ((ks == 1 || ks == 2) && more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NPW + NUI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NPW) : "memory");
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int dr = ph - a;
+                const bool ok = jok && ih2 + dr >= 0 && ih2 + dr < g.H2 && iw2 + dc >= 0 && iw2 + dc < g.W2;
+                pb[a][dc + 1] = ((ok ? pidx + dr * g.W2 + dc : PS - 1) + lrow * PS) * 4;
             }
-            if (u + 2 < steps_total) issue_w(u + 2);
-            if (ks == 0 && more) issue_patch(phase + 1);
-            const char *Ws = reinterpret_cast<const char *>(lds) + (2 * PATCH_FLOATS + (u % CP_STAGES) * WT) * 4 + abase;
-            const char *Pc = Pp + ks * 4 * PS * 4;
+        int pvoff[NUI];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+        for (int i = 0; i < NUI; ++i) {
+            const int u = i * 256 + t, c = u / PSV, q = (u - c * PSV) * (X4 ? 4 : 1);
+            int off = BUF_OOB;
+            if (c < CP2_KPH && q < g.ps_raw) {
+                if (g.mode_a) {
+                    const int img = q / g.OHW, pos = q - img * g.OHW;
+                    if (n0 + img <= n1) off = ((img * g.Cout + c) * g.OHW + pos) * 4;      // only the images the tile touches
+                } else {
+                    const int row = q / g.W2, ih = r0 - 1 + row;
+                    if (ih >= 0 && ih < g.H2) off = (c * g.OHW + ih * g.W2 + (q - row * g.W2)) * 4;
+                }
+            }
+            pvoff[i] = off;
+        }
+        const BufBase dyb = buf_base(dy + (size_t)n0 * g.Cout * g.OHW);
+        auto issue_patch = [&](int phase) {
+            const i32x4_t rs = g2_rsrc(dyb, (long)phase * CP2_KPH * g.OHW, 0x7fffffff);
+            const unsigned base = lds0 + (phase & 1) * PATCH_FLOATS * 4;
+            asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const float bm1 = *reinterpret_cast<const float *>(Pc + pb[a][0] + 2 * c * PS * 4);
-                    const float b0 = *reinterpret_cast<const float *>(Pc + pb[a][1] + 2 * c * PS * 4);
-                    const float bp1 = *reinterpret_cast<const float *>(Pc + pb[a][2] + 2 * c * PS * 4);
-                    const int kr = 8 * c + 2 * a;
-                    const float a00 = *reinterpret_cast<const float *>(Ws + (kr * 32) * 4);
-                    const float a01 = *reinterpret_cast<const float *>(Ws + ((kr + 1) * 32) * 4);
-                    const float a10 = *reinterpret_cast<const float *>(Ws + (CP_BK * 32 + kr * 32) * 4);
-                    const float a11 = *reinterpret_cast<const float *>(Ws + (CP_BK * 32 + (kr + 1) * 32) * 4);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, bp1, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, bm1, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b0, acc[1], 0, 0, 0);
+            for (int i = 0; i < NUI; ++i) {
+                const unsigned dst = g2_uni(base + (i * 256 + wave * 64) * (X4 ? 16 : 4));
+                if (X4) g2_dma16(rs, pvoff[i], dst);
+                else g2_dma4(rs, pvoff[i], 0, dst);
+            }
+        };
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+        if (tile > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous tile's readers are done
+        issue_w(0);
+        if (steps_total > 1) issue_w(1);
+        issue_patch(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        int u = 0;
+        for (int phase = 0; phase < nphase; ++phase) {
+            const bool more = phase + 1 < nphase;               // block-uniform
+            const char *Pp = reinterpret_cast<const char *>(lds) + (phase & 1) * PATCH_FLOATS * 4;
+#pragma unroll
+            for (int ks = 0; ks < CP2_SPP; ++ks, ++u) {
+                if (u > 0) {
+                    // what may stay in flight behind step u's weights: step u + 1's, and (steps 1, 2 of a phase) the next patch
+                    if (u + 1 >= steps_total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if ((ks == 1 || ks == 2) && more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NPW + NUI) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NPW) : "memory");
+                }
+                if (u + 2 < steps_total) issue_w(u + 2);
+                if (ks == 0 && more) issue_patch(phase + 1);
+                const char *Ws = reinterpret_cast<const char *>(lds) + (2 * PATCH_FLOATS + (u % CP_STAGES) * WT) * 4 + abase;
+                const char *Pc = Pp + ks * 4 * PS * 4;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const float bm1 = *reinterpret_cast<const float *>(Pc + pb[a][0] + 2 * c * PS * 4);
+                        const float b0 = *reinterpret_cast<const float *>(Pc + pb[a][1] + 2 * c * PS * 4);
+                        const float bp1 = *reinterpret_cast<const float *>(Pc + pb[a][2] + 2 * c * PS * 4);
+                        const int kr = 8 * c + 2 * a;
+                        const float a00 = *reinterpret_cast<const float *>(Ws + (kr * 32) * 4);
+                        const float a01 = *reinterpret_cast<const float *>(Ws + ((kr + 1) * 32) * 4);
+                        const float a10 = *reinterpret_cast<const float *>(Ws + (CP_BK * 32 + kr * 32) * 4);
+                        const float a11 = *reinterpret_cast<const float *>(Ws + (CP_BK * 32 + (kr + 1) * 32) * 4);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, bp1, acc[1], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, bm1, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b0, acc[1], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
-    EpNCHWPair et = e;
-    et.set_class(ph * 2);
-    et.tile(j0);
-    (void)et.col(j);
-    const int rb = __builtin_amdgcn_readfirstlane(i0);
+        if constexpr (STATS) {
+            // sums around a shift (gemm_core.h STATK): the first value lane 0 of each half wave holds of every row
 #pragma unroll
-    for (int r = 0; r < 16; ++r) et.put2_b(rb, r, acc[0][r], acc[1][r]);
+            for (int r = 0; r < 16; ++r) {
+                if (tile == 0) {
+                    const int bits = __float_as_int(acc[0][r]);
+                    const float lo = __int_as_float(__builtin_amdgcn_readlane(bits, 0));
+                    const float hi = __int_as_float(__builtin_amdgcn_readlane(bits, 32));
+                    shf[r] = lrow ? hi : lo;
+                    st1[r] = 0.f; st2[r] = 0.f;
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float d = acc[b][r] - shf[r];
+                    st1[r] += d;
+                    st2[r] = fmaf(d, d, st2[r]);
+                }
+            }
+        } else {
+            E et = e;
+            et.set_class(ph * 2);
+            et.tile(j0);
+            (void)et.col(j);
+            const int rb = __builtin_amdgcn_readfirstlane(i0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) et.put2_b(rb, r, acc[0][r], acc[1][r]);
+        }
+    }
+    if constexpr (STATS) {
+        // per (wave, row): 2 tiles x 2 pw x 32 positions = 128 values; the four waves merged in wave order
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st1[r] = half_wave_sum(st1[r]); st2[r] = half_wave_sum(st2[r]); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float *red = lds;                                   // [wave][32 rows][3]
+        if (lcol == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                red[(wave * 32 + row) * 3 + 0] = st1[r];
+                red[(wave * 32 + row) * 3 + 1] = st2[r];
+                red[(wave * 32 + row) * 3 + 2] = shf[r];
+            }
+        }
+        __syncthreads();
+        if (t < 32) {
+            const float nw = (float)(TILES * 64);
+            float mw[4], m2w[4], mean = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const float *rr = red + (w2 * 32 + t) * 3;
+                const float d = rr[0] / nw;
+                mw[w2] = rr[2] + d;
+                m2w[w2] = fmaxf(rr[1] - rr[0] * d, 0.f);
+                mean += mw[w2];
+            }
+            mean /= 4.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) m2 += m2w[w2] + nw * (mw[w2] - mean) * (mw[w2] - mean);
+            if (i0 + t < e.C) {
+                float *dst = e.part + ((size_t)blockIdx.x * e.C + i0 + t) * 2;
+                dst[0] = mean;
+                dst[1] = m2;
+            }
+        }
+    }
 }
 
 // which instantiation covers a geometry (0: none)
@@ -418,9 +485,9 @@ inline PatchPlan convt_patch_plan(int B, int Cout, int Cin, int OH, int OW, bool
     if (J * 4 >= (1L << 31) || (long)B * Cout * g.OHW >= (1L << 29)) return pl;
     g.J = (int)J; g.K = Cout * 4;
     if (stats) {
-        if (Cin == 32 && OH == 16 && OW == 16 && Cout % 32 == 0) {     // 8 lattice rows + a halo row either side
-            pl.kind = 4; g.mode_a = 0; g.nimg = 1; g.ps_raw = 160;
-            pl.blocks = (int)cdiv(J, 128);
+        if (Cin == 32 && OH == 16 && OW == 16 && Cout % CP2_KPH == 0 && J % 128 == 0) {     // two 64-position tiles per record
+            pl.kind = 4; g.mode_a = 0; g.nimg = 1; g.ps_raw = 96;
+            pl.blocks = (int)(J / 64);
         }
         return pl;
     }
@@ -449,18 +516,18 @@ int launch_convt_patch(const PatchPlan &pl, const float *dy, const float *wr, E 
     return mvae_launch_status();
 }
 
-template <int PS, bool X4>
-int launch_convt_patch2(const PatchPlan &pl, const float *dy, const float *wr, const EpNCHWPair &e, hipStream_t st) {
+template <class E, int TILES, int PS, bool X4>
+int launch_convt_patch2(const PatchPlan &pl, const float *dy, const float *wr, const E &e, hipStream_t st) {
     constexpr int PSV = X4 ? PS / 4 : PS;
     constexpr int NUI = (CP2_KPH * PSV + 255) / 256;
     constexpr size_t lds = ((size_t)2 * NUI * 256 * (X4 ? 4 : 1) + (size_t)CP_STAGES * 4 * CP_BK * 32) * sizeof(float);
-    auto kern = convT_patch2_kernel<PS, X4, NUI>;
+    auto kern = convT_patch2_kernel<E, TILES, PS, X4, NUI>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.blocks, pl.g.Cin / 32), dim3(256), lds, st, dy, wr, e, pl.g);
+    hipLaunchKernelGGL(kern, dim3(pl.blocks / TILES, pl.g.Cin / 32), dim3(256), lds, st, dy, wr, e, pl.g);
     return mvae_launch_status();
 }
 

@@ -27,6 +27,18 @@ def convT_fwd(B, Cin, H, Cout, tag, stats=False):
     return ('%s convT fwd' % tag, fl, lambda: K.convT2d_fwd(x, w, y, a, 2, 1), lambda: (y, a))
 
 
+def convT_stats(B, Cin, H, Cout, tag):
+    r = gb.r
+    x, w = r(B, Cin, H, H), r(Cin, Cout, 4, 4)
+    fl = 2.0 * B * Cin * H * H * Cout * 16
+    box = {}
+
+    def fn():
+        box['part'] = K.convT2d_fwd_stats(x, w, 2, 1)
+    fn()
+    return ('%s convT fwd stats' % tag, fl, fn, lambda: (box['part'],))
+
+
 def conv_dgrad(B, Cin, H, Cout, tag):
     r = gb.r
     OH = H // 2
@@ -44,7 +56,9 @@ def main():
              conv_dgrad(256, 64, 16, 128, 'enc3 64->128 16x16 B256'),
              convT_fwd(512, 64, 16, 32, 'dec3 64->32 16x16 B512'),
              convT_fwd(256, 64, 16, 32, 'dec3 64->32 16x16 B256'),
-             conv_dgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256')]
+             conv_dgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256'),
+             convT_stats(4608, 64, 16, 32, 'dec3 64->32 16x16 B4608'),
+             convT_stats(256, 64, 16, 32, 'dec3 64->32 16x16 B256')]
     print('%-40s %7s | %9s %9s  (TFLOP/s, us)  | max rel diff' % ('op', 'GFLOP', 'gather', 'patch'))
     for name, fl, fn, outs in cases:
         row, ref, worst = [], None, 0.0
