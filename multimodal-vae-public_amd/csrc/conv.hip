@@ -1653,8 +1653,8 @@ int conv_dgrad_impl(const float *dy, const float *w, float *dx, float *act, cons
         if (pp.kind) {
             EpNCHWPair ep;
             static_cast<EpNCHW &>(ep) = e;
-            if (pp.kind == 1) return launch_convt_patch2<EpNCHWPair, 1, 68, true>(pp, dy, wr, ep, st);
-            if (pp.kind == 2) return launch_convt_patch2<EpNCHWPair, 1, 148, false>(pp, dy, wr, ep, st);
+            if (pp.kind == 1) return launch_convt_patch2<EpNCHWPair, 1, 68, true, MVAE_PATCH_STAGE8 ? 8 : 0, 8>(pp, dy, wr, ep, st);
+            if (pp.kind == 2) return launch_convt_patch2<EpNCHWPair, 1, 148, false, MVAE_PATCH_STAGE7 ? 7 : 0, 11>(pp, dy, wr, ep, st);
             if (pp.kind == 3) return launch_convt_patch2<EpNCHWPair, 1, 100, true>(pp, dy, wr, ep, st);
         }
     }

@@ -13,11 +13,17 @@
 //     no registers, no ds_write); the B fragment of class (ph, pw), tap (a, b), channel c for the lane's position is the
 //     patch value at (ih' + ph - a, iw' + pw - b): ONE ds_read_b32 at a per-lane neighbour address (a neighbour outside
 //     the image points at a zero slot kept per channel), no im2col image anywhere;
-//   * the repacked weights wr[class][k = (c, a, b)][ci] stream through a 3-deep LDS ring by LDS-DMA, 16 k's per step, the
-//     two pw classes of the current ph side by side: a wave holds acc[ph][pw] -- FOUR accumulators over the whole launch,
-//     two in use per step; the three patch values of a (channel, a) feed four matrix instructions;
-//   * the epilogue is gemm_core.h's pair store (EpNCHW::put2_b: the two pw classes of an output row as float2) or the
-//     statistics-only record (EpStats), unchanged.
+//   * the repacked weights wr[class][k = (c, a, b)][ci] stream through a 3-deep LDS ring by LDS-DMA, 16 k's per step, all
+//     four classes side by side; a block is 32 rows x 64 positions, a wave = (position half, ph) holds the two pw
+//     accumulators of its ph: the three patch values of a (channel, a) feed four matrix instructions;
+//   * the patch is DOUBLE-BUFFERED in phases of 16 input channels: the next phase's pieces are issued behind the weights
+//     of the phase's first step and have three steps to land (a first version that drained the memory queue at every
+//     phase start ran the 7 x 7 maps 4 % slower than the gather launch: profiles/r06_patch_bench_v1.txt);
+//   * the epilogue is gemm_core.h's pair store (EpNCHW::put2_b: the two pw classes of an output row as float2), the
+//     statistics-only record (EpStats) -- or, for maps whose output rows are shorter than a cache line (7 x 7 -> 14 x 14:
+//     56-byte rows; a wave's pair stores are 56-byte pieces with 56-byte gaps that the OTHER ph's wave fills: 58 % partial
+//     write requests, profiles/r05_convT_l2_counters.txt), a pass through LDS: the block's 4 x 64 outputs per channel are
+//     laid out as they lie in memory and leave as 512 contiguous bytes per store instruction.
 #pragma once
 #include "gemm2.h"
 
@@ -25,6 +31,12 @@ namespace {
 
 #ifndef MVAE_CONVT_PATCH
 #define MVAE_CONVT_PATCH 1          // 0: every stride-2 dgrad-form launch stays on igemm_kernel (A/B builds)
+#endif
+#ifndef MVAE_PATCH_STAGE7
+#define MVAE_PATCH_STAGE7 0         // 1: 7 x 7 lattices: outputs through LDS, whole lines per store.  Measured x3 interleaved (profiles/r06_patch_ab.txt): FashionMNIST 2.1103 ms against 2.0945 with pair stores (2.1032 on the gather launch) -- not the partial lines: off
+#endif
+#ifndef MVAE_PATCH_STAGE8
+#define MVAE_PATCH_STAGE8 0         // 8 x 8 lattices: the same (64-byte output rows)
 #endif
 #ifndef MVAE_PATCH_MINBLOCKS
 #define MVAE_PATCH_MINBLOCKS 512
@@ -41,238 +53,15 @@ struct PatchGeo {
 
 constexpr int CP_BK = 16, CP_STAGES = 3;
 
-// E: EpNCHWPair (put2_b) or EpStats.  CI: rows (= Cin, 64 or 32).  NPOS: lattice positions per block (64 with CI = 64:
-// 2 x 2 waves; 128 with CI = 32: 1 x 4).  PS: floats per channel in the patch incl. the zero slot (PS - 1).  X4: 16-byte
-// DMA pieces.  KPH: input channels per phase.  NUI: DMA instructions per thread and phase (ceil(KPH * PS[/4] / 256)).
-template <class E, int CI, int NPOS, int PS, bool X4, int KPH, int NUI>
-__global__ __launch_bounds__(256) void convT_patch_kernel(const float *__restrict__ dy, const float *__restrict__ wr, E e,
-                                                          PatchGeo g) {
-    static_assert((CI == 64 && NPOS == 64) || (CI == 32 && NPOS == 128), "wave layouts");
-    static_assert(!X4 || PS % 4 == 0, "16-byte pieces");
-    constexpr int PSV = X4 ? PS / 4 : PS;                  // DMA units per channel
-    constexpr int PATCH_FLOATS = NUI * 256 * (X4 ? 4 : 1);  // what the DMA covers (>= KPH * PS)
-    constexpr int WT = 2 * CP_BK * CI;                      // floats per ring stage: [pw][16][CI]
-    constexpr int SPP = KPH / 4;                            // k-steps per (phase, ph)
-    constexpr int NPW = CI == 64 ? 2 : 1;                   // weight DMA instructions per wave and step
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [patch | ring of 3 weight stages | stats scratch]
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = g2_uni(t >> 6);
-    const int wi = CI == 64 ? wave >> 1 : 0, wj = CI == 64 ? wave & 1 : wave;
-    const int lrow = lane >> 5, lcol = lane & 31;
-    const int j0 = blockIdx.x * NPOS;
-    const unsigned lds0 = (unsigned)(unsigned long)(g2_lds_void *)lds;
-    const unsigned ring0 = lds0 + PATCH_FLOATS * 4;
-
-    // ---- the lane's lattice position and its 3 x 3 neighbour places in a channel's patch slab
-    const int j = j0 + wj * 32 + lcol;
-    const bool jok = j < g.J;
-    const int jj = jok ? j : 0;
-    const int n = jj / g.OHW, rem = jj - n * g.OHW;
-    const int ih2 = rem / g.W2, iw2 = rem - ih2 * g.W2;
-    const int n0 = g2_uni(j0 / g.OHW);
-    const int r0 = g2_uni((j0 - n0 * g.OHW) / g.W2);       // mode b: first lattice row of the block
-    const int pidx = g.mode_a ? (n - n0) * g.OHW + rem : (ih2 - r0 + 1) * g.W2 + iw2;
-    int nb[3][3];
-#pragma unroll
-    for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-            const bool ok = jok && ih2 + dr >= 0 && ih2 + dr < g.H2 && iw2 + dc >= 0 && iw2 + dc < g.W2;
-            nb[dr + 1][dc + 1] = ((ok ? pidx + dr * g.W2 + dc : PS - 1) + lrow * PS) * 4;      // bytes; the upper half wave takes the next channel
-        }
-    // ---- patch DMA: unit u = i * 256 + t -> (channel u / PSV, piece u % PSV) -> bytes from (image n0, first channel of the phase)
-    int pvoff[NUI];
-#pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-        const int u = i * 256 + t, c = u / PSV, q = (u - c * PSV) * (X4 ? 4 : 1);
-        int off = BUF_OOB;
-        if (c < KPH && q < g.ps_raw) {
-            if (g.mode_a) {
-                const int img = q / g.OHW, pos = q - img * g.OHW;
-                if (n0 + img < g.B) off = ((img * g.Cout + c) * g.OHW + pos) * 4;
-            } else {
-                const int row = q / g.W2, ih = r0 - 1 + row;
-                if (ih >= 0 && ih < g.H2) off = (c * g.OHW + ih * g.W2 + (q - row * g.W2)) * 4;
-            }
-        }
-        pvoff[i] = off;
-    }
-    const BufBase dyb = buf_base(dy + (size_t)n0 * g.Cout * g.OHW);
-    auto issue_patch = [&](int phase) {
-        const i32x4_t rs = g2_rsrc(dyb, (long)phase * KPH * g.OHW, 0x7fffffff);
-        asm volatile("s_nop 4" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NUI; ++i) {
-            const unsigned dst = g2_uni(lds0 + (i * 256 + wave * 64) * (X4 ? 16 : 4));
-            if (X4) g2_dma16(rs, pvoff[i], dst);
-            else g2_dma4(rs, pvoff[i], 0, dst);
-        }
-    };
-    // ---- weight DMA: stage layout [pw][16][CI], 16 bytes per thread and class half
-    const BufBase wb = buf_base(wr);
-    const int tq = CI == 64 ? t : (t & 127);
-    const int wvoff = ((tq / (CI / 4)) * g.Cin + (tq % (CI / 4)) * 4) * 4;
-    const int steps_total = (g.Cout / KPH) * 2 * SPP;
-    auto issue_w = [&](int u) {                                // flat step u = (phase, ph, ks)
-        if (u >= steps_total) return;
-        const int phase = u / (2 * SPP), r2 = u - phase * 2 * SPP, ph = r2 / SPP, ks = r2 - ph * SPP;
-        const long k0 = (long)phase * KPH * 4 + ks * CP_BK;
-        const unsigned dst = ring0 + (u % CP_STAGES) * WT * 4;
-        asm volatile("s_nop 4" ::: "memory");
-        if (CI == 64) {
-#pragma unroll
-            for (int pw = 0; pw < 2; ++pw) {
-                const i32x4_t rs = g2_rsrc(wb, ((long)(ph * 2 + pw) * g.K + k0) * g.Cin, 0x7fffffff);
-                g2_dma16(rs, wvoff, g2_uni(dst + (pw * CP_BK * CI + wave * 256) * 4));
-            }
-        } else {
-            const int pw = wave >> 1;
-            const i32x4_t rs = g2_rsrc(wb, ((long)(ph * 2 + pw) * g.K + k0) * g.Cin, 0x7fffffff);
-            g2_dma16(rs, wvoff, g2_uni(dst + wave * 256 * 4));
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int abase = (4 * lrow * CI + wi * 32 + lcol) * 4;    // bytes inside a stage: row 4 * lrow + tap, column = the lane's GEMM row
-    issue_w(0);
-    issue_w(1);
-    int u = 0;
-    const int nphase = g.Cout / KPH;
-    for (int phase = 0; phase < nphase; ++phase) {
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            // neighbour rows of this ph: tap a = 0 -> row ih' + ph, a = 1 -> row ih' + ph - 1
-            int pb[2][3];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int dc = 0; dc < 3; ++dc) pb[a][dc] = nb[ph - a + 1][dc];
-            for (int ks = 0; ks < SPP; ++ks, ++u) {
-                if (ph == 0 && ks == 0) {
-                    // a new phase: everyone is done with the old patch and every weight piece has landed
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    issue_patch(phase);
-                    issue_w(u + 2);
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                } else {
-                    // step u's weights have landed when only the pieces of step u + 1 are still in flight
-                    if (u + 1 < steps_total) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NPW) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    issue_w(u + 2);
-                }
-                const char *Ws = reinterpret_cast<const char *>(lds) + (PATCH_FLOATS + (u % CP_STAGES) * WT) * 4 + abase;
-                const char *Pc = reinterpret_cast<const char *>(lds) + (size_t)ks * 4 * PS * 4;       // the step's first channel
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const float bm1 = *reinterpret_cast<const float *>(Pc + pb[a][0] + 2 * c * PS * 4);
-                        const float b0 = *reinterpret_cast<const float *>(Pc + pb[a][1] + 2 * c * PS * 4);
-                        const float bp1 = *reinterpret_cast<const float *>(Pc + pb[a][2] + 2 * c * PS * 4);
-                        const int kr = 8 * c + 2 * a;                                               // + 4 * lrow inside abase
-                        const float a00 = *reinterpret_cast<const float *>(Ws + (kr * CI) * 4);
-                        const float a01 = *reinterpret_cast<const float *>(Ws + ((kr + 1) * CI) * 4);
-                        const float a10 = *reinterpret_cast<const float *>(Ws + (CP_BK * CI + kr * CI) * 4);
-                        const float a11 = *reinterpret_cast<const float *>(Ws + (CP_BK * CI + (kr + 1) * CI) * 4);
-                        acc[ph][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, b0, acc[ph][0], 0, 0, 0);
-                        acc[ph][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, bp1, acc[ph][1], 0, 0, 0);
-                        acc[ph][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, bm1, acc[ph][0], 0, 0, 0);
-                        acc[ph][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, b0, acc[ph][1], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- epilogue
-    if constexpr (ep_stats<E>::value) {
-        // (mean, M2) of every row over the block's 4 * NPOS values, around a shift (gemm_core.h STATK): one record per block
-        static_assert(CI == 32, "the statistics record is the 32-row layout's");
-        f32x16 st1, st2, shf;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int bits = __float_as_int(acc[0][0][r]);
-            const float lo = __int_as_float(__builtin_amdgcn_readlane(bits, 0));
-            const float hi = __int_as_float(__builtin_amdgcn_readlane(bits, 32));
-            shf[r] = lrow ? hi : lo;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float d = acc[a][b][r] - shf[r];
-                    s1 += d;
-                    s2 = fmaf(d, d, s2);
-                }
-            st1[r] = half_wave_sum(s1);
-            st2[r] = half_wave_sum(s2);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float *red = lds;                                   // [wave][32 rows][3]
-        if (lcol == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                red[(wave * 32 + row) * 3 + 0] = st1[r];
-                red[(wave * 32 + row) * 3 + 1] = st2[r];
-                red[(wave * 32 + row) * 3 + 2] = shf[r];
-            }
-        }
-        __syncthreads();
-        if (t < 32) {
-            const float nw = 128.f;                         // values per (wave, row): 32 positions x 4 classes
-            float mw[4], m2w[4], mean = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) {
-                const float *rr = red + (w2 * 32 + t) * 3;
-                const float d = rr[0] / nw;
-                mw[w2] = rr[2] + d;
-                m2w[w2] = fmaxf(rr[1] - rr[0] * d, 0.f);
-                mean += mw[w2];
-            }
-            mean /= 4.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) m2 += m2w[w2] + nw * (mw[w2] - mean) * (mw[w2] - mean);
-            if (t < e.C) {
-                float *dst = e.part + ((size_t)blockIdx.x * e.C + t) * 2;
-                dst[0] = mean;
-                dst[1] = m2;
-            }
-        }
-    } else {
-        E et = e;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            et.set_class(ph * 2);
-            et.tile(j0);
-            (void)et.col(j);
-            const int rb = __builtin_amdgcn_readfirstlane(wi * 32);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) et.put2_b(rb, r, acc[ph][0][r], acc[ph][1][r]);
-        }
-    }
-}
-
-// ---- version 2 of the storing form: 32 rows x 64 positions per block, wave = (position half, ph) with the two pw
-// accumulators of ITS ph -- the same 16 matrix instructions per wave and step, half the accumulators (112 registers: four
-// waves per SIMD), twice the blocks (the 256-image launches: 512 instead of 256), and the patch DOUBLE-BUFFERED in
-// phases of 16 input channels: the next phase's pieces are issued behind the weights of the phase's first step and have
-// three steps to land -- no drain, no exposed patch latency except the first (version 1 above drained the memory queue at
-// every phase start: 7 x 7 maps 4 % SLOWER than the gather launch, 8 x 8 / 16 x 16 maps 4-9 % faster,
-// profiles/r06_patch_bench.txt).  Rows: i0 = 32 * blockIdx.y (Cin = 64: two row halves re-read the patch).
+// Rows: i0 = 32 * blockIdx.y (Cin = 64: two row halves re-read the patch).  PS: floats per channel in the patch incl. the
+// zero slot (PS - 1); X4: 16-byte DMA pieces; NUI: patch DMA instructions per thread and phase.
 constexpr int CP2_KPH = 16, CP2_SPP = CP2_KPH / 4;
 
 // E = EpNCHWPair: one tile per block, pair stores.  E = EpStats: TILES = 2 consecutive tiles per block and one (mean, M2)
 // record over their 4 x 128 values per row -- the record mvae_bn_stats_merge expects (gemm_core.h STATK).
-template <class E, int TILES, int PS, bool X4, int NUI>
+// SW2: 0 = pair stores straight from the accumulators; else the lattice width of a whole-image (mode a) geometry whose
+// outputs pass through LDS (SROWS = lattice rows a 64-position tile can touch).
+template <class E, int TILES, int PS, bool X4, int NUI, int SW2, int SROWS>
 __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__restrict__ dy, const float *__restrict__ wr,
                                                               E e, PatchGeo g) {
     static_assert(!X4 || PS % 4 == 0, "16-byte pieces");
@@ -421,6 +210,53 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
                     st2[r] = fmaf(d, d, st2[r]);
                 }
             }
+        } else if constexpr (SW2 > 0) {
+            // ---- through LDS: S[channel][lattice row of the tile][ph][2 b + pw] -- a channel's outputs in memory order
+            // (image planes apart; the tile's lattice rows of one image are one contiguous run of 4 * SW2 floats each)
+            constexpr int RW = 4 * SW2, SP = SROWS * RW;     // floats per lattice row of outputs / per channel
+            static_assert(32 * SP <= 2 * PATCH_FLOATS + CP_STAGES * WT, "the staging image overlays the patch buffers and the ring");
+            const int a0 = r0;                               // first lattice row of the tile in image n0
+            const int jl = min(j0 + 63, g.J - 1);
+            const int nl = g2_uni(jl / g.OHW), al = g2_uni((jl - nl * g.OHW) / SW2);
+            const int rows = g2_uni((nl - n0) * g.H2 + al - a0 + 1);      // lattice rows the tile touches
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave is done with the ring and the patch
+            if (jok) {
+                const int grow = (n - n0) * g.H2 + ih2 - a0;
+                float *dstp = lds + grow * RW + ph * 2 * SW2 + 2 * iw2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                    *reinterpret_cast<float2 *>(dstp + cl * SP) = make_float2(acc[0][r], acc[1][r]);
+                }
+            }
+            __syncthreads();
+            // wave w writes channels 8 w .. 8 w + 7: a lane owns pair p of the tile's run (64 lanes = 512 contiguous bytes
+            // inside an image), geometry once per pair, reused for the eight channels
+            const int np = rows * (RW / 2);
+            const int HWo = e.HW, Wo = e.Wfull;
+            for (int p2 = lane; p2 < np; p2 += 64) {
+                const int grow = p2 / (RW / 2), within = p2 - grow * (RW / 2);
+                const int pph = within / SW2, b = within - pph * SW2;
+                const int gr = a0 + grow, img = gr / g.H2, a = gr - img * g.H2;
+                const int jq = ((n0 + img) * g.H2 + a) * SW2 + b;
+                const bool owned = jq >= j0 && jq <= jl;
+                const size_t o0 = ((size_t)(n0 + img) * e.C + i0 + wave * 8) * HWo + (2 * a + pph) * Wo + 2 * b;
+                const float *src = lds + (wave * 8) * SP + 2 * p2;
+                if (owned) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        if (i0 + wave * 8 + ch >= e.C) break;
+                        float2 v = *reinterpret_cast<const float2 *>(src + ch * SP);
+                        const size_t o = o0 + (size_t)ch * HWo;
+                        if (e.dpre) {
+                            const float2 d = *reinterpret_cast<const float2 *>(e.dpre + o);
+                            v.x *= swish_grad_(d.x); v.y *= swish_grad_(d.y);
+                        }
+                        if (e.out) *reinterpret_cast<float2 *>(e.out + o) = v;
+                        if (e.act) *reinterpret_cast<float2 *>(e.act + o) = make_float2(swishf_(v.x), swishf_(v.y));
+                    }
+                }
+            }
         } else {
             E et = e;
             et.set_class(ph * 2);
@@ -501,27 +337,12 @@ inline PatchPlan convt_patch_plan(int B, int Cout, int Cin, int OH, int OW, bool
     return pl;
 }
 
-template <class E, int CI, int NPOS, int PS, bool X4, int KPH>
-int launch_convt_patch(const PatchPlan &pl, const float *dy, const float *wr, E e, hipStream_t st) {
-    constexpr int PSV = X4 ? PS / 4 : PS;
-    constexpr int NUI = (KPH * PSV + 255) / 256;
-    constexpr size_t lds = ((size_t)NUI * 256 * (X4 ? 4 : 1) + (size_t)CP_STAGES * 2 * CP_BK * CI) * sizeof(float);
-    auto kern = convT_patch_kernel<E, CI, NPOS, PS, X4, KPH, NUI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(pl.blocks), dim3(256), lds, st, dy, wr, e, pl.g);
-    return mvae_launch_status();
-}
-
-template <class E, int TILES, int PS, bool X4>
+template <class E, int TILES, int PS, bool X4, int SW2 = 0, int SROWS = 0>
 int launch_convt_patch2(const PatchPlan &pl, const float *dy, const float *wr, const E &e, hipStream_t st) {
     constexpr int PSV = X4 ? PS / 4 : PS;
     constexpr int NUI = (CP2_KPH * PSV + 255) / 256;
     constexpr size_t lds = ((size_t)2 * NUI * 256 * (X4 ? 4 : 1) + (size_t)CP_STAGES * 4 * CP_BK * 32) * sizeof(float);
-    auto kern = convT_patch2_kernel<E, TILES, PS, X4, NUI>;
+    auto kern = convT_patch2_kernel<E, TILES, PS, X4, NUI, SW2, SROWS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -530,15 +351,5 @@ int launch_convt_patch2(const PatchPlan &pl, const float *dy, const float *wr, c
     hipLaunchKernelGGL(kern, dim3(pl.blocks / TILES, pl.g.Cin / 32), dim3(256), lds, st, dy, wr, e, pl.g);
     return mvae_launch_status();
 }
-
-#ifndef MVAE_PATCH_KPH64
-#define MVAE_PATCH_KPH64 64         // input channels per phase of the 64-row kernels (8 x 8 maps)
-#endif
-#ifndef MVAE_PATCH_KPH49
-#define MVAE_PATCH_KPH49 32         // ... 7 x 7 maps (dword pieces: 148 floats per channel)
-#endif
-#ifndef MVAE_PATCH_KPH32
-#define MVAE_PATCH_KPH32 32         // ... of the 32-row kernels (16 x 16 maps, 164 floats per channel)
-#endif
 
 }  // namespace
