@@ -3,6 +3,7 @@
 #include "gemm_core.h"
 #include "gemm2.h"
 #include "convt_patch.h"
+#include "wgrad_patch.h"
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
@@ -2132,6 +2133,21 @@ int conv_wgrad_impl(const float *dy, const float *x, float *dw, ConvGeom g, int 
                 hipLaunchKernelGGL((finish_few_kernel<EpRowMajor>), dim3((J + 255) / 256, I), dim3(256), 0, st, fs,
                                    blocks, e);
             }
+            return mvae_launch_status();
+        }
+    }
+    if (g.stride == 2 && g.pad == 1 && !MVAE_TUNE(wm) && !MVAE_TUNE(splits)) {
+        // both operands in their natural layout through LDS-DMA (wgrad_patch.h): the 8 x 8 and 16 x 16 lattices
+        WgradPatchGeo wg;
+        if (wgrad_patch_plan(g.B, g.Cout, g.Cin, g.OH, g.OW, dy, x, ws, ws_bytes, &wg)) {
+            launch_wgrad_patch(wg, dy, x, st);
+            SplitSink fs = make_sink(ws, I, J, false);
+            if (wg.splits > 64)
+                hipLaunchKernelGGL((finish_wide_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(1024), 0, st, fs, wg.splits, e);
+            else if (wg.splits > 16)         // (the 1024-thread form issues 32 loads per thread whatever the count)
+                hipLaunchKernelGGL((finish_kernel<EpRowMajor>), dim3((J + 31) / 32, I), dim3(256), 0, st, fs, wg.splits, e);
+            else
+                hipLaunchKernelGGL((finish_few_kernel<EpRowMajor>), dim3((J + 255) / 256, I), dim3(256), 0, st, fs, wg.splits, e);
             return mvae_launch_status();
         }
     }

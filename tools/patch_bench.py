@@ -48,8 +48,30 @@ def conv_dgrad(B, Cin, H, Cout, tag):
     return ('%s conv dgrad' % tag, fl, lambda: K.conv2d_dgrad(dy, w, dx, x, 2, 1), lambda: (dx,))
 
 
+def wgrad(B, Cin, H, Cout, tag, transposed):
+    """Conv2d(Cin, Cout) on H x H maps / ConvTranspose2d(Cin, Cout) on H x H maps (stride 2, pad 1)."""
+    r = gb.r
+    if transposed:
+        x, dy, dw = r(B, Cin, H, H), r(B, Cout, 2 * H, 2 * H), torch.empty(Cin, Cout, 4, 4, device='cuda')
+        fl = 2.0 * B * Cin * H * H * Cout * 16
+        return ('%s convT wgrad' % tag, fl, lambda: K.convT2d_wgrad(dy, x, dw, 2, 1), lambda: (dw,))
+    x, dy, dw = r(B, Cin, H, H), r(B, Cout, H // 2, H // 2), torch.empty(Cout, Cin, 4, 4, device='cuda')
+    fl = 2.0 * B * Cout * (H // 2) ** 2 * Cin * 16
+    return ('%s conv wgrad' % tag, fl, lambda: K.conv2d_wgrad(dy, x, dw, 2, 1), lambda: (dw,))
+
+
 def main():
-    cases = [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
+    which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if len(sys.argv) > 2:
+        os.environ['MVAE_WGRAD_PATCH_TARGET'] = sys.argv[2]
+    switch = 'MVAE_WGRAD_PATCH_OFF' if which == 'wgrad' else 'MVAE_PATCH_OFF'
+    wcases = [wgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256', False),
+              wgrad(256, 64, 16, 128, 'enc3 64->128 16x16 B256', False),
+              wgrad(512, 128, 8, 64, 'dec2 128->64 8x8 B512', True),
+              wgrad(512, 64, 16, 32, 'dec3 64->32 16x16 B512', True),
+              wgrad(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608', True),
+              wgrad(7, 64, 16, 128, 'ragged 64->128 16x16 B7', False)]
+    cases = wcases if which == 'wgrad' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
              conv_dgrad(1024, 64, 14, 128, 'fm enc2 64->128 14x14 B1024'),
              convT_fwd(512, 128, 8, 64, 'dec2 128->64 8x8 B512'),
              convT_fwd(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608'),
@@ -64,9 +86,9 @@ def main():
         row, ref, worst = [], None, 0.0
         for off in (True, False):
             if off:
-                os.environ['MVAE_PATCH_OFF'] = '1'
+                os.environ[switch] = '1'
             else:
-                os.environ.pop('MVAE_PATCH_OFF', None)
+                os.environ.pop(switch, None)
             for o in outs():
                 o.fill_(float('nan'))
             fn()
@@ -79,7 +101,7 @@ def main():
                     d = ((g - rf).abs().max() / rf.abs().max().clamp_min(1e-30)).item()
                     worst = max(worst, d if d == d else float('inf'))
             row.append(gb.timeit(fn, launches=10, replays=3))
-        os.environ.pop('MVAE_PATCH_OFF', None)
+        os.environ.pop(switch, None)
         print('%-40s %7.2f | ' % (name, fl / 1e9) + ' '.join('%6.1f %6.1f' % (fl / (ms * 1e-3) / 1e12, ms * 1e3) for ms in row) + '   | %.2e' % worst)
 
 
