@@ -15,6 +15,8 @@
 //     (bc, kh, kw) at position (a, b) is ONE ds_read_b32 at  lane part (bc, kh, kw, upper half wave) + immediate (a, b):
 //     no im2col image, no address arithmetic in the loop;
 //   * two such buffers: the DMA of chunk q + 1 flies while chunk q is multiplied; one barrier per 64 matrix instructions.
+// (The stride-1 layers on 5 x 5 <-> 8 x 8 maps were tried the same way -- two images per chunk, S by 4-byte pieces -- and ran
+// equal to 12 % slower than the implicit-GEMM launch: removed, profiles/r06_wgrad_patch_bench.txt.)
 // The reduction is cut over blocks (grid.z); the partial tiles go to the caller's scratch in the layout of gemm_core.h's
 // split launches and its finish kernels sum them in a fixed order -- deterministic, no atomics.
 #pragma once

@@ -60,6 +60,18 @@ def wgrad(B, Cin, H, Cout, tag, transposed):
     return ('%s conv wgrad' % tag, fl, lambda: K.conv2d_wgrad(dy, x, dw, 2, 1), lambda: (dw,))
 
 
+def wgrad_s1(B, Cin, Cout, tag, transposed):
+    """Conv2d(Cin, Cout, 4, 1, 0) on 8 x 8 maps / ConvTranspose2d(Cin, Cout, 4, 1, 0) on 5 x 5 maps."""
+    r = gb.r
+    if transposed:
+        x, dy, dw = r(B, Cin, 5, 5), r(B, Cout, 8, 8), torch.empty(Cin, Cout, 4, 4, device='cuda')
+        fl = 2.0 * B * Cin * 25 * Cout * 16
+        return ('%s convT wgrad' % tag, fl, lambda: K.convT2d_wgrad(dy, x, dw, 1, 0), lambda: (dw,))
+    x, dy, dw = r(B, Cin, 8, 8), r(B, Cout, 5, 5), torch.empty(Cout, Cin, 4, 4, device='cuda')
+    fl = 2.0 * B * Cout * 25 * Cin * 16
+    return ('%s conv wgrad' % tag, fl, lambda: K.conv2d_wgrad(dy, x, dw, 1, 0), lambda: (dw,))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if len(sys.argv) > 2:
@@ -70,7 +82,11 @@ def main():
               wgrad(512, 128, 8, 64, 'dec2 128->64 8x8 B512', True),
               wgrad(512, 64, 16, 32, 'dec3 64->32 16x16 B512', True),
               wgrad(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608', True),
-              wgrad(7, 64, 16, 128, 'ragged 64->128 16x16 B7', False)]
+              wgrad(7, 64, 16, 128, 'ragged 64->128 16x16 B7', False),
+              wgrad_s1(256, 128, 256, 'enc4 128->256 8x8 s1 B256', False),
+              wgrad_s1(512, 256, 128, 'dec1 256->128 5x5 s1 B512', True),
+              wgrad_s1(4608, 256, 128, 'dec1 256->128 5x5 s1 B4608', True),
+              wgrad_s1(255, 128, 256, 'enc4 128->256 8x8 s1 B255', False)]
     cases = wcases if which == 'wgrad' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
              conv_dgrad(1024, 64, 14, 128, 'fm enc2 64->128 14x14 B1024'),
              convT_fwd(512, 128, 8, 64, 'dec2 128->64 8x8 B512'),
