@@ -4,6 +4,7 @@
 #include "gemm2.h"
 #include "convt_patch.h"
 #include "wgrad_patch.h"
+#include "conv_patch.h"
 
 // k-tile depth of the gather-fed forward / dgrad forms (32 or 64; the weight-gradient loaders decode their
 // tap fields for 32)
@@ -982,6 +983,13 @@ int conv_fwd_impl(const float *x, const float *w, float *pre, float *act, const 
     e.C = g.Cout; e.HW = g.OH * g.OW; e.Wfull = g.OW; e.H2 = g.OH; e.W2 = g.OW;
     e.sy = 1; e.py = 0; e.px = 0; e.J = J; e.off = 0;
     e.lg_hw2 = g.lg_ohw; e.lg_w2 = g.lg_ow;
+    if (MVAE_CONV_PATCH && aligned16(w) && aligned16(x) && MVAE_EP_BUFFER && !MVAE_TUNE(wm)) {
+        // the input as an LDS patch, the weights as they lie in memory (conv_patch.h)
+        const ConvPatchPlan pp = conv_patch_plan(g.B, g.Cin, g.H, g.W, g.Cout, g.OH, g.OW, g.stride, g.pad);
+        if (pp.kind == 1 || pp.kind == 4) return launch_conv_patch<260>(pp, x, w, e, st);
+        if (pp.kind == 2) return launch_conv_patch<324>(pp, x, w, e, st);
+        if (pp.kind == 3) return launch_conv_patch<592>(pp, x, w, e, st);
+    }
     auto mp = [&](auto &p) { p.src = w; p.ld = K; p.R = I; p.Klen = K; };
     auto mq = [&](auto &q) { q.x = x; q.g = g; q.Mtot = J; };
     if (aligned16(w) && (size_t)g.Cin * g.H * g.W * 4 * (256 / (g.OH * g.OW) + 2) < ((size_t)1 << 31)) {

@@ -72,11 +72,39 @@ def wgrad_s1(B, Cin, Cout, tag, transposed):
     return ('%s conv wgrad' % tag, fl, lambda: K.conv2d_wgrad(dy, x, dw, 1, 0), lambda: (dw,))
 
 
+def conv_fwd(B, Cin, H, Cout, s_, p_, tag):
+    r = gb.r
+    OH = (H + 2 * p_ - 4) // s_ + 1
+    x, w = r(B, Cin, H, H), r(Cout, Cin, 4, 4)
+    y, a = torch.empty(B, Cout, OH, OH, device='cuda'), torch.empty(B, Cout, OH, OH, device='cuda')
+    fl = 2.0 * B * Cout * OH * OH * Cin * 16
+    return ('%s conv fwd' % tag, fl, lambda: K.conv2d_fwd(x, w, y, a, s_, p_), lambda: (y, a))
+
+
+def convT_dgrad(B, Cin, H, Cout, s_, p_, tag):
+    """Data gradient of ConvTranspose2d(Cin, Cout) on H x H inputs: dy [B, Cout, OH, OH] -> dx [B, Cin, H, H] (x Swish'(pre))."""
+    r = gb.r
+    OH = (H - 1) * s_ - 2 * p_ + 4
+    x, w, dy = r(B, Cin, H, H), r(Cin, Cout, 4, 4), r(B, Cout, OH, OH)
+    dx = torch.empty_like(x)
+    fl = 2.0 * B * Cin * H * H * Cout * 16
+    return ('%s convT dgrad' % tag, fl, lambda: K.convT2d_dgrad(dy, w, dx, x, s_, p_), lambda: (dx,))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if len(sys.argv) > 2:
         os.environ['MVAE_WGRAD_PATCH_TARGET'] = sys.argv[2]
-    switch = 'MVAE_WGRAD_PATCH_OFF' if which == 'wgrad' else 'MVAE_PATCH_OFF'
+    switch = {'wgrad': 'MVAE_WGRAD_PATCH_OFF', 'fwd': 'MVAE_CONV_PATCH_OFF'}.get(which, 'MVAE_PATCH_OFF')
+    fcases = [conv_fwd(256, 32, 32, 64, 2, 1, 'enc2 32->64 32x32 B256'),
+              conv_fwd(256, 64, 16, 128, 2, 1, 'enc3 64->128 16x16 B256'),
+              conv_fwd(256, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1 B256'),
+              convT_dgrad(512, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1 B512'),
+              convT_dgrad(512, 128, 8, 64, 2, 1, 'dec2 128->64 8x8 B512'),
+              convT_dgrad(512, 64, 16, 32, 2, 1, 'dec3 64->32 16x16 B512'),
+              conv_fwd(1024, 64, 14, 128, 2, 1, 'fm enc2 64->128 14x14 B1024'),
+              convT_dgrad(2048, 128, 7, 64, 2, 1, 'fm dec2 128->64 7x7 B2048'),
+              conv_fwd(37, 64, 14, 128, 2, 1, 'ragged 64->128 14x14 B37')]
     wcases = [wgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256', False),
               wgrad(256, 64, 16, 128, 'enc3 64->128 16x16 B256', False),
               wgrad(512, 128, 8, 64, 'dec2 128->64 8x8 B512', True),
@@ -87,7 +115,7 @@ def main():
               wgrad_s1(512, 256, 128, 'dec1 256->128 5x5 s1 B512', True),
               wgrad_s1(4608, 256, 128, 'dec1 256->128 5x5 s1 B4608', True),
               wgrad_s1(255, 128, 256, 'enc4 128->256 8x8 s1 B255', False)]
-    cases = wcases if which == 'wgrad' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
+    cases = wcases if which == 'wgrad' else fcases if which == 'fwd' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
              conv_dgrad(1024, 64, 14, 128, 'fm enc2 64->128 14x14 B1024'),
              convT_fwd(512, 128, 8, 64, 'dec2 128->64 8x8 B512'),
              convT_fwd(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608'),
