@@ -1412,6 +1412,12 @@ constexpr int S1_BK = MVAE_S1_BK;
 #ifndef MVAE_S1_TAPS
 #define MVAE_S1_TAPS 1          // 8x8 outputs: the col2im tap table is computed once per thread, not once per image (0: A/B builds)
 #endif
+#ifndef MVAE_S1_EPI2
+#define MVAE_S1_EPI2 1          // 5 x 5 -> 8 x 8: col2im with a zero slot, a row / column tap table and the image as an immediate (0: A/B builds)
+#endif
+#ifndef MVAE_S1_KO
+#define MVAE_S1_KO 0            // knock-out builds (tools/build_variants.sh; results are WRONG by construction): low 3 bits 1 = no global loads in
+#endif                          // the main loop, 2 = + no LDS stores / barriers, 3 = + no fragment reads; bit 3 (8) = no col2im epilogue
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
                                                           const float *dpre, ConvGeom g, int NI) {
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
@@ -1490,14 +1496,15 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        load(min(s + 1, nsteps - 1) * S1_BK);          // unconditional (the last trip re-reads its own tile): no branch
+        if ((MVAE_S1_KO & 7) < 1) load(min(s + 1, nsteps - 1) * S1_BK);    // unconditional (the last trip re-reads its own tile): no branch
         float a0[2], b0;
         a0[0] = Ps(buf)[lrow][wi * 64 + lcol]; a0[1] = Ps(buf)[lrow][wi * 64 + 32 + lcol];
         b0 = Qs(buf)[lrow][wj * 32 + lcol];
 #pragma unroll
         for (int kk = 0; kk < S1_BK / 2; ++kk) {
             float a1[2] = {0.f, 0.f}, b1 = 0.f;
-            if (kk + 1 < S1_BK / 2) {
+            if ((MVAE_S1_KO & 7) >= 3) { a1[0] = a0[0]; a1[1] = a0[1]; b1 = b0; }
+            else if (kk + 1 < S1_BK / 2) {
                 a1[0] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + lcol];
                 a1[1] = Ps(buf)[(kk + 1) * 2 + lrow][wi * 64 + 32 + lcol];
                 b1 = Qs(buf)[(kk + 1) * 2 + lrow][wj * 32 + lcol];
@@ -1508,8 +1515,19 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             __builtin_amdgcn_sched_barrier(0);
             a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
         }
-        store(buf ^ 1);
-        __syncthreads();
+        if ((MVAE_S1_KO & 7) < 2) {
+            store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (MVAE_S1_KO & 8) {           // no col2im: one (never taken) store keeps the matrix instructions alive
+        float sum = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[x][r];
+        if (sum == 12345.678f && out) out[t] = sum;
+        return;
     }
     // col2im: park the 128 (packed positions) x 64 (4 channels x 16 taps) tile in LDS and let every thread gather the
     // <= 16 taps of its output pixels (image, channel, pixel).  The reads are unconditional from clamped positions with
@@ -1522,9 +1540,48 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
             sc[row * TP + wj * 32 + lcol] = acc[x][r];
         }
+    if (MVAE_S1_EPI2 && t < 5) sc[t * 25 * TP + S1_COLS] = 0.f;     // the pad column of the first row of each 5 x 5 image: the zero its taps outside the image read
     __syncthreads();
     const int HW = g.H * g.W;
     const int per_img = 4 * HW;
+    if (MVAE_S1_EPI2 && g.H == 8 && g.W == 8 && g.OH == 5 && g.OW == 5) {
+        // 5 x 5 -> 8 x 8 (the two layers this kernel serves), NI = 5 whole images: as the path below, with what was still
+        // re-derived per image or per tap taken out (profiles/r06_celeba_sq_counters.txt: 3.7 vector instructions per matrix
+        // instruction over this kernel, 0.9 in its main loop -- the rest is here).  A tap outside the image reads the zero
+        // slot of its image instead of a clamped position times a 0 / 1 factor (no mask registers, a plain add); the tap table is built from
+        // 4 row parts + 4 column parts; the image loop is unrolled, so an image is an IMMEDIATE offset of the LDS read
+        // (25 * 65 * 4 = 6500 bytes apart) and costs no address arithmetic.  Same taps in the same order: identical sums.
+        constexpr int P5 = 25, IMG_FL = P5 * TP;
+        const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
+        int rowp[4], colp[4];
+        bool rok[4], cok[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int oh = ih - k4, ow = iw - k4;
+            rok[k4] = (unsigned)oh < 5u; cok[k4] = (unsigned)ow < 5u;
+            rowp[k4] = oh * (5 * TP) + cl * 16 + k4 * 4;
+            colp[k4] = ow * TP + k4;
+        }
+        int toff[16];
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) toff[kh * 4 + kw] = (rok[kh] && cok[kw]) ? rowp[kh] + colp[kw] : S1_COLS;
+        const int ci = ci0 + cl;
+        size_t o = ((size_t)n0 * g.Cin + ci) * 64 + (t & 63);
+        const size_t ostep = (size_t)g.Cin * 64;
+#pragma unroll
+        for (int img = 0; img < 5; ++img, o += ostep) {
+            if (n0 + img >= g.B) break;                 // block-uniform
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += sc[img * IMG_FL + toff[k]];
+            if (dpre) v *= swish_grad_(dpre[o]);
+            if (out) out[o] = v;
+            if (act) act[o] = swishf_(v);
+        }
+        return;
+    }
     if (MVAE_S1_TAPS && g.H == 8 && g.W == 8) {
         // 8 x 8 outputs (both layers that use this kernel): 4 channels x 64 pixels = the 256 threads, so a thread's
         // (channel, pixel) -- and with it the 16 tap positions and their validity -- is the same for every image of the

@@ -38,6 +38,12 @@ namespace {
 #ifndef MVAE_PATCH_STAGE8
 #define MVAE_PATCH_STAGE8 0         // 8 x 8 lattices: the same (64-byte output rows)
 #endif
+#ifndef MVAE_PATCH_CONSTGEO
+#define MVAE_PATCH_CONSTGEO 1       // the lattice of an instantiation as compile-time constants (0: run-time divisors, A/B builds)
+#endif
+#ifndef MVAE_PATCH_MINBLK
+#define MVAE_PATCH_MINBLK 4         // blocks per CU the register allocation aims at: the LDS footprint (40 KB) admits four; at 2 the
+#endif                              // statistics form took 135 registers = three.  (At 4: 128, eight dwords spilled outside the loops.)
 #ifndef MVAE_PATCH_MINBLOCKS
 #define MVAE_PATCH_MINBLOCKS 512
 #endif
@@ -62,9 +68,18 @@ constexpr int CP2_KPH = 16, CP2_SPP = CP2_KPH / 4;
 // SW2: 0 = pair stores straight from the accumulators; else the lattice width of a whole-image (mode a) geometry whose
 // outputs pass through LDS (SROWS = lattice rows a 64-position tile can touch).
 template <class E, int TILES, int PS, bool X4, int NUI, int SW2, int SROWS>
-__global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__restrict__ dy, const float *__restrict__ wr,
+__global__ __launch_bounds__(256, MVAE_PATCH_MINBLK) void convT_patch2_kernel(const float *__restrict__ dy, const float *__restrict__ wr,
                                                               E e, PatchGeo g) {
     static_assert(!X4 || PS % 4 == 0, "16-byte pieces");
+    static_assert(PS == 68 || PS == 100 || PS == 148, "the lattice is a compile-time constant of the instantiation");
+    // the lattice this instantiation serves (convt_patch_plan picks it by exactly these geometries): every division of the
+    // per-tile set-up below is by a constant -- shifts for the 8 x 8 / 16 x 16 maps.  With run-time divisors the set-up was 249
+    // vector instructions per wave and tile (656 on the 7 x 7 maps) against 256 matrix instructions of a 64 -> 32-channel tile.
+#if MVAE_PATCH_CONSTGEO
+    constexpr int W2c = PS == 68 ? 8 : PS == 100 ? 16 : 7, H2c = W2c, OHWc = W2c * W2c;
+#else
+    const int W2c = g.W2, H2c = g.H2, OHWc = g.OHW;
+#endif
     constexpr bool STATS = ep_stats<E>::value;
     constexpr int PSV = X4 ? PS / 4 : PS;
     constexpr int PATCH_FLOATS = NUI * 256 * (X4 ? 4 : 1);  // one buffer
@@ -100,12 +115,12 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
         const int j = j0 + wj * 32 + lcol;
         const bool jok = j < g.J;
         const int jj = jok ? j : 0;
-        const int n = jj / g.OHW, rem = jj - n * g.OHW;
-        const int ih2 = rem / g.W2, iw2 = rem - ih2 * g.W2;
-        const int n0 = g2_uni(j0 / g.OHW);
-        const int n1 = g2_uni((min(j0 + 63, g.J - 1)) / g.OHW);      // last image of the tile
-        const int r0 = g2_uni((j0 - n0 * g.OHW) / g.W2);
-        const int pidx = g.mode_a ? (n - n0) * g.OHW + rem : (ih2 - r0 + 1) * g.W2 + iw2;
+        const int n = jj / OHWc, rem = jj - n * OHWc;
+        const int ih2 = rem / W2c, iw2 = rem - ih2 * W2c;
+        const int n0 = g2_uni(j0 / OHWc);
+        const int n1 = g2_uni((min(j0 + 63, g.J - 1)) / OHWc);       // last image of the tile
+        const int r0 = g2_uni((j0 - n0 * OHWc) / W2c);
+        const int pidx = g.mode_a ? (n - n0) * OHWc + rem : (ih2 - r0 + 1) * W2c + iw2;
         // the wave's ph picks two of the three neighbour rows: tap a = 0 -> row ih' + ph, a = 1 -> row ih' + ph - 1
         int pb[2][3];
 #pragma unroll
@@ -113,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
 #pragma unroll
             for (int dc = -1; dc <= 1; ++dc) {
                 const int dr = ph - a;
-                const bool ok = jok && ih2 + dr >= 0 && ih2 + dr < g.H2 && iw2 + dc >= 0 && iw2 + dc < g.W2;
-                pb[a][dc + 1] = ((ok ? pidx + dr * g.W2 + dc : PS - 1) + lrow * PS) * 4;
+                const bool ok = jok && ih2 + dr >= 0 && ih2 + dr < H2c && iw2 + dc >= 0 && iw2 + dc < W2c;
+                pb[a][dc + 1] = ((ok ? pidx + dr * W2c + dc : PS - 1) + lrow * PS) * 4;
             }
         int pvoff[NUI];
 #pragma unroll
@@ -123,18 +138,18 @@ __global__ __launch_bounds__(256, 2) void convT_patch2_kernel(const float *__res
             int off = BUF_OOB;
             if (c < CP2_KPH && q < g.ps_raw) {
                 if (g.mode_a) {
-                    const int img = q / g.OHW, pos = q - img * g.OHW;
-                    if (n0 + img <= n1) off = ((img * g.Cout + c) * g.OHW + pos) * 4;      // only the images the tile touches
+                    const int img = q / OHWc, pos = q - img * OHWc;
+                    if (n0 + img <= n1) off = ((img * g.Cout + c) * OHWc + pos) * 4;       // only the images the tile touches
                 } else {
-                    const int row = q / g.W2, ih = r0 - 1 + row;
-                    if (ih >= 0 && ih < g.H2) off = (c * g.OHW + ih * g.W2 + (q - row * g.W2)) * 4;
+                    const int row = q / W2c, ih = r0 - 1 + row;
+                    if (ih >= 0 && ih < H2c) off = (c * OHWc + ih * W2c + (q - row * W2c)) * 4;
                 }
             }
             pvoff[i] = off;
         }
-        const BufBase dyb = buf_base(dy + (size_t)n0 * g.Cout * g.OHW);
+        const BufBase dyb = buf_base(dy + (size_t)n0 * g.Cout * OHWc);
         auto issue_patch = [&](int phase) {
-            const i32x4_t rs = g2_rsrc(dyb, (long)phase * CP2_KPH * g.OHW, 0x7fffffff);
+            const i32x4_t rs = g2_rsrc(dyb, (long)phase * CP2_KPH * OHWc, 0x7fffffff);
             const unsigned base = lds0 + (phase & 1) * PATCH_FLOATS * 4;
             asm volatile("s_nop 4" ::: "memory");
 #pragma unroll

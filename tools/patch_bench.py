@@ -95,7 +95,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if len(sys.argv) > 2:
         os.environ['MVAE_WGRAD_PATCH_TARGET'] = sys.argv[2]
-    switch = {'wgrad': 'MVAE_WGRAD_PATCH_OFF', 'fwd': 'MVAE_CONV_PATCH_OFF'}.get(which, 'MVAE_PATCH_OFF')
+    switch = {'wgrad': 'MVAE_WGRAD_PATCH_OFF', 'fwd': 'MVAE_CONV_PATCH_OFF', 'tail': 'MVAE_TAIL_OFF'}.get(which, 'MVAE_PATCH_OFF')
     fcases = [conv_fwd(256, 32, 32, 64, 2, 1, 'enc2 32->64 32x32 B256'),
               conv_fwd(256, 64, 16, 128, 2, 1, 'enc3 64->128 16x16 B256'),
               conv_fwd(256, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1 B256'),
@@ -105,6 +105,13 @@ def main():
               conv_fwd(1024, 64, 14, 128, 2, 1, 'fm enc2 64->128 14x14 B1024'),
               convT_dgrad(2048, 128, 7, 64, 2, 1, 'fm dec2 128->64 7x7 B2048'),
               conv_fwd(37, 64, 14, 128, 2, 1, 'ragged 64->128 14x14 B37')]
+    tcases = [convT_dgrad(512, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1 B512'),
+              conv_fwd(256, 128, 8, 256, 1, 0, 'enc4 128->256 8x8 s1 B256'),
+              conv_fwd(1024, 64, 14, 128, 2, 1, 'fm enc2 64->128 14x14 B1024'),
+              convT_dgrad(2048, 128, 7, 64, 2, 1, 'fm dec2 128->64 7x7 B2048'),
+              convT_dgrad(4608, 256, 5, 128, 1, 0, 'dec1 256->128 5x5 s1 B4608'),
+              convT_dgrad(509, 256, 5, 128, 1, 0, 'ragged dec1 256->128 5x5 s1 B509'),
+              conv_fwd(250, 128, 8, 256, 1, 0, 'ragged enc4 128->256 8x8 s1 B250')] if which == 'tail' else []
     wcases = [wgrad(256, 32, 32, 64, 'enc2 32->64 32x32 B256', False),
               wgrad(256, 64, 16, 128, 'enc3 64->128 16x16 B256', False),
               wgrad(512, 128, 8, 64, 'dec2 128->64 8x8 B512', True),
@@ -115,7 +122,7 @@ def main():
               wgrad_s1(512, 256, 128, 'dec1 256->128 5x5 s1 B512', True),
               wgrad_s1(4608, 256, 128, 'dec1 256->128 5x5 s1 B4608', True),
               wgrad_s1(255, 128, 256, 'enc4 128->256 8x8 s1 B255', False)]
-    cases = wcases if which == 'wgrad' else fcases if which == 'fwd' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
+    cases = wcases if which == 'wgrad' else fcases if which == 'fwd' else tcases if which == 'tail' else [convT_fwd(2048, 128, 7, 64, 'fm dec2 128->64 7x7 B2048'),
              conv_dgrad(1024, 64, 14, 128, 'fm enc2 64->128 14x14 B1024'),
              convT_fwd(512, 128, 8, 64, 'dec2 128->64 8x8 B512'),
              convT_fwd(4608, 128, 8, 64, 'dec2 128->64 8x8 B4608'),

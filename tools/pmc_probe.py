@@ -52,7 +52,7 @@ def show(db):
     print('%-6s %-70s ' % ('id', 'kernel') + ' '.join('%16s' % n[-16:] for n in names))
     for d in sorted(disp):
         n, vals = disp[d]
-        if not re.search(r'igemm|convT|conv_small|smallcin', n):
+        if not re.search(r'igemm|convT|conv_small|smallcin|conv_patch|wgrad_patch|gemm2', n):
             continue
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:70]
         print('%-6d %-70s ' % (d, short) + ' '.join('%16.0f' % vals.get(k, 0) for k in names))

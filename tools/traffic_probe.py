@@ -76,6 +76,7 @@ CONV_CASES = {
     ('convT2d_fwd', '512x128x8x8'): ('convT', 512, 256, 5, 128, 1, 0),
     ('convT2d_wgrad', '256x128x4x4'): ('convT', 512, 256, 5, 128, 1, 0),
     ('convT2d_fwd', '512x32x32x32'): ('convT', 512, 64, 16, 32, 2, 1),
+    ('convT2d_wgrad', '128x64x4x4'): ('convT', 512, 128, 8, 64, 2, 1),      # the patch weight gradient (wgrad_patch.h)
     ('conv2d_fwd', '256x64x16x16'): ('conv', 256, 32, 32, 64, 2, 1),
     # FashionMNIST B = 1024 (two image-decoder terms): ConvTranspose2d(128, 64) on 7x7 maps, fashionmnist/model.py:112
     ('convT2d_dgrad', '2048x128x7x7'): ('convT', 2048, 128, 7, 64, 2, 1),
@@ -123,7 +124,7 @@ def algorithmic_bytes(name, key):
 def _per_call_kib(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)).fetchall()
-    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|wgrad_direct|wgrad_batched|wgrad_smallcin|repack_dgrad', n)]
+    ours = [(n, v) for n, v in rows if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|convT_patch|conv_patch|wgrad_patch|wgrad_direct|wgrad_batched|wgrad_smallcin|repack_dgrad', n)]
     per_kernel = {}
     for n, v in ours:
         short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:90]
@@ -165,7 +166,7 @@ def counters(db):
     rows = c.execute('select kernel_name, counter_name, value from counters_collection').fetchall()
     acc = {}
     for n, cn, v in rows:
-        if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|wgrad_direct|wgrad_batched|wgrad_smallcin', n):
+        if re.search(r'igemm_kernel|gemm2s?_kernel|g2_finish|dgrad_smalln|finish|convT_s1|convT_small|conv_small|convT_patch|conv_patch|wgrad_patch|wgrad_direct|wgrad_batched|wgrad_smallcin', n):
             short = re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:100]
             acc.setdefault(short, {}).setdefault(cn, 0.0)
             acc[short][cn] += v / N_CALLS
