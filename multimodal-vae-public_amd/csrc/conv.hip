@@ -1415,6 +1415,9 @@ constexpr int S1_BK = MVAE_S1_BK;
 #ifndef MVAE_S1_EPI2
 #define MVAE_S1_EPI2 1          // 5 x 5 -> 8 x 8: col2im with a zero slot, a row / column tap table and the image as an immediate (0: A/B builds)
 #endif
+#ifndef MVAE_S1_DMA
+#define MVAE_S1_DMA 1           // operands by LDS-DMA into a 3-deep ring (dy rows as 4-byte pieces, weight rows as 16-byte pieces): no staging
+#endif                          // registers, no ds_write, two k-tiles in flight behind the one being multiplied (0: register staging, A/B builds)
 #ifndef MVAE_S1_KO
 #define MVAE_S1_KO 0            // knock-out builds (tools/build_variants.sh; results are WRONG by construction): low 3 bits 1 = no global loads in
 #endif                          // the main loop, 2 = + no LDS stores / barriers, 3 = + no fragment reads; bit 3 (8) = no col2im epilogue
@@ -1423,9 +1426,12 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
     constexpr int P_FL = S1_BK * PP, Q_FL = S1_BK * QP;
     // (col2im in two 32-column passes -- 17 KB of staging, six blocks per CU -- measured neutral against four: not kept)
-    __shared__ __attribute__((aligned(16))) float s1_lds[2 * P_FL + 2 * Q_FL > S1_ROWS * TP ? 2 * P_FL + 2 * Q_FL : S1_ROWS * TP];
+    constexpr int S1_ST = 3, ST_FL = S1_BK * (S1_ROWS + S1_COLS);       // DMA ring: stages, floats per stage (P [BK][128], then Q [BK][64])
+    constexpr int RING_FL = MVAE_S1_DMA ? S1_ST * ST_FL : 2 * P_FL + 2 * Q_FL;
+    __shared__ __attribute__((aligned(16))) float s1_lds[RING_FL > S1_ROWS * TP ? RING_FL : S1_ROWS * TP];
     auto Ps = [&](int b2) { return reinterpret_cast<float (*)[PP]>(s1_lds + b2 * P_FL); };
     auto Qs = [&](int b2) { return reinterpret_cast<float (*)[QP]>(s1_lds + 2 * P_FL + b2 * Q_FL); };
+    (void)Ps; (void)Qs;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int P = g.OH * g.OW;                      // positions per image (<= 32)
@@ -1446,6 +1452,84 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     }
     const int n0 = by * NI, ci0 = bx * 4;
     const int K = g.Cout, J = g.Cin * 16;
+#if MVAE_S1_DMA
+    // Operands by LDS-DMA (gemm2.h's machinery).  A stage holds k-tile [k0, k0 + 16): P as [k][128 packed rows] -- the 25
+    // positions of an image at one channel are contiguous in dy but start at a multiple of 100 bytes, so its pieces are
+    // 4-byte ones: one instruction fills 64 rows of one k (lane = row: image / position / validity are lane constants, the k
+    // row rides the scalar offset; pad rows and images past the batch are out-of-range pieces, which the hardware zero-fills)
+    // -- and Q as [k][64] by 16-byte pieces (a k row of the weight slab = 64 contiguous floats; one instruction = four rows).
+    // Per wave and stage: 8 + 1 instructions, no vector registers, no ds_write.  Three stages: while k-tile s is multiplied,
+    // s + 1 has landed or is landing and s + 2 is requested -- in the step the dy tile comes from HBM (118 MB at 4608 images:
+    // 1139 us in situ against 991 re-issued hot), and one tile ahead in registers did not cover that.
+    static_assert(S1_BK == 16, "four k rows of P and one 16-byte piece of Q per wave");
+    const int wv = g2_uni(wave);
+    const unsigned lds0 = (unsigned)(unsigned long)(g2_lds_void *)s1_lds;
+    int pvo[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = h * 64 + lane, img = r / P, pos = r - img * P;
+        pvo[h] = (img < NI && n0 + img < g.B) ? (img * K * P + pos) * 4 : BUF_OOB;
+    }
+    const int qf = wv * 64 + lane;
+    const int qvo = ((qf >> 4) * J + (qf & 15) * 4) * 4;
+    const BufBase pblk = buf_base(dy + (size_t)n0 * K * P);
+    const BufBase qblk = buf_base(w + (size_t)ci0 * 16);
+    auto issue = [&](int s2, int stage) {
+        const int k0 = s2 * S1_BK;
+        const i32x4_t prs = g2_rsrc(pblk, 0, 0x7fffffff);
+        const i32x4_t qrs = g2_rsrc(qblk, (long)k0 * J, 0x7fffffff);
+        asm volatile("s_nop 4" ::: "memory");
+        const unsigned base = lds0 + (unsigned)(stage * ST_FL) * 4u;
+#pragma unroll
+        for (int kr = 0; kr < 4; ++kr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                g2_dma4(prs, pvo[h], g2_uni((k0 + 4 * wv + kr) * P * 4), g2_uni(base + (unsigned)(((4 * wv + kr) * S1_ROWS + h * 64) * 4)));
+        g2_dma16(qrs, qvo, g2_uni(base + (unsigned)((S1_BK * S1_ROWS + wv * 256) * 4)));
+    };
+    constexpr int S1_NPW = 9;                       // DMA instructions per wave and stage
+    f32x16 acc[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int nsteps = K / S1_BK;                   // K % S1_BK == 0: launch condition
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    int st_c = 0, st_i = 2;
+    for (int s = 0; s < nsteps; ++s) {
+        // k-tile s has landed (the younger one may stay in flight), and every wave is done with the stage the next issue fills
+        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(S1_NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 2 < nsteps) issue(s + 2, st_i);
+        st_i = st_i == S1_ST - 1 ? 0 : st_i + 1;
+        const float *Pst = s1_lds + st_c * ST_FL, *Qst = Pst + S1_BK * S1_ROWS;
+        st_c = st_c == S1_ST - 1 ? 0 : st_c + 1;
+        float a0[2], b0;
+        // (a bank swizzle of the odd k rows -- the two half wavefronts of a fragment read on disjoint bank halves -- measured
+        //  -0.8 % at 4608 images, +5 % on the 256-image data gradient, the steps equal: not kept)
+        const int pc0 = lrow * S1_ROWS + wi * 64 + lcol, pc1 = pc0 + 32;
+        const int qc = lrow * S1_COLS + wj * 32 + lcol;
+        a0[0] = Pst[pc0]; a0[1] = Pst[pc1];
+        b0 = Qst[qc];
+#pragma unroll
+        for (int kk = 0; kk < S1_BK / 2; ++kk) {
+            float a1[2] = {0.f, 0.f}, b1 = 0.f;
+            if (kk + 1 < S1_BK / 2) {
+                a1[0] = Pst[(kk + 1) * 2 * S1_ROWS + pc0];
+                a1[1] = Pst[(kk + 1) * 2 * S1_ROWS + pc1];
+                b1 = Qst[(kk + 1) * 2 * S1_COLS + qc];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
+        }
+    }
+    __syncthreads();                                // every wave is done with the ring: the col2im tile takes its place
+#else
     // P loader: lanes along the packed row axis r = image * P + position, 2 k rows per pass.  Buffer loads
     // (gemm_core.h): the lane part of the address -- image, position, k parity -- is a constant voffset (BUF_OOB
     // for the 3 pad rows / images past the batch: zero fill), the k-step part rides the scalar soffset; nothing
@@ -1520,6 +1604,7 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             __syncthreads();
         }
     }
+#endif
     if (MVAE_S1_KO & 8) {           // no col2im: one (never taken) store keeps the matrix instructions alive
         float sum = 0.f;
 #pragma unroll
