@@ -1418,15 +1418,25 @@ constexpr int S1_BK = MVAE_S1_BK;
 #ifndef MVAE_S1_DMA
 #define MVAE_S1_DMA 1           // operands by LDS-DMA into a 3-deep ring (dy rows as 4-byte pieces, weight rows as 16-byte pieces): no staging
 #endif                          // registers, no ds_write, two k-tiles in flight behind the one being multiplied (0: register staging, A/B builds)
+#ifndef MVAE_S1_WIDE_MIN
+#define MVAE_S1_WIDE_MIN 6144   // blocks (of 128 columns) from which a launch takes the wide form of convT_s1_kernel; 0: never (A/B builds)
+#endif
 #ifndef MVAE_S1_KO
 #define MVAE_S1_KO 0            // knock-out builds (tools/build_variants.sh; results are WRONG by construction): low 3 bits 1 = no global loads in
 #endif                          // the main loop, 2 = + no LDS stores / barriers, 3 = + no fragment reads; bit 3 (8) = no col2im epilogue
+// CW: 64-column blocks (4 channels x 16 taps) per block.  CW = 2 (DMA form only): 128 x 128 block tiles, 64 x 64 per wave -- every
+// fragment read feeds two matrix instructions, a barrier every 32 of them, half the dy pieces per matrix instruction; the col2im
+// runs once per column block through the same 33-KB tile.  48 KB of ring: three blocks per CU.  The host picks it for launches
+// with enough blocks (conv_dgrad_s1).
+template <int CW>
 __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const float *w, float *out, float *act,
                                                           const float *dpre, ConvGeom g, int NI) {
+    static_assert(CW == 1 || (CW == 2 && MVAE_S1_DMA), "the wide form exists on the DMA ring only");
     constexpr int PP = S1_ROWS + LPAD, QP = S1_COLS + LPAD, TP = S1_COLS + 1;
     constexpr int P_FL = S1_BK * PP, Q_FL = S1_BK * QP;
+    constexpr int COLS = S1_COLS * CW;
     // (col2im in two 32-column passes -- 17 KB of staging, six blocks per CU -- measured neutral against four: not kept)
-    constexpr int S1_ST = 3, ST_FL = S1_BK * (S1_ROWS + S1_COLS);       // DMA ring: stages, floats per stage (P [BK][128], then Q [BK][64])
+    constexpr int S1_ST = 3, ST_FL = S1_BK * (S1_ROWS + COLS);          // DMA ring: stages, floats per stage (P [BK][128], then Q [BK][COLS])
     constexpr int RING_FL = MVAE_S1_DMA ? S1_ST * ST_FL : 2 * P_FL + 2 * Q_FL;
     __shared__ __attribute__((aligned(16))) float s1_lds[RING_FL > S1_ROWS * TP ? RING_FL : S1_ROWS * TP];
     auto Ps = [&](int b2) { return reinterpret_cast<float (*)[PP]>(s1_lds + b2 * P_FL); };
@@ -1450,7 +1460,7 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
         by = (int)(xcd + 8u * grp);
         if (by * NI >= g.B) return;
     }
-    const int n0 = by * NI, ci0 = bx * 4;
+    const int n0 = by * NI, ci0 = bx * 4 * CW;
     const int K = g.Cout, J = g.Cin * 16;
 #if MVAE_S1_DMA
     // Operands by LDS-DMA (gemm2.h's machinery).  A stage holds k-tile [k0, k0 + 16): P as [k][128 packed rows] -- the 25
@@ -1470,8 +1480,12 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
         const int r = h * 64 + lane, img = r / P, pos = r - img * P;
         pvo[h] = (img < NI && n0 + img < g.B) ? (img * K * P + pos) * 4 : BUF_OOB;
     }
-    const int qf = wv * 64 + lane;
-    const int qvo = ((qf >> 4) * J + (qf & 15) * 4) * 4;
+    int qvo[CW];                                    // 16-byte piece f = wave * 64 + lane + 256 u of a stage's [16][COLS] weight image
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+        const int qf = wv * 64 + lane + 256 * u;
+        qvo[u] = ((qf / (COLS / 4)) * J + (qf % (COLS / 4)) * 4) * 4;
+    }
     const BufBase pblk = buf_base(dy + (size_t)n0 * K * P);
     const BufBase qblk = buf_base(w + (size_t)ci0 * 16);
     auto issue = [&](int s2, int stage) {
@@ -1485,14 +1499,18 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 g2_dma4(prs, pvo[h], g2_uni((k0 + 4 * wv + kr) * P * 4), g2_uni(base + (unsigned)(((4 * wv + kr) * S1_ROWS + h * 64) * 4)));
-        g2_dma16(qrs, qvo, g2_uni(base + (unsigned)((S1_BK * S1_ROWS + wv * 256) * 4)));
+#pragma unroll
+        for (int u = 0; u < CW; ++u)
+            g2_dma16(qrs, qvo[u], g2_uni(base + (unsigned)((S1_BK * S1_ROWS + wv * 256 + 1024 * u) * 4)));
     };
-    constexpr int S1_NPW = 9;                       // DMA instructions per wave and stage
-    f32x16 acc[2];
+    constexpr int S1_NPW = 8 + CW;                  // DMA instructions per wave and stage
+    f32x16 acc[CW][2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int y = 0; y < CW; ++y)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][x][r] = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
     const int nsteps = K / S1_BK;                   // K % S1_BK == 0: launch condition
     issue(0, 0);
@@ -1506,26 +1524,35 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
         st_i = st_i == S1_ST - 1 ? 0 : st_i + 1;
         const float *Pst = s1_lds + st_c * ST_FL, *Qst = Pst + S1_BK * S1_ROWS;
         st_c = st_c == S1_ST - 1 ? 0 : st_c + 1;
-        float a0[2], b0;
+        float a0[2], b0[CW];
         // (a bank swizzle of the odd k rows -- the two half wavefronts of a fragment read on disjoint bank halves -- measured
         //  -0.8 % at 4608 images, +5 % on the 256-image data gradient, the steps equal: not kept)
         const int pc0 = lrow * S1_ROWS + wi * 64 + lcol, pc1 = pc0 + 32;
-        const int qc = lrow * S1_COLS + wj * 32 + lcol;
+        const int qc = lrow * COLS + wj * 32 + lcol;        // column block y of this wave: + 64 y
         a0[0] = Pst[pc0]; a0[1] = Pst[pc1];
-        b0 = Qst[qc];
+#pragma unroll
+        for (int y = 0; y < CW; ++y) b0[y] = Qst[qc + 64 * y];
 #pragma unroll
         for (int kk = 0; kk < S1_BK / 2; ++kk) {
-            float a1[2] = {0.f, 0.f}, b1 = 0.f;
+            float a1[2] = {0.f, 0.f}, b1[CW];
+#pragma unroll
+            for (int y = 0; y < CW; ++y) b1[y] = 0.f;
             if (kk + 1 < S1_BK / 2) {
                 a1[0] = Pst[(kk + 1) * 2 * S1_ROWS + pc0];
                 a1[1] = Pst[(kk + 1) * 2 * S1_ROWS + pc1];
-                b1 = Qst[(kk + 1) * 2 * S1_COLS + qc];
+#pragma unroll
+                for (int y = 0; y < CW; ++y) b1[y] = Qst[(kk + 1) * 2 * COLS + qc + 64 * y];
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int y = 0; y < CW; ++y) {
+                acc[y][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[y], acc[y][0], 0, 0, 0);
+                acc[y][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[y], acc[y][1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
+            a0[0] = a1[0]; a0[1] = a1[1];
+#pragma unroll
+            for (int y = 0; y < CW; ++y) b0[y] = b1[y];
         }
     }
     __syncthreads();                                // every wave is done with the ring: the col2im tile takes its place
@@ -1568,11 +1595,11 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
             *reinterpret_cast<float4 *>(&Qs(buf)[f >> 4][(f & 15) * 4]) = qr[v];
         }
     };
-    f32x16 acc[2];
+    f32x16 acc[1][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[0][x][r] = 0.f;
     const int lrow = lane >> 5, lcol = lane & 31;
     const int nsteps = (K + S1_BK - 1) / S1_BK;
     load(0);
@@ -1594,8 +1621,8 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
                 b1 = Qs(buf)[(kk + 1) * 2 + lrow][wj * 32 + lcol];
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0, acc[0][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a0[0] = a1[0]; a0[1] = a1[1]; b0 = b1;
         }
@@ -1608,130 +1635,139 @@ __global__ __launch_bounds__(256, 2) void convT_s1_kernel(const float *dy, const
     if (MVAE_S1_KO & 8) {           // no col2im: one (never taken) store keeps the matrix instructions alive
         float sum = 0.f;
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int y = 0; y < CW; ++y)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[x][r];
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[y][x][r];
         if (sum == 12345.678f && out) out[t] = sum;
         return;
     }
-    // col2im: park the 128 (packed positions) x 64 (4 channels x 16 taps) tile in LDS and let every thread gather the
-    // <= 16 taps of its output pixels (image, channel, pixel).  The reads are unconditional from clamped positions with
-    // a 0/1 factor (16 LDS reads in flight; a branch per tap made every read wait for the one before it).
-    float *sc = s1_lds;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-            sc[row * TP + wj * 32 + lcol] = acc[x][r];
+    auto col2im = [&](const f32x16 (&accy)[2], const int cib) {
+        // col2im: park the 128 (packed positions) x 64 (4 channels x 16 taps) tile in LDS and let every thread gather the
+        // <= 16 taps of its output pixels (image, channel, pixel).  The reads are unconditional from clamped positions with
+        // a 0/1 factor (16 LDS reads in flight; a branch per tap made every read wait for the one before it).
+        float *sc = s1_lds;
+    #pragma unroll
+        for (int x = 0; x < 2; ++x)
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                sc[row * TP + wj * 32 + lcol] = accy[x][r];
+            }
+        if (MVAE_S1_EPI2 && t < 5) sc[t * 25 * TP + S1_COLS] = 0.f;     // the pad column of the first row of each 5 x 5 image: the zero its taps outside the image read
+        __syncthreads();
+        const int HW = g.H * g.W;
+        const int per_img = 4 * HW;
+        if (MVAE_S1_EPI2 && g.H == 8 && g.W == 8 && g.OH == 5 && g.OW == 5) {
+            // 5 x 5 -> 8 x 8 (the two layers this kernel serves), NI = 5 whole images: as the path below, with what was still
+            // re-derived per image or per tap taken out (profiles/r06_celeba_sq_counters.txt: 3.7 vector instructions per matrix
+            // instruction over this kernel, 0.9 in its main loop -- the rest is here).  A tap outside the image reads the zero
+            // slot of its image instead of a clamped position times a 0 / 1 factor (no mask registers, a plain add); the tap table is built from
+            // 4 row parts + 4 column parts; the image loop is unrolled, so an image is an IMMEDIATE offset of the LDS read
+            // (25 * 65 * 4 = 6500 bytes apart) and costs no address arithmetic.  Same taps in the same order: identical sums.
+            constexpr int P5 = 25, IMG_FL = P5 * TP;
+            const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
+            int rowp[4], colp[4];
+            bool rok[4], cok[4];
+    #pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int oh = ih - k4, ow = iw - k4;
+                rok[k4] = (unsigned)oh < 5u; cok[k4] = (unsigned)ow < 5u;
+                rowp[k4] = oh * (5 * TP) + cl * 16 + k4 * 4;
+                colp[k4] = ow * TP + k4;
+            }
+            int toff[16];
+    #pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+    #pragma unroll
+                for (int kw = 0; kw < 4; ++kw) toff[kh * 4 + kw] = (rok[kh] && cok[kw]) ? rowp[kh] + colp[kw] : S1_COLS;
+            const int ci = cib + cl;
+            size_t o = ((size_t)n0 * g.Cin + ci) * 64 + (t & 63);
+            const size_t ostep = (size_t)g.Cin * 64;
+    #pragma unroll
+            for (int img = 0; img < 5; ++img, o += ostep) {
+                if (n0 + img >= g.B) break;                 // block-uniform
+                float v = 0.f;
+    #pragma unroll
+                for (int k = 0; k < 16; ++k) v += sc[img * IMG_FL + toff[k]];
+                if (dpre) v *= swish_grad_(dpre[o]);
+                if (out) out[o] = v;
+                if (act) act[o] = swishf_(v);
+            }
+            return;
         }
-    if (MVAE_S1_EPI2 && t < 5) sc[t * 25 * TP + S1_COLS] = 0.f;     // the pad column of the first row of each 5 x 5 image: the zero its taps outside the image read
-    __syncthreads();
-    const int HW = g.H * g.W;
-    const int per_img = 4 * HW;
-    if (MVAE_S1_EPI2 && g.H == 8 && g.W == 8 && g.OH == 5 && g.OW == 5) {
-        // 5 x 5 -> 8 x 8 (the two layers this kernel serves), NI = 5 whole images: as the path below, with what was still
-        // re-derived per image or per tap taken out (profiles/r06_celeba_sq_counters.txt: 3.7 vector instructions per matrix
-        // instruction over this kernel, 0.9 in its main loop -- the rest is here).  A tap outside the image reads the zero
-        // slot of its image instead of a clamped position times a 0 / 1 factor (no mask registers, a plain add); the tap table is built from
-        // 4 row parts + 4 column parts; the image loop is unrolled, so an image is an IMMEDIATE offset of the LDS read
-        // (25 * 65 * 4 = 6500 bytes apart) and costs no address arithmetic.  Same taps in the same order: identical sums.
-        constexpr int P5 = 25, IMG_FL = P5 * TP;
-        const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
-        int rowp[4], colp[4];
-        bool rok[4], cok[4];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int oh = ih - k4, ow = iw - k4;
-            rok[k4] = (unsigned)oh < 5u; cok[k4] = (unsigned)ow < 5u;
-            rowp[k4] = oh * (5 * TP) + cl * 16 + k4 * 4;
-            colp[k4] = ow * TP + k4;
+        if (MVAE_S1_TAPS && g.H == 8 && g.W == 8) {
+            // 8 x 8 outputs (both layers that use this kernel): 4 channels x 64 pixels = the 256 threads, so a thread's
+            // (channel, pixel) -- and with it the 16 tap positions and their validity -- is the same for every image of the
+            // block: computed ONCE; per image a tap is one address add, one LDS read, one FMA.  On fp32 MFMA the vector
+            // instructions of this epilogue are matrix time taken from the co-resident blocks (profiles/r04_celeba_sq_counters.txt:
+            // 5.4 VALU per MFMA instruction over the whole kernel, about half of them here, re-derived per image).
+            const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
+            int toff[16];
+            float tmask[16];
+    #pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oh = ih - kh;
+                const bool okh = oh >= 0 && oh < g.OH;
+                const int ohc = min(max(oh, 0), g.OH - 1);
+    #pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ow = iw - kw;
+                    const bool ok = okh && ow >= 0 && ow < g.OW;
+                    const int owc = min(max(ow, 0), g.OW - 1);
+                    toff[kh * 4 + kw] = (ohc * g.OW + owc) * TP + cl * 16 + kh * 4 + kw;
+                    tmask[kh * 4 + kw] = ok ? 1.f : 0.f;
+                }
+            }
+            const int ci = cib + cl, img_fl = P * TP;
+            for (int img = 0; img < NI; ++img) {
+                const int n = n0 + img;
+                if (n >= g.B) break;                        // block-uniform
+                const float *base = sc + img * img_fl;
+                float v = 0.f;
+    #pragma unroll
+                for (int k = 0; k < 16; ++k) v += tmask[k] * base[toff[k]];
+                const size_t o = ((size_t)n * g.Cin + ci) * HW + (t & 63);
+                if (dpre) v *= swish_grad_(dpre[o]);
+                if (out) out[o] = v;
+                if (act) act[o] = swishf_(v);
+            }
+            return;
         }
-        int toff[16];
-#pragma unroll
-        for (int kh = 0; kh < 4; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) toff[kh * 4 + kw] = (rok[kh] && cok[kw]) ? rowp[kh] + colp[kw] : S1_COLS;
-        const int ci = ci0 + cl;
-        size_t o = ((size_t)n0 * g.Cin + ci) * 64 + (t & 63);
-        const size_t ostep = (size_t)g.Cin * 64;
-#pragma unroll
-        for (int img = 0; img < 5; ++img, o += ostep) {
-            if (n0 + img >= g.B) break;                 // block-uniform
+        for (int idx = t; idx < NI * per_img; idx += 256) {
+            const int img = idx / per_img;
+            const int rem = idx - img * per_img;
+            const int cl = rem / HW;
+            const int px = rem - cl * HW;
+            const int ih = px / g.W, iw = px - ih * g.W;
+            const int n = n0 + img, ci = cib + cl;
+            if (n >= g.B || ci >= g.Cin) continue;
+            const float *base = sc + (img * P) * TP + cl * 16;
             float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v += sc[img * IMG_FL + toff[k]];
+    #pragma unroll
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oh = ih - kh;
+                const bool okh = oh >= 0 && oh < g.OH;
+                const int ohc = min(max(oh, 0), g.OH - 1);
+    #pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ow = iw - kw;
+                    const bool ok = okh && ow >= 0 && ow < g.OW;
+                    const int owc = min(max(ow, 0), g.OW - 1);
+                    v += (ok ? 1.f : 0.f) * base[(ohc * g.OW + owc) * TP + kh * 4 + kw];
+                }
+            }
+            const size_t o = ((size_t)n * g.Cin + ci) * HW + ih * g.W + iw;
             if (dpre) v *= swish_grad_(dpre[o]);
             if (out) out[o] = v;
             if (act) act[o] = swishf_(v);
         }
-        return;
-    }
-    if (MVAE_S1_TAPS && g.H == 8 && g.W == 8) {
-        // 8 x 8 outputs (both layers that use this kernel): 4 channels x 64 pixels = the 256 threads, so a thread's
-        // (channel, pixel) -- and with it the 16 tap positions and their validity -- is the same for every image of the
-        // block: computed ONCE; per image a tap is one address add, one LDS read, one FMA.  On fp32 MFMA the vector
-        // instructions of this epilogue are matrix time taken from the co-resident blocks (profiles/r04_celeba_sq_counters.txt:
-        // 5.4 VALU per MFMA instruction over the whole kernel, about half of them here, re-derived per image).
-        const int cl = (t >> 6) & 3, ih = (t >> 3) & 7, iw = t & 7;
-        int toff[16];
-        float tmask[16];
+    };
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int oh = ih - kh;
-            const bool okh = oh >= 0 && oh < g.OH;
-            const int ohc = min(max(oh, 0), g.OH - 1);
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int ow = iw - kw;
-                const bool ok = okh && ow >= 0 && ow < g.OW;
-                const int owc = min(max(ow, 0), g.OW - 1);
-                toff[kh * 4 + kw] = (ohc * g.OW + owc) * TP + cl * 16 + kh * 4 + kw;
-                tmask[kh * 4 + kw] = ok ? 1.f : 0.f;
-            }
-        }
-        const int ci = ci0 + cl, img_fl = P * TP;
-        for (int img = 0; img < NI; ++img) {
-            const int n = n0 + img;
-            if (n >= g.B) break;                        // block-uniform
-            const float *base = sc + img * img_fl;
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v += tmask[k] * base[toff[k]];
-            const size_t o = ((size_t)n * g.Cin + ci) * HW + (t & 63);
-            if (dpre) v *= swish_grad_(dpre[o]);
-            if (out) out[o] = v;
-            if (act) act[o] = swishf_(v);
-        }
-        return;
-    }
-    for (int idx = t; idx < NI * per_img; idx += 256) {
-        const int img = idx / per_img;
-        const int rem = idx - img * per_img;
-        const int cl = rem / HW;
-        const int px = rem - cl * HW;
-        const int ih = px / g.W, iw = px - ih * g.W;
-        const int n = n0 + img, ci = ci0 + cl;
-        if (n >= g.B || ci >= g.Cin) continue;
-        const float *base = sc + (img * P) * TP + cl * 16;
-        float v = 0.f;
-#pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int oh = ih - kh;
-            const bool okh = oh >= 0 && oh < g.OH;
-            const int ohc = min(max(oh, 0), g.OH - 1);
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int ow = iw - kw;
-                const bool ok = okh && ow >= 0 && ow < g.OW;
-                const int owc = min(max(ow, 0), g.OW - 1);
-                v += (ok ? 1.f : 0.f) * base[(ohc * g.OW + owc) * TP + kh * 4 + kw];
-            }
-        }
-        const size_t o = ((size_t)n * g.Cin + ci) * HW + ih * g.W + iw;
-        if (dpre) v *= swish_grad_(dpre[o]);
-        if (out) out[o] = v;
-        if (act) act[o] = swishf_(v);
+    for (int y = 0; y < CW; ++y) {
+        if (y) __syncthreads();                     // the previous column block's readers are done with the tile
+        col2im(acc[y], ci0 + 4 * y);
     }
 }
 
@@ -1745,7 +1781,15 @@ inline int conv_dgrad_s1(const float *dy, const float *w, float *dx, float *act,
     const int NI = S1_ROWS / (g.OH * g.OW);         // whole images per block
     dim3 grid(g.Cin / 4, (g.B + NI - 1) / NI);
     if (MVAE_S1_XCD) grid.y = (grid.y + 7) / 8 * 8;   // XCD-local image groups (see the kernel)
-    hipLaunchKernelGGL(convT_s1_kernel, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g, NI);
+#if MVAE_S1_DMA
+    // 128-column blocks (three per CU) where the launch still has MVAE_S1_WIDE_MIN of them: the 4608-image passes of celeba19
+    if (MVAE_S1_WIDE_MIN > 0 && g.Cin % 8 == 0 && (long)(g.Cin / 8) * grid.y >= MVAE_S1_WIDE_MIN) {
+        grid.x = g.Cin / 8;
+        hipLaunchKernelGGL(convT_s1_kernel<2>, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g, NI);
+        return mvae_launch_status();
+    }
+#endif
+    hipLaunchKernelGGL(convT_s1_kernel<1>, grid, dim3(256), 0, st, dy, w, dx, act, dpre, g, NI);
     return mvae_launch_status();
 }
 
