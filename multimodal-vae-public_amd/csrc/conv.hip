@@ -1305,6 +1305,124 @@ __global__ __launch_bounds__(256) void convT_small3_kernel(const float *__restri
     }
 }
 
+#ifndef MVAE_SMALL3_DMA
+#define MVAE_SMALL3_DMA 1         // convT_small3's staging by LDS-DMA into a 3-deep ring (0: registers + ds_write, A/B builds)
+#endif
+// The same kernel with the zero-bordered channel images filled by LDS-DMA (gemm2.h's machinery): a channel image is NQ pieces of 64
+// consecutive LDS floats, a piece = one `buffer_load_dword ... lds` whose lane l fetches the input element that belongs at float
+// 64 q + l of the image -- or nothing: a border, a row outside the map, an image past the batch or the tail of the padded image is
+// an out-of-range source, and the hardware writes the zero (no fill loop, no dummy slot logic).  Wave w owns pieces w, w + 4, ...
+// (QPW of them: their source offsets are lane constants, the channel rides the scalar offset).  With one output channel the
+// register form spent three quarters of its instructions on staging (32 loads + 32 ds_write + 96 address / select operations per
+// trip against 64 packed multiply-adds); here a trip issues QPW x D pieces per wave and nothing else.  Three stages of D channels.
+template <int C, int D, int QPW>
+__global__ __launch_bounds__(256) void convT_small3d_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                            float *__restrict__ out, float *__restrict__ act,
+                                                            const float *__restrict__ dpre, ConvGeom g, Small3Geo sg) {
+    extern __shared__ __attribute__((aligned(16))) float s3_lds[];      // [3][D][chs] + 4 x 64 floats nobody reads
+    constexpr int ST = 3, QW = QPW * D;
+    static_assert(2 * QW <= 63, "vmcnt");
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = g2_uni(t >> 6);
+    const int OH = g.OH, OW = g.OW, OW2 = OW >> 1, PITCH = OW + 2, plane = OH * OW;
+    const int n0 = blockIdx.x * sg.NI, a0 = blockIdx.y * sg.R;
+    const int nq = (sg.ch_stride + 63) >> 6, chs = nq * 64, stage_fl = D * chs;
+    const unsigned lds0 = (unsigned)(unsigned long)(g2_lds_void *)s3_lds;
+    const unsigned sink = lds0 + (unsigned)((ST * stage_fl + wv * 64) * 4);
+    int vo[QPW];
+    const int per_img_l = (sg.R + 2) * PITCH;
+#pragma unroll
+    for (int u = 0; u < QPW; ++u) {
+        const int p = (wv + 4 * u) * 64 + lane;
+        const int i = p / per_img_l, rem = p - i * per_img_l, rr = rem / PITCH, cc = rem - rr * PITCH - 1;
+        const int row = a0 - 1 + rr;
+        const bool ok = p < sg.ch_stride && cc >= 0 && cc < OW && row >= 0 && row < OH && n0 + i < g.B;
+        vo[u] = ok ? ((i * g.Cout * OH + row) * OW + cc) * 4 : BUF_OOB;
+    }
+    const BufBase bb = buf_base(dy + (size_t)n0 * g.Cout * plane);
+    auto issue = [&](int kb, int stage) {
+        const i32x4_t rs = g2_rsrc(bb, 0, 0x7fffffff);
+        asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int so = g2_uni((kb * D + d) * plane * 4);
+#pragma unroll
+            for (int u = 0; u < QPW; ++u) {
+                const int q = wv + 4 * u;                       // wave-uniform
+                const bool real = q < nq;
+                g2_dma4(rs, real ? vo[u] : BUF_OOB, so, g2_uni(real ? lds0 + (unsigned)((stage * stage_fl + d * chs + q * 64) * 4) : sink));
+            }
+        }
+    };
+    const int per_band = sg.R * OW2;
+    const int ti = t / per_band, trem = t - ti * per_band, al = trem / OW2, b0 = (trem - al * OW2) * 2;
+    const int n = n0 + ti, a = a0 + al;
+    const bool live = ti < sg.NI && n < g.B && a < OH;
+    const int rd = live ? (ti * (sg.R + 2) + al) * PITCH + b0 : 0;      // neighbourhood corner (row a - 1, column b0 - 1)
+    float acc[C][2][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q >> 2][q & 3] = 0.f;
+    const int nb = g.Cout / D;                      // host: Cout % D == 0
+    issue(0, 0);
+    if (nb > 1) issue(1, 1);
+    int st_c = 0, st_i = 2;
+#pragma unroll 1
+    for (int kb = 0; kb < nb; ++kb) {
+        if (kb + 1 < nb) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(QW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kb + 2 < nb) issue(kb + 2, st_i);
+        st_i = st_i == ST - 1 ? 0 : st_i + 1;
+        const float *cur = s3_lds + st_c * stage_fl;
+        st_c = st_c == ST - 1 ? 0 : st_c + 1;
+#pragma unroll 2
+        for (int d = 0; d < D; ++d) {
+            const float *img = cur + d * chs + rd;
+            float e[3][4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(img + r * PITCH);
+                const float2 hi = *reinterpret_cast<const float2 *>(img + r * PITCH + 2);
+                e[r][0] = lo.x; e[r][1] = lo.y; e[r][2] = hi.x; e[r][3] = hi.y;
+            }
+            const float *wc = w + (size_t)(kb * D + d) * C * 16;      // block-uniform
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float *wp = wc + c * 16;      // [kh][kw]
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) {
+                    const int q = pos;
+                    auto mac4 = [](float acc0, float w0, float x0, float w1, float x1, float w2, float x2, float w3, float x3) {
+                        return fmaf(w3, x3, fmaf(w2, x2, fmaf(w1, x1, fmaf(w0, x0, acc0))));
+                    };
+                    // the tap <-> neighbour table of convT_small3_kernel: the same products in the same order
+                    acc[c][0][2 * pos] = mac4(acc[c][0][2 * pos], wp[5], e[1][q + 1], wp[7], e[1][q], wp[13], e[0][q + 1], wp[15], e[0][q]);
+                    acc[c][0][2 * pos + 1] = mac4(acc[c][0][2 * pos + 1], wp[4], e[1][q + 2], wp[6], e[1][q + 1], wp[12], e[0][q + 2], wp[14], e[0][q + 1]);
+                    acc[c][1][2 * pos] = mac4(acc[c][1][2 * pos], wp[1], e[2][q + 1], wp[3], e[2][q], wp[9], e[1][q + 1], wp[11], e[1][q]);
+                    acc[c][1][2 * pos + 1] = mac4(acc[c][1][2 * pos + 1], wp[0], e[2][q + 2], wp[2], e[2][q + 1], wp[8], e[1][q + 2], wp[10], e[1][q + 1]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const int H = 2 * OH, W = 2 * OW;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t o = (((size_t)n * C + c) * H + 2 * a + ph) * W + 2 * b0;     // 16-byte aligned: b0 even, W % 4 == 0
+            float4 v = make_float4(acc[c][ph][0], acc[c][ph][1], acc[c][ph][2], acc[c][ph][3]);
+            if (dpre) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(dpre + o);
+                v.x *= swish_grad_(p4.x); v.y *= swish_grad_(p4.y); v.z *= swish_grad_(p4.z); v.w *= swish_grad_(p4.w);
+            }
+            if (out) *reinterpret_cast<float4 *>(out + o) = v;
+            if (act) *reinterpret_cast<float4 *>(act + o) = make_float4(swishf_(v.x), swishf_(v.y), swishf_(v.z), swishf_(v.w));
+        }
+    }
+}
+
 // block geometry and batch depth of convT_small3_kernel; false: the shape stays with convT_small2_kernel
 inline bool conv_small3_plan(const ConvGeom &g, Small3Geo &sg, int &depth, size_t &lds) {
     if (!MVAE_CONVT_SMALL3 || (g.OW & 1) || g.OW / 2 > 256) return false;
@@ -1345,6 +1463,24 @@ inline int conv_dgrad_small(const float *dy, const float *w, float *dx, float *a
         if (conv_small3_plan(g, sg, depth, lds3) && aligned16(dx ? dx : act) && (!dx || !act || aligned16(act)) &&
             (!dpre || aligned16(dpre)) && (2 * g.OW) % 4 == 0) {
             const dim3 grid3((g.B + sg.NI - 1) / sg.NI, sg.bands);
+            {
+                // the DMA form: pieces of 64 floats, at most 12 per channel image (three per wave), four channels per stage
+                const int nq = (sg.ch_stride + 63) / 64, qpw = (nq + 3) / 4;
+                const size_t ldsd = ((size_t)3 * 4 * nq * 64 + 256) * sizeof(float);
+                if (MVAE_SMALL3_DMA && g.Cout % 4 == 0 && qpw >= 2 && qpw <= 3 && ldsd <= 48 * 1024) {
+#define MVAE_S3DMA(CV)                                                                                                   \
+                    if (qpw == 2) hipLaunchKernelGGL((convT_small3d_kernel<CV, 4, 2>), grid3, blk, ldsd, st, dy, w, dx, act, dpre, g, sg); \
+                    else hipLaunchKernelGGL((convT_small3d_kernel<CV, 4, 3>), grid3, blk, ldsd, st, dy, w, dx, act, dpre, g, sg);
+                    switch (g.Cin) {
+                        case 1: MVAE_S3DMA(1) break;
+                        case 2: MVAE_S3DMA(2) break;
+                        case 3: MVAE_S3DMA(3) break;
+                        default: MVAE_S3DMA(4) break;
+                    }
+#undef MVAE_S3DMA
+                    return mvae_launch_status();
+                }
+            }
 #define MVAE_S3(CV, DV) hipLaunchKernelGGL((convT_small3_kernel<CV, DV>), grid3, blk, lds3, st, dy, w, dx, act, dpre, g, sg)
 #define MVAE_S3D(CV)                                                                                     \
             if (depth == 8) MVAE_S3(CV, 8); else if (depth == 4) MVAE_S3(CV, 4);                         \
