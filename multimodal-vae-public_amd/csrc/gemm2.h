@@ -420,6 +420,9 @@ __global__ __launch_bounds__(256) void g2_finish_kernel(E e, G2Args a) {
 // ---- host side
 struct G2Plan { int wm, wn, occ, stages; bool ok; size_t ws_floats; G2Args a; };
 
+#ifndef MVAE_G2_ACT_ONLY
+#define MVAE_G2_ACT_ONLY 1        // 0: A/B builds
+#endif
 #ifndef MVAE_G2
 #define MVAE_G2 1                 // 0: every launch stays on the round-1-5 kernels (A/B builds)
 #endif
@@ -479,7 +482,7 @@ inline G2Plan g2_plan(int I, int J, int K, int ncls, bool rowsum, int force_wm =
 //     the long-reduction weight gradients and loses as much on the short ones: the slabs of the cut tiles and the blocks
 //     running in lock-step through their epilogues cost what the balance gains) and stays where it was; the persistent
 //     modes remain reachable through MVAE_G2_FORCE in the tuning build.
-enum G2Hint { G2_PLAIN = 0, G2_FWD_TWO_OUTPUTS = 1, G2_CONV_FWD = 2 };
+enum G2Hint { G2_PLAIN = 0, G2_FWD_TWO_OUTPUTS = 1, G2_CONV_FWD = 2, G2_FWD_ACT_ONLY = 3 };
 inline G2Plan g2_plan_for(int I, int J, int K, int ncls, bool rowsum, void *ws, size_t ws_bytes, G2Hint hint = G2_PLAIN) {
     G2Plan none; none.ok = false;
     if (!MVAE_G2) return none;
@@ -490,7 +493,11 @@ inline G2Plan g2_plan_for(int I, int J, int K, int ncls, bool rowsum, void *ws, 
 #endif
     if (!fwm) {
         const long tiles64 = cdiv(I, 64) * cdiv(J, 64) * ncls;
-        if (!(hint == G2_FWD_TWO_OUTPUTS && K <= 640 && tiles64 >= 1536)) return none;
+        // ... and (MVAE_G2_ACT_ONLY) the forwards of a statistics-only pass, which keep the Swish output alone, over a very short
+        // reduction: celeba19's 4608 x 6400 x 100 (7200 tiles of four k-steps: prologue and epilogue are the launch)
+        const bool two = hint == G2_FWD_TWO_OUTPUTS && K <= 640 && tiles64 >= 1536;
+        const bool one = MVAE_G2_ACT_ONLY && hint == G2_FWD_ACT_ONLY && K <= 128 && tiles64 >= 1536;
+        if (!two && !one) return none;
         fwm = 1; fwn = 1; focc = -1;
     }
     G2Plan pl = g2_plan(I, J, K, ncls, rowsum, fwm, fwn, focc);

@@ -62,7 +62,7 @@ static int linear_fwd_impl(const float *x, int ldx, const float *w, const float 
     auto mp = [&](auto &p) { p.src = x; p.ld = ldx; p.R = M; p.Klen = K; p.cls_stride = gr.a; };
     auto mq = [&](auto &q) { q.src = w; q.ld = K; q.R = N; q.Klen = K; q.cls_stride = gr.b; };
     if (vec) {
-        G2Plan g2 = g2_plan_for(M, N, K, gr.G, false, ws, ws_bytes, (pre && act) ? G2_FWD_TWO_OUTPUTS : G2_PLAIN);
+        G2Plan g2 = g2_plan_for(M, N, K, gr.G, false, ws, ws_bytes, (pre && act) ? G2_FWD_TWO_OUTPUTS : (act && !pre && !mask) ? G2_FWD_ACT_ONLY : G2_PLAIN);
         if (g2.ok) return launch_gemm2<G2RowsK, G2RowsK, EpRowMajor, false>(g2, mp, mq, e, st);
     }
     if (vec) {
