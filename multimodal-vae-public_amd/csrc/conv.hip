@@ -844,24 +844,25 @@ inline bool conv_args_ok(int B, int Cin, int H, int W, int Cout, int stride, int
 //      outputs touch (two float2 + two scalars, clamped addresses and 0/1 factors: no load under a branch) and
 //      per tap reads the 32 weights of the group from LDS (transposed there once per block: [ci][tap][co], eight
 //      broadcast ds_read_b128 per 64 FMAs).  Outputs leave as float2 per channel. ----
-template <int CIN>
+// CG: output channels of a block's group (32; 16 for launches that would leave the chip half empty: conv_fwd_small)
+template <int CIN, int CG>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                              float *__restrict__ out, float *__restrict__ act,
                                                              const float *__restrict__ dpre, ConvGeom g, int total) {
-    __shared__ __attribute__((aligned(16))) float wl[CIN * 16 * 32];
-    const int cg = blockIdx.y * 32;
-    for (int j = threadIdx.x; j < CIN * 16 * 32; j += 256) {        // coalesced read of the group's rows, transposing store
+    __shared__ __attribute__((aligned(16))) float wl[CIN * 16 * CG];
+    const int cg = blockIdx.y * CG;
+    for (int j = threadIdx.x; j < CIN * 16 * CG; j += 256) {        // coalesced read of the group's rows, transposing store
         const int col = j / (CIN * 16), rem = j - col * (CIN * 16);  // rem = ci * 16 + tap
-        wl[rem * 32 + col] = (cg + col < g.Cout) ? w[(size_t)cg * CIN * 16 + j] : 0.f;
+        wl[rem * CG + col] = (cg + col < g.Cout) ? w[(size_t)cg * CIN * 16 + j] : 0.f;
     }
     __syncthreads();
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int OW2 = g.OW >> 1;
     const int ow0 = (idx % OW2) * 2, oh = (idx / OW2) % g.OH, n = idx / (OW2 * g.OH);
-    float acc[2][32];
+    float acc[2][CG];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { acc[0][c] = 0.f; acc[1][c] = 0.f; }
+    for (int c = 0; c < CG; ++c) { acc[0][c] = 0.f; acc[1][c] = 0.f; }
     const float lm = ow0 > 0 ? 1.f : 0.f, rm = ow0 + 2 < g.OW ? 1.f : 0.f;     // columns 2*ow0-1 and 2*ow0+4 inside?
     const int lo = ow0 > 0 ? -1 : 0, ro = ow0 + 2 < g.OW ? 4 : 3;              // clamped (always legal) offsets
     const float *img = x + (size_t)n * CIN * g.H * g.W + 2 * ow0;
@@ -885,10 +886,10 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__rest
         fetch(min(it + 1, CIN * 4 - 1));              // the last trip re-reads its own row: no load under a branch
 #pragma unroll
         for (int kw = 0; kw < 4; ++kw) {
-            const float4 *wp = reinterpret_cast<const float4 *>(wl + (it * 4 + kw) * 32);     // it * 4 = ci * 16 + kh * 4
+            const float4 *wp = reinterpret_cast<const float4 *>(wl + (it * 4 + kw) * CG);     // it * 4 = ci * 16 + kh * 4
             const float x0 = v[kw], x1 = v[kw + 2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < CG / 4; ++q) {
                 const float4 ww = wp[q];
                 acc[0][4 * q + 0] = fmaf(ww.x, x0, acc[0][4 * q + 0]); acc[1][4 * q + 0] = fmaf(ww.x, x1, acc[1][4 * q + 0]);
                 acc[0][4 * q + 1] = fmaf(ww.y, x0, acc[0][4 * q + 1]); acc[1][4 * q + 1] = fmaf(ww.y, x1, acc[1][4 * q + 1]);
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__rest
     }
     const int ohw = g.OH * g.OW;
     const size_t o0 = ((size_t)n * g.Cout + cg) * ohw + (size_t)oh * g.OW + ow0;
-    if (MVAE_SMALL_EPI_BATCH && dpre && cg + 32 <= g.Cout) {
+    if (MVAE_SMALL_EPI_BATCH && dpre && cg + CG <= g.Cout) {
         // the data-gradient use (ConvTranspose2d(64, 1) / (32, 3) backward, times the producer's Swish'): the producer's
         // pre-activations of EIGHT channels are fetched together, one batch ahead of the batch being finished.  In the
         // loop below every channel's load sits under its own block-uniform branches, hipcc waits for the whole memory
@@ -924,18 +925,22 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__rest
         __builtin_amdgcn_sched_barrier(0);
         finish8(pa, 0);
         __builtin_amdgcn_sched_barrier(0);
-        load8(pa, 16);
-        __builtin_amdgcn_sched_barrier(0);
-        finish8(pb, 8);
-        __builtin_amdgcn_sched_barrier(0);
-        load8(pb, 24);
-        __builtin_amdgcn_sched_barrier(0);
-        finish8(pa, 16);
-        finish8(pb, 24);
+        if constexpr (CG == 32) {
+            load8(pa, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            finish8(pb, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            load8(pb, 24);
+            __builtin_amdgcn_sched_barrier(0);
+            finish8(pa, 16);
+            finish8(pb, 24);
+        } else {
+            finish8(pb, 8);
+        }
         return;
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < CG; ++c) {
         if (cg + c < g.Cout) {                      // (no break: the accumulators must stay statically indexed)
             const size_t o = o0 + (size_t)c * ohw;
             float v0 = acc[0][c], v1 = acc[1][c];
@@ -951,16 +956,29 @@ inline bool conv_fwd_small_ok(const ConvGeom &g, const float *x, const float *pr
            g.OW % 2 == 0 && aligned8(x) && (!pre || aligned8(pre)) && (!act || aligned8(act)) && (!dpre || aligned8(dpre));
 }
 
+#ifndef MVAE_SMALL_FWD_CG16
+#define MVAE_SMALL_FWD_CG16 1     // 16-channel groups for launches with < 1024 blocks of 32 (0: A/B builds)
+#endif
 inline int conv_fwd_small(const float *x, const float *w, float *pre, float *act, const float *dpre, ConvGeom g,
                           hipStream_t st) {
     const int total = g.B * g.OH * (g.OW / 2);
-    const dim3 grid((total + 255) / 256, (g.Cout + 31) / 32), blk(256);
+    const dim3 blk(256);
+    dim3 grid((total + 255) / 256, (g.Cout + 31) / 32);
+    // A thread carries 64 accumulators and walks CIN * 4 dependent trips of six loads: with two blocks per CU (Conv2d(3, 32) at
+    // 256 images: 512 blocks) nothing covers a trip's latency -- 22.9 us re-issued hot, 31.5 us in the step, where x comes
+    // from HBM.  Half the channels per thread = twice the blocks.
+    const bool half = MVAE_SMALL_FWD_CG16 && g.Cout % 16 == 0 && (long)grid.x * grid.y < 1024;
+    if (half) grid.y = g.Cout / 16;
+#define MVAE_CSF(CV)                                                                                          \
+    if (half) hipLaunchKernelGGL((conv_small_fwd_kernel<CV, 16>), grid, blk, 0, st, x, w, pre, act, dpre, g, total); \
+    else hipLaunchKernelGGL((conv_small_fwd_kernel<CV, 32>), grid, blk, 0, st, x, w, pre, act, dpre, g, total);
     switch (g.Cin) {
-        case 1: hipLaunchKernelGGL(conv_small_fwd_kernel<1>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
-        case 2: hipLaunchKernelGGL(conv_small_fwd_kernel<2>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
-        case 3: hipLaunchKernelGGL(conv_small_fwd_kernel<3>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
-        default: hipLaunchKernelGGL(conv_small_fwd_kernel<4>, grid, blk, 0, st, x, w, pre, act, dpre, g, total); break;
+        case 1: MVAE_CSF(1) break;
+        case 2: MVAE_CSF(2) break;
+        case 3: MVAE_CSF(3) break;
+        default: MVAE_CSF(4) break;
     }
+#undef MVAE_CSF
     return mvae_launch_status();
 }
 
