@@ -402,12 +402,14 @@ def test_conv2d(B, Cin, H, Cout, s, p):
     assert_close(dw, 2 * w.grad, 'conv wgrad accumulate')
 
 
-@pytest.mark.parametrize('B,Cin,H,Cout', [(2049, 6, 14, 1), (512, 8, 32, 3), (1024, 4, 28, 2)])
+@pytest.mark.parametrize('B,Cin,H,Cout', [(2049, 6, 14, 1), (2049, 8, 14, 1), (2047, 64, 14, 1), (512, 8, 32, 3), (1024, 4, 28, 2)])
 def test_small_channel_transposed_conv_through_lds(B, Cin, H, Cout):
     """<= 4 output channels and >= 1024 blocks: the launch that stages the input rows through LDS (conv.hip:
     convT_small3_kernel) -- whole images per block with a ragged last block, 8 / 2 / 4 channels per trip; row bands of
     one image, the last band partial -- as a transposed conv forward and as the data gradient of the mirrored conv with
-    the producer's Swish' folded in."""
+    the producer's Swish' folded in.  Channel counts that are multiples of 4 take the LDS-DMA form (convT_small3d_kernel:
+    two / three pieces per wave, borders and the missing image of a ragged last block as out-of-range pieces), 6 the
+    register-staged one."""
     x = g(B, Cin, H, H, seed=40)
     w = g(Cin, Cout, 4, 4, seed=41, scale=(Cin * 4) ** -0.5)
     y = F.conv_transpose2d(x, w, None, 2, 1)
