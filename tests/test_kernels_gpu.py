@@ -425,7 +425,8 @@ def test_small_channel_transposed_conv_through_lds(B, Cin, H, Cout):
 
 
 CONVT_CASES = [(3, 256, 5, 128, 1, 0), (2, 128, 8, 64, 2, 1), (2, 64, 16, 32, 2, 1), (2, 32, 32, 3, 2, 1),
-               (4, 128, 7, 64, 2, 1), (3, 64, 14, 1, 2, 1), (2, 3, 2, 5, 1, 0)]
+               (4, 128, 7, 64, 2, 1), (3, 64, 14, 1, 2, 1), (2, 3, 2, 5, 1, 0),
+               (1923, 256, 5, 128, 1, 0)]     # >= 6144 blocks: the wide form of convT_s1_kernel, ragged last image group
 
 
 @pytest.mark.parametrize('B,Cin,H,Cout,s,p', CONVT_CASES)
