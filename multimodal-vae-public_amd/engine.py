@@ -151,9 +151,21 @@ class _StepBase(object):
         self._bucket0_done = False
         # independent stacks (image vs label side) run as two branches; each kernel here fills
         # well under the 256 CUs, so the branches overlap instead of queueing
-        n_streams = int(os.environ.get('MVAE_STREAMS', '2'))
+        n_streams = os.environ.get('MVAE_STREAMS', 'auto')
+        if n_streams == 'auto':
+            # conv stacks WITHOUT BatchNorm (FashionMNIST): the weight gradients are the step's longest launches (140-250 us
+            # each) and have no BatchNorm backward between them to pace the chain -- on streams of their own (4) the step
+            # is 2 % shorter than with the label branch's stream carrying them (2.082 -> 2.039 ms, x4 interleaved,
+            # profiles/r06_sched_ab.txt); with BatchNorm (CelebA +1.8 %, CelebA-19 0) and for the MLP stacks (MNIST +25 %:
+            # every fork is a cross-queue signal) two streams stay
+            mods = list(model.modules())
+            has_conv = any(isinstance(m, (L.Conv2d, L.ConvTranspose2d)) for m in mods)
+            has_bn = any(isinstance(m, L._BatchNormMixin) for m in mods)
+            # (MVAE_FUSE_ADAM=1, a non-default mode whose fused launches leave from the branch's own stream, keeps two)
+            n_streams = 4 if (has_conv and not has_bn and os.environ.get('MVAE_FUSE_ADAM', '0') != '1') else 2
+        n_streams = int(n_streams)
         self.side = torch.cuda.Stream(device=self.dev) if n_streams >= 2 else None
-        # MVAE_STREAMS=3/4 (tuning aid, off by default): each branch queues its weight-gradient
+        # MVAE_STREAMS=3/4 (the default only for conv stacks without BatchNorm, above): each branch queues its weight-gradient
         # launches (layers.backward_tape ``deferred``) and runs them with ONE fork per backward
         # chain on a further stream, so only the data-gradient chains stay serial.  Measured on
         # MI355X: no gain (MNIST B=512 0.58-0.60 vs 0.56 ms/step, CelebA B=256 3.54-3.67 vs 3.58) --
