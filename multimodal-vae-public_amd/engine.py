@@ -179,10 +179,11 @@ class _StepBase(object):
         # graph keeps the successor that was recorded first on its producer's queue (0-3 us behind it) and reaches
         # the other over a cross-queue edge (9-12 us).  MVAE_MAIN_FIRST=0: side branch first (rounds 1-2).
         self.main_first = os.environ.get('MVAE_MAIN_FIRST', '1') != '0'
-        # ... at the DECODER fork only when the image decoder is a conv stack (its chain is several times the label
-        # side's).  Two equal MLP decoders (MNIST): the side branch also carries both decoders' weight gradients and
-        # is the one that must not start late.  MVAE_MAIN_FIRST_DEC=0|1 overrides.
-        self.main_first_dec = os.environ.get('MVAE_MAIN_FIRST_DEC', 'auto')
+        # ... and at the DECODER fork.  Rounds 3-5 kept the side branch first there for two equal MLP decoders (MNIST: the
+        # side branch also carries both decoders' weight gradients, 'auto'); on round 6's kernels main-first is 1.3 %
+        # faster on MNIST as well (0.2699 -> 0.2663 ms, 6 of 6 interleaved rounds, profiles/r06_sched_ab.txt).
+        # MVAE_MAIN_FIRST_DEC=0|auto: side first always | unless the image decoder is a conv stack.
+        self.main_first_dec = os.environ.get('MVAE_MAIN_FIRST_DEC', '1')
         # a decoder that ends in a plain Linear: that launch also evaluates the reconstruction term (the logits never
         # reach memory); MVAE_LOSS_FOLD=0: Linear, then the loss kernel.  'image' / 'label': only that decoder.
         fold = os.environ.get('MVAE_LOSS_FOLD', '1')
