@@ -152,6 +152,7 @@ class _StepBase(object):
         # independent stacks (image vs label side) run as two branches; each kernel here fills
         # well under the 256 CUs, so the branches overlap instead of queueing
         n_streams = os.environ.get('MVAE_STREAMS', 'auto')
+        wg_batched_auto = False
         if n_streams == 'auto':
             # conv stacks WITHOUT BatchNorm (FashionMNIST): the weight gradients are the step's longest launches (140-250 us
             # each) and have no BatchNorm backward between them to pace the chain -- on streams of their own (4) the step
@@ -163,7 +164,14 @@ class _StepBase(object):
             has_bn = any(isinstance(m, L._BatchNormMixin) for m in mods)
             # (MVAE_FUSE_ADAM=1, a non-default mode whose fused launches leave from the branch's own stream, keeps two)
             n_streams = 4 if (has_conv and not has_bn and os.environ.get('MVAE_FUSE_ADAM', '0') != '1') else 2
-        self._streams_auto = n_streams == 4 and os.environ.get('MVAE_STREAMS', 'auto') == 'auto'
+            # ... and everywhere else ONE further stream that takes the label decoder's weight-gradient BATCH (one launch for
+            # its Linear layers + the conv closures) off the side stream, whose chain -- label decoder backward, then the label
+            # encoder's -- no longer waits behind it: MNIST 0.2660 -> 0.2600 ms (-2.3 %, 5 of 5 interleaved rounds), CelebA
+            # -0.4 %, CelebA-19 0 (profiles/r06_sched_ab.txt).  Single-GPU steps only: the data-parallel step sends its
+            # decoder bucket from the side stream behind that batch (_launch_deferred, capture).
+            if n_streams == 2 and os.environ.get('MVAE_FUSE_ADAM', '0') != '1' and os.environ.get('MVAE_PAIR_ENC', '0') != '1':
+                n_streams, wg_batched_auto = 3, True
+        self._streams_auto = os.environ.get('MVAE_STREAMS', 'auto') == 'auto' and int(n_streams) > 2
         n_streams = int(n_streams)
         self.side = torch.cuda.Stream(device=self.dev) if n_streams >= 2 else None
         # MVAE_STREAMS=3/4 (the default only for conv stacks without BatchNorm, above): each branch queues its weight-gradient
@@ -198,6 +206,8 @@ class _StepBase(object):
         self.batch_repack = os.environ.get('MVAE_BATCH_REPACK', '1') != '0'
         self._conv_mods = [m for m in model.modules() if isinstance(m, (L.Conv2d, L.ConvTranspose2d))]
         self.wg_main = torch.cuda.Stream(device=self.dev) if n_streams >= 3 else None
+        # the branches keep their batched weight-gradient launches and the label decoder's batch runs on the further stream
+        self.wg_batched = os.environ.get('MVAE_WG_BATCHED', '1' if wg_batched_auto else '0') == '1'
         self.wg_side = torch.cuda.Stream(device=self.dev) if n_streams >= 4 else self.wg_main
         self._wg_pending = []
         self._forked = False
@@ -235,7 +245,7 @@ class _StepBase(object):
         """The list a backward chain queues its weight-gradient launches in (None: launch inline).  Default:
         a ``layers.WgradBatch`` -- the chain's Linear weight gradients leave as ONE launch when the chain is
         done (MVAE_BATCH_WGRAD=0: inline, one launch per layer)."""
-        if self.wg_main is not None:
+        if self.wg_main is not None and not self.wg_batched:
             return []
         return L.WgradBatch(adam=self._fusion) if self.batch_wgrad else None
 
@@ -245,15 +255,19 @@ class _StepBase(object):
         hipGraph capture (ROCm 7.0) crashes in EndCapture when a fork of a fork joins back into
         its parent (tools/graph_fork_probe.py: 'nested' vs 'nested_join_main').  A ``WgradBatch`` is
         flushed on the current stream instead."""
-        if isinstance(fns, L.WgradBatch):
+        if isinstance(fns, L.WgradBatch) and not (self.wg_batched and stream is not None and len(fns)
+                                                 and self._comm is None and self.on_bucket_ready is None):
             fns.flush()
             return
         if not fns:
             return
         stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(stream):
-            for fn in fns:
-                fn()
+            if isinstance(fns, L.WgradBatch):
+                fns.flush()                 # MVAE_WG_BATCHED=1: the batch (one Linear launch + the conv closures) on the weight-gradient stream
+            else:
+                for fn in fns:
+                    fn()
         self._carry.setdefault('deferred', []).append(fns)     # the closures own the gradients
         if stream not in self._wg_pending:
             self._wg_pending.append(stream)
