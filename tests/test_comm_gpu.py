@@ -18,7 +18,7 @@ from mvae_amd.optim import FusedAdam
 from mvae_amd.parallel import DataParallel, RcclBuckets, RcclComm
 from oracle import steps as OS
 from test_engine_gpu import build_pair
-from util import assert_close
+from util import assert_close, init_world1
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
@@ -26,10 +26,7 @@ DEV = torch.device('cuda', 0)
 
 @pytest.fixture(scope='module')
 def world1():
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=DEV)
+    init_world1('nccl', DEV)
     yield
     dist.destroy_process_group()
 

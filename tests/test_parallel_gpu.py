@@ -30,9 +30,8 @@ def _free_port():
 
 @pytest.fixture
 def nccl_world1():
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(_free_port())
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from util import init_world1
+    init_world1('nccl', torch.device('cuda', 0))
     yield
     dist.destroy_process_group()
 

@@ -35,10 +35,8 @@ N_ATTRS = 18
 
 @pytest.fixture(scope='module')
 def rccl_world1():
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from util import init_world1
+    init_world1('nccl', torch.device('cuda', 0))
     yield
     dist.destroy_process_group()
 

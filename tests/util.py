@@ -80,3 +80,24 @@ REDRAWS = []
 def note_redraws(test, n):
     if n:
         REDRAWS.append((test, int(n)))
+
+
+def init_world1(backend='nccl', device_id=None, attempts=5):
+    """torch.distributed at world size 1 on a fresh local port.  A port that was free a moment ago can be taken by the time the
+    store binds it (seen once on a shared box: EADDRINUSE right behind the data-parallel bench runs): take another one."""
+    import os
+    import socket
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    for attempt in range(attempts):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ['MASTER_PORT'] = str(port)
+        try:
+            if device_id is not None:
+                dist.init_process_group(backend, rank=0, world_size=1, device_id=device_id)
+            else:
+                dist.init_process_group(backend, rank=0, world_size=1)
+            return port
+        except (RuntimeError, OSError):        # DistNetworkError is a RuntimeError
+            if attempt == attempts - 1:
+                raise
