@@ -1042,15 +1042,10 @@ class BimodalStep(_StepBase):
                 # stay referenced until the streams have joined, or the allocator hands their memory to this
                 # stream's next launches while the weight-gradient kernel is still queued
                 c['wgrad_on_side_keep'] = list(wi)
-                # MVAE_WG_IMG=1 (experiment): with the third stream of the single-GPU step, this batch goes there as well
-                ws = self.side
-                if (os.environ.get('MVAE_WG_IMG', '0') == '1' and self.wg_batched and self.wg_main is not None and not dp_side
-                        and self._comm is None and self.on_bucket_ready is None and getattr(self, '_adam_split', None) is None):
-                    ws = self.wg_main
-                    if ws not in self._wg_pending:
-                        self._wg_pending.append(ws)
-                with torch.cuda.stream(ws):
-                    ws.wait_event(ev_img)
+                # (with the third stream of the single-GPU step this batch was tried there as well: MNIST +10 %, CelebA +0.7 %,
+                #  profiles/r06_sched_ab.txt -- it stays on the side stream, behind the label decoder's chain)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev_img)
                     wi.flush()
                     if getattr(self, '_adam_split', None) is not None:
                         ev_dec = torch.cuda.Event()
