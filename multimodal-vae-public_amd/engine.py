@@ -1142,6 +1142,20 @@ class BimodalStep(_StepBase):
             else:
                 L.backward_tape(m.image_encoder.plan(), c['tape_img'], g_heads_img, deferred=wi)
             if isinstance(wi, L.WgradBatch):
+                if (os.environ.get('MVAE_TAIL_LANES', '1') == '1' and self.wg_batched and self.wg_main is not None
+                        and self._comm is None and self.on_bucket_ready is None):
+                    # the image encoder's batch is the step's tail -- on CelebA 140 us of conv weight gradients and their finish
+                    # launches one after the other, nothing beside them: every other conv closure goes to the third stream
+                    # (CelebA -0.25 %, 3 of 3 interleaved rounds, profiles/r06_sched_ab.txt; MNIST has no closures)
+                    lane, keep, k = L.WgradBatch(adam=wi.adam), [], 0
+                    for e in list(wi):
+                        if not isinstance(e, tuple):
+                            (lane if k % 2 else keep).append(e)
+                            k += 1
+                        else:
+                            keep.append(e)
+                    wi[:] = keep
+                    self._launch_deferred(lane, self.wg_main)
                 wi.flush()
                 wi = None
             if fork is not None:
